@@ -1,0 +1,94 @@
+/*
+ * rlr_engine.h -- host-side mirror of the reference's operator interface for the hot
+ * path, layered on the device ABI of rlr_gpu.h.  It is what RagEngine::search /
+ * search_with_diversity / get_embedding_candidates (rust-local-rag
+ * src/rag_engine.rs:470-701, :717-759, :415-461) do between "query embedding obtained"
+ * (:493) and "results handed back" -- same names, argument meaning and edge-case
+ * behaviour -- written in C++ because this image has no Rust toolchain.  A Rust host
+ * binds rlr_gpu.h directly and keeps its own copy of this logic.
+ *
+ * Everything that is not the hot path stays with the caller: the query string ->
+ * embedding step (embeddings.rs), BM25 (`LexicalIndex::score`, passed in as
+ * (row, score) pairs), the LLM reranker and chunk metadata.
+ */
+#ifndef RLR_ENGINE_H
+#define RLR_ENGINE_H
+
+#include "rlr_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* QueryWeights (rag_engine.rs:1846-1865): optional per-query overrides. */
+typedef struct rlr_query_weights {
+    int32_t has_embedding;
+    float embedding;
+    int32_t has_lexical;
+    float lexical;
+    int32_t has_reranker;
+    float reranker;
+    int32_t has_initial;
+    float initial;
+} rlr_query_weights;
+
+/* ResolvedWeights (rag_engine.rs:1877-1896) */
+typedef struct rlr_resolved_weights {
+    float embedding, lexical, reranker, initial;
+} rlr_resolved_weights;
+
+/* SearchResult's numeric fields (rag_engine.rs:72-100); `row` stands in for chunk_id. */
+typedef struct rlr_search_hit {
+    uint64_t row;
+    float score;           /* = initial_score when no reranker ran (:682) */
+    float embedding_score; /* raw cosine (:689) */
+    float lexical_score;   /* bm25 / max_bm25, 0 if the row is not a lexical candidate (:527-530) */
+    float initial_score;   /* w_e * embedding + w_l * lexical (:531-532) */
+} rlr_search_hit;
+
+/* API-layer constants (mcp_server.rs:85-86, :359-364) */
+#define RLR_MAX_TOP_K 100
+#define RLR_DEFAULT_TOP_K 5
+#define RLR_DEFAULT_DIVERSITY 0.3f
+
+/* resolve_weight (rag_engine.rs:1869-1873): override if finite and in [0,1], else default */
+float rlr_resolve_weight(int32_t has_override, float w, float dflt);
+/* ResolvedWeights::from_query_weights (:1888-1895); defaults 0.7/0.3/0.7/0.3 or the
+ * RAG_{EMBEDDING,LEXICAL,RERANKER,INITIAL_SCORE}_WEIGHT environment (:1813-1841), cached
+ * on first use like the reference's OnceLock. `w` may be NULL. */
+void rlr_resolve_weights(const rlr_query_weights *w, rlr_resolved_weights *out);
+/* normalize (rag_engine.rs:1763-1771), host side, reference order. */
+void rlr_normalize(float *v, size_t n);
+
+/* RagEngine::search, exact-scan branch, reranker absent.
+ *   query_raw/dq  raw query embedding (normalised here, :494; zip-truncated or
+ *                 zero-extended to the index dim like dot_product's zip, :1778)
+ *   top_k         0 is treated as 1 (:490)
+ *   lex_*         LexicalIndex::score output as (row, bm25) pairs, may be empty
+ *   stage         0: final results, min(top_k, N) hits (:667-698)
+ *                 1: the initial_k = min(N, max(3*top_k, top_k)) candidates a reranker
+ *                    would receive (:544-561)
+ * Ordering: (initial_score desc, row asc), NaN last -- the build's definition of the
+ * reference's unspecified tie order. */
+int32_t rlr_engine_search(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_t top_k,
+                          const rlr_query_weights *weights, const uint64_t *lex_rows,
+                          const float *lex_scores, uint32_t n_lex, int32_t stage,
+                          rlr_search_hit *out, uint32_t cap, uint32_t *n_out);
+
+/* RagEngine::search_with_diversity (:717-759): clamp lambda, lambda == 0 -> search,
+ * else pool = max(3k, k+10), search(pool), MMR on the GPU. */
+int32_t rlr_engine_search_with_diversity(rlr_index *idx, const float *query_raw, uint32_t dq,
+                                         uint32_t top_k, float diversity_factor,
+                                         const rlr_query_weights *weights, const uint64_t *lex_rows,
+                                         const float *lex_scores, uint32_t n_lex,
+                                         rlr_search_hit *out, uint32_t cap, uint32_t *n_out);
+
+/* RagEngine::get_embedding_candidates (:415-461), `None` arm: top `count` by cosine. */
+int32_t rlr_engine_embedding_candidates(rlr_index *idx, const float *query_raw, uint32_t dq,
+                                        uint32_t count, uint64_t *rows_out, float *scores_out,
+                                        uint32_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLR_ENGINE_H */

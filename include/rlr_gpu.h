@@ -1,0 +1,173 @@
+/*
+ * rlr_gpu.h -- C ABI of the MI355X-native search_documents hot path.
+ *
+ * This is the drop-in boundary: the entry points below are exactly what a Rust
+ * `extern "C"` block in rust-local-rag's src/rag_engine.rs would bind (see
+ * INTEGRATION.md for the binding and the patch).  The reference has no FFI /
+ * plugin seam of its own for this path (the scan is inline in
+ * `RagEngine::search`), so every function cites the reference lines it
+ * replaces.  Paths are relative to the reference repository root.
+ *
+ * Conventions
+ *   - plain C: opaque handle, pointers and sizes only; no exceptions cross it.
+ *   - every function returns an int32 status: RLR_OK (0) or a negative code;
+ *     rlr_last_error() returns a thread-local message for the last failure.
+ *   - the caller owns every buffer it passes; the library owns only what sits
+ *     behind the opaque handle.
+ *   - rows are dense, row-major, `dim` elements each; row numbers are the
+ *     position in upload/append order ("row" <-> chunk_id table stays with the
+ *     host, src/rag_engine.rs:105).
+ *   - thread-safety mirrors the reference's tokio RwLock (mcp_server.rs:89,
+ *     worker.rs:397-399): search / score / fetch / mmr calls may run
+ *     concurrently from any number of OS threads; mutators (upload, append,
+ *     delete, fill, reserve, destroy) need external exclusion.
+ *   - there is NO CPU fallback inside the library: with no usable GPU every
+ *     compute entry point returns RLR_E_NO_DEVICE.
+ */
+#ifndef RLR_GPU_H
+#define RLR_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLR_VERSION 100 /* 0.1.0 */
+
+typedef struct rlr_index rlr_index;
+
+enum rlr_status {
+    RLR_OK = 0,
+    RLR_E_INVALID = -1,   /* bad argument */
+    RLR_E_NO_DEVICE = -2, /* no usable HIP device / device id out of range */
+    RLR_E_HIP = -3,       /* a HIP runtime call failed (message in rlr_last_error) */
+    RLR_E_OOM = -4,       /* device or pinned-host allocation failed */
+    RLR_E_RANGE = -5,     /* a row number is >= the index size */
+    RLR_E_INTERNAL = -6
+};
+
+enum rlr_dtype {
+    RLR_F32 = 0, /* rows stored as IEEE binary32 (the reference's Vec<f32>, rag_engine.rs:51) */
+    RLR_F16 = 1  /* rows rounded to binary16 after normalisation; arithmetic on the widened values */
+};
+
+/* ---- library ---------------------------------------------------------- */
+int32_t rlr_version(void);
+/* number of visible HIP devices (0 when the runtime reports none) */
+int32_t rlr_device_count(void);
+const char *rlr_last_error(void);
+/* guard band the approximate scan uses for a given dim: an upper
+ * bound on |wavefront-order dot - reference-order dot| for unit-norm operands. */
+float rlr_default_guard_eps(uint32_t dim);
+
+/* ---- index lifetime and mutation --------------------------------------- */
+/* replaces: the `chunks: HashMap<String, DocumentChunk>` embedding storage
+ * (rag_engine.rs:46-59, :105) by one dense row-major matrix in HBM. */
+int32_t rlr_index_create(uint32_t dim, int32_t dtype, int32_t device_id, rlr_index **out);
+int32_t rlr_index_destroy(rlr_index *idx);
+int32_t rlr_index_info(const rlr_index *idx, uint64_t *n_rows, uint32_t *dim, int32_t *dtype,
+                       int32_t *device_id);
+int32_t rlr_index_reserve(rlr_index *idx, uint64_t n_rows);
+
+/* Replace all rows.  rows: n_rows x dim f32, host memory.
+ * normalize_on_device != 0 applies the reference `normalize` (rag_engine.rs:1763-1771:
+ * sequential sum of squares, skip if <= 1e-20, true division by sqrtf) to every row on
+ * the GPU, bit-identically -- the bulk re-normalise-on-load site rag_engine.rs:1675-1680.
+ * With 0 the rows are stored as given (already normalised by the host, :358-359). */
+int32_t rlr_index_upload(rlr_index *idx, const float *rows, uint64_t n_rows,
+                         int32_t normalize_on_device);
+/* Append rows (site rag_engine.rs:379-384); *first_row_out = row number of rows[0]. */
+int32_t rlr_index_append(rlr_index *idx, const float *rows, uint64_t n_rows,
+                         int32_t normalize_on_device, uint64_t *first_row_out);
+/* Delete rows (site `chunks.retain(..)` rag_engine.rs:347-348, :265-266).  Stable
+ * compaction: surviving rows keep their relative order and are renumbered densely, i.e.
+ * new_row = old_row - |{deleted d : d < old_row}|.  Duplicates in `rows` are ignored. */
+int32_t rlr_index_delete_rows(rlr_index *idx, const uint64_t *rows, uint64_t n);
+/* Fill the index with the deterministic synthetic corpus of SURVEY.md 8(d) without
+ * crossing PCIe: rows [row0, row0+n_rows) of stream `seed` (integer-only generator,
+ * bit-identical to oracle/rlr_oracle.c:rlr_o_synth_rows), reference-normalised, then
+ * rounded to the index dtype.  Benchmark / test support. */
+int32_t rlr_index_fill_synthetic(rlr_index *idx, uint64_t n_rows, uint64_t row0, uint64_t seed,
+                                 uint32_t n_clusters);
+
+/* ---- the hot path ------------------------------------------------------- */
+/* Brute-force cosine scan + top-k.
+ * replaces: the exact-scan branch of RagEngine::search, rag_engine.rs:496-503 (ids = all
+ * chunks) + :524-545 (dot per chunk, sort desc, take) and get_embedding_candidates
+ * :431-445.
+ *   queries   n_queries x dim f32, host memory, ALREADY normalised by the caller in
+ *             reference order (rag_engine.rs:494) -- 3 KB, stays on the host so the staged
+ *             query is bit-identical.
+ *   k         results wanted per query (clamped to the index size).
+ *   guard_eps half-width of the guard band; < 0 selects rlr_default_guard_eps(dim).
+ *   rows_out  n_queries x k row numbers, cos_out n_queries x k scores, n_out[q] = count.
+ * Result per query: the k rows with the largest reference-order dot product
+ * (dot_product, rag_engine.rs:1777-1779), scores bit-identical to it, ordered by
+ * (score desc, row asc); NaN scores order last.  The wavefront-order scan only
+ * nominates candidates (everything within the guard band of the k-th score); the
+ * nominated rows are re-scored on the GPU in strict reference order before the final
+ * ordering, so the band never leaks into the result. */
+int32_t rlr_search_topk(rlr_index *idx, const float *queries, uint32_t n_queries, uint32_t k,
+                        float guard_eps, uint64_t *rows_out, float *cos_out, uint32_t *n_out);
+
+/* Reference-order dot product of one query with the listed rows (the <= 5*top_k lexical
+ * candidates of rag_engine.rs:505-509, whose embedding score the hybrid blend needs).
+ * replaces: dot_product(&query_embedding, &chunk.embedding) rag_engine.rs:526. */
+int32_t rlr_score_rows(rlr_index *idx, const float *query, const uint64_t *rows, uint32_t n,
+                       float *cos_out);
+
+/* Copy rows back to the host as f32 (exact values; fp16 rows are widened).
+ * replaces: the `chunk.embedding.clone()` re-lookups rag_engine.rs:559, :742-753. */
+int32_t rlr_fetch_rows(rlr_index *idx, const uint64_t *rows, uint32_t n, float *out);
+
+/* Maximal-marginal-relevance selection over a candidate pool that lives in the index.
+ * replaces: RagEngine::mmr_diversify, rag_engine.rs:767-839 (greedy loop :788-835).
+ *   pool_rows / pool_scores  P candidates in the order `search` returned them (the
+ *             reference's visiting order; swap_remove perturbs it exactly as :783, :825)
+ *   k         results wanted (k == 0 still yields the first candidate, as :782-785)
+ *   lambda    diversity factor, already clamped by the caller (:725)
+ *   order_out indices into the pool in pick order; mmr_out (nullable) the MMR value of
+ *             each pick (NaN for the first); *n_out = number of picks.
+ * Pairwise similarities are reference-order dot products computed on the GPU, so the
+ * pick sequence and MMR values are bit-identical to the reference loop. */
+int32_t rlr_mmr_select(rlr_index *idx, const uint64_t *pool_rows, const float *pool_scores,
+                       uint32_t P, uint32_t k, float lambda, uint32_t *order_out, float *mmr_out,
+                       uint32_t *n_out);
+
+/* ---- device-resident variant (multi-GPU sharding) ------- */
+/* Same search, but the per-query result stays in device memory so the caller can hand it
+ * to an RCCL all-gather without a host round trip.
+ *   d_packed_out  device pointer, n_queries x k uint64: (ordered-score-bits << 32) |
+ *                 (0xFFFFFFFF - local_row); descending u64 order == (score desc, row asc).
+ *                 Unused tail entries are 0.
+ *   stream        hipStream_t the caller will consume the result on (may be NULL = the
+ *                 null stream); the library makes its work visible to that stream. */
+int32_t rlr_search_topk_device(rlr_index *idx, const float *queries, uint32_t n_queries,
+                               uint32_t k, float guard_eps, void *d_packed_out, void *stream);
+/* helpers for the packed format (host side) */
+uint64_t rlr_pack_result(float score, uint32_t row);
+void rlr_unpack_result(uint64_t packed, float *score, uint32_t *row);
+
+/* ---- measurement hooks --------------------------------------------------- */
+typedef struct rlr_profile {
+    uint64_t n_searches;   /* rlr_search_topk* calls (queries, not batches) since reset */
+    uint64_t n_scan_launches;
+    double scan_ms;        /* sum of HIP-event durations of the scan kernel, on its stream */
+    double select_ms;      /* histogram / threshold / collect kernels */
+    double rescore_ms;     /* reference-order re-score + final sort */
+    double total_ms;       /* first launch -> results ready, per call, summed */
+    uint64_t scan_bytes;   /* algorithmic bytes the scan launches covered (rows*dim*elem) */
+    uint64_t n_candidates; /* rows nominated by the guard band, summed */
+    uint64_t n_retries;    /* band overflow retries */
+} rlr_profile;
+/* enable != 0: record HIP events around each stage on the stream it is launched on
+ * (adds one event pair per stage).  Disabled by default. */
+int32_t rlr_profile_enable(rlr_index *idx, int32_t enable);
+int32_t rlr_profile_read(rlr_index *idx, rlr_profile *out, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLR_GPU_H */

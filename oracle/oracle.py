@@ -1,0 +1,202 @@
+"""ctypes binding of the CPU oracle (oracle/rlr_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (rust-local-rag_amd/) never
+imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "librlr_oracle.so")
+
+_f32p = C.POINTER(C.c_float)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "rlr_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.rlr_o_normalize.argtypes = [_f32p, C.c_size_t]
+        L.rlr_o_normalize.restype = None
+        L.rlr_o_dot.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t]
+        L.rlr_o_dot.restype = C.c_float
+        L.rlr_o_cosine.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t]
+        L.rlr_o_cosine.restype = C.c_float
+        L.rlr_o_resolve_weight.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.rlr_o_resolve_weight.restype = C.c_float
+        L.rlr_o_scan.argtypes = [_f32p, C.c_size_t, C.c_size_t, _f32p, C.c_size_t, _f32p]
+        L.rlr_o_scan.restype = None
+        L.rlr_o_scan_mt.argtypes = [_f32p, C.c_size_t, C.c_size_t, _f32p, C.c_size_t, _f32p, C.c_int]
+        L.rlr_o_scan_mt.restype = None
+        L.rlr_o_search.argtypes = [
+            _f32p, C.c_size_t, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
+            _u64p, _f32p, C.c_size_t, C.c_int, C.c_int, _u64p, _f32p, _f32p, _f32p, C.c_size_t]
+        L.rlr_o_search.restype = C.c_size_t
+        L.rlr_o_embedding_candidates.argtypes = [
+            _f32p, C.c_size_t, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, _u64p, _f32p]
+        L.rlr_o_embedding_candidates.restype = C.c_size_t
+        L.rlr_o_mmr.argtypes = [_f32p, _f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, _u32p, _f32p]
+        L.rlr_o_mmr.restype = C.c_size_t
+        L.rlr_o_search_with_diversity.argtypes = [
+            _f32p, C.c_size_t, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
+            C.c_float, _u64p, _f32p, C.c_size_t, C.c_int, _u64p, _f32p, _f32p, _f32p, C.c_size_t]
+        L.rlr_o_search_with_diversity.restype = C.c_size_t
+        L.rlr_o_synth_raw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.rlr_o_synth_raw.restype = C.c_float
+        L.rlr_o_synth_rows.argtypes = [_f32p, C.c_uint64, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint32]
+        L.rlr_o_synth_rows.restype = None
+        L.rlr_o_f32_to_f16.argtypes = [C.c_float]
+        L.rlr_o_f32_to_f16.restype = C.c_uint16
+        L.rlr_o_f16_to_f32.argtypes = [C.c_uint16]
+        L.rlr_o_f16_to_f32.restype = C.c_float
+        L.rlr_o_round_rows_f16.argtypes = [_f32p, C.c_size_t]
+        L.rlr_o_round_rows_f16.restype = None
+        L.rlr_o_build_flags.argtypes = []
+        L.rlr_o_build_flags.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_f32p)
+
+
+def normalize(v) -> np.ndarray:
+    v = _f32(v).copy()
+    lib().rlr_o_normalize(_p(v), v.size)
+    return v
+
+
+def dot(a, b) -> float:
+    a, b = _f32(a), _f32(b)
+    return float(lib().rlr_o_dot(_p(a), a.size, _p(b), b.size))
+
+
+def cosine(a, b) -> float:
+    a, b = _f32(a), _f32(b)
+    return float(lib().rlr_o_cosine(_p(a), a.size, _p(b), b.size))
+
+
+def resolve_weight(override, default) -> float:
+    has = override is not None
+    return float(lib().rlr_o_resolve_weight(int(has), float(override) if has else 0.0, float(default)))
+
+
+def scan(rows, q, threads: int = 1) -> np.ndarray:
+    rows, q = _f32(rows), _f32(q)
+    n, d = rows.shape
+    out = np.empty(n, dtype=np.float32)
+    if threads > 1:
+        lib().rlr_o_scan_mt(_p(rows), n, d, _p(q), q.size, _p(out), threads)
+    else:
+        lib().rlr_o_scan(_p(rows), n, d, _p(q), q.size, _p(out))
+    return out
+
+
+def _lex(lex):
+    if lex:
+        lr = np.ascontiguousarray([r for r, _ in lex], dtype=np.uint64)
+        ls = np.ascontiguousarray([s for _, s in lex], dtype=np.float32)
+    else:
+        lr = np.zeros(1, dtype=np.uint64)
+        ls = np.zeros(1, dtype=np.float32)
+    return lr, ls, (len(lex) if lex else 0)
+
+
+def search(rows, q_raw, top_k, w_e=0.7, w_l=0.3, lex=None, normalize_query=True, stage=0):
+    """-> (rows u64[k], combined f32[k], embedding f32[k], lexical f32[k])"""
+    rows, q = _f32(rows), _f32(q_raw)
+    n, d = rows.shape if rows.ndim == 2 else (0, 0)
+    cap = max(3 * max(top_k, 1), 1)
+    o_r = np.zeros(cap, dtype=np.uint64)
+    o_c, o_e, o_l = (np.zeros(cap, dtype=np.float32) for _ in range(3))
+    lr, ls, nl = _lex(lex)
+    k = lib().rlr_o_search(_p(rows), n, d, _p(q), q.size, top_k, w_e, w_l,
+                           lr.ctypes.data_as(_u64p), _p(ls), nl, int(normalize_query), stage,
+                           o_r.ctypes.data_as(_u64p), _p(o_c), _p(o_e), _p(o_l), cap)
+    return o_r[:k], o_c[:k], o_e[:k], o_l[:k]
+
+
+def embedding_candidates(rows, q_raw, count):
+    rows, q = _f32(rows), _f32(q_raw)
+    n, d = rows.shape
+    o_r = np.zeros(max(count, 1), dtype=np.uint64)
+    o_e = np.zeros(max(count, 1), dtype=np.float32)
+    k = lib().rlr_o_embedding_candidates(_p(rows), n, d, _p(q), q.size, count,
+                                         o_r.ctypes.data_as(_u64p), _p(o_e))
+    return o_r[:k], o_e[:k]
+
+
+def mmr(emb, scores, top_k, lam):
+    """-> (order u32[k] indices into the candidate list, mmr f32[k])"""
+    emb, scores = _f32(emb), _f32(scores)
+    P = scores.size
+    d = emb.shape[1] if emb.ndim == 2 and P else 0
+    order = np.zeros(max(P, 1), dtype=np.uint32)
+    mm = np.zeros(max(P, 1), dtype=np.float32)
+    k = lib().rlr_o_mmr(_p(emb), _p(scores), P, d, top_k, lam, order.ctypes.data_as(_u32p), _p(mm))
+    return order[:k], mm[:k]
+
+
+def search_with_diversity(rows, q_raw, top_k, diversity, w_e=0.7, w_l=0.3, lex=None,
+                          normalize_query=True):
+    rows, q = _f32(rows), _f32(q_raw)
+    n, d = rows.shape if rows.ndim == 2 else (0, 0)
+    cap = max(3 * max(top_k, 1), top_k + 10)
+    o_r = np.zeros(cap, dtype=np.uint64)
+    o_c, o_e, o_l = (np.zeros(cap, dtype=np.float32) for _ in range(3))
+    lr, ls, nl = _lex(lex)
+    k = lib().rlr_o_search_with_diversity(
+        _p(rows), n, d, _p(q), q.size, top_k, diversity, w_e, w_l,
+        lr.ctypes.data_as(_u64p), _p(ls), nl, int(normalize_query),
+        o_r.ctypes.data_as(_u64p), _p(o_c), _p(o_e), _p(o_l), cap)
+    return o_r[:k], o_c[:k], o_e[:k], o_l[:k]
+
+
+def synth_rows(n, d, seed, row0=0, n_clusters=0, f16=False) -> np.ndarray:
+    out = np.empty((n, d), dtype=np.float32)
+    lib().rlr_o_synth_rows(_p(out), row0, n, d, seed, n_clusters)
+    if f16:
+        lib().rlr_o_round_rows_f16(_p(out), out.size)
+    return out
+
+
+def synth_query(d, seed) -> np.ndarray:
+    """raw (un-normalised) query: generator row 0 of the stream `seed`, before normalize()."""
+    L = lib()
+    return np.array([L.rlr_o_synth_raw(seed, 0, c, d, 0) for c in range(d)], dtype=np.float32)
+
+
+def f32_to_f16_bits(a) -> np.ndarray:
+    a = _f32(a).ravel()
+    L = lib()
+    return np.array([L.rlr_o_f32_to_f16(float(x)) for x in a], dtype=np.uint16)
+
+
+def round_f16(a) -> np.ndarray:
+    a = _f32(a).copy()
+    lib().rlr_o_round_rows_f16(_p(a), a.size)
+    return a

@@ -1,0 +1,334 @@
+// engine.cpp -- host-side mirror of RagEngine::search / search_with_diversity /
+// get_embedding_candidates (reference src/rag_engine.rs:470-701, :717-759, :415-461),
+// orchestrating the device entry points of rlr_gpu.h.  Host arithmetic here is the
+// reference's (this file is compiled with -ffp-contract=off; no FMA, no reassociation).
+// No dot product over corpus rows is ever computed on the host: cosines come from
+// rlr_search_topk / rlr_score_rows, MMR from rlr_mmr_select.
+#include "../../include/rlr_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+constexpr float kDefaultEmbeddingWeight = 0.7f; // rag_engine.rs:1801-1804
+constexpr float kDefaultLexicalWeight = 0.3f;
+constexpr float kDefaultRerankerWeight = 0.7f;
+constexpr float kDefaultInitialWeight = 0.3f;
+
+bool weight_ok(float w)
+{
+    return std::isfinite(w) && w >= 0.0f && w <= 1.0f;
+}
+
+// parse_weight (rag_engine.rs:1813-1819)
+float parse_weight(const char *env, float dflt)
+{
+    const char *s = std::getenv(env);
+    if (!s || !*s)
+        return dflt;
+    char *end = nullptr;
+    const float w = std::strtof(s, &end);
+    if (end == s || *end != '\0' || !weight_ok(w))
+        return dflt;
+    return w;
+}
+
+rlr_resolved_weights g_defaults;
+std::once_flag g_defaults_once;
+
+const rlr_resolved_weights &cached_defaults()
+{
+    std::call_once(g_defaults_once, [] {
+        g_defaults.embedding = parse_weight("RAG_EMBEDDING_WEIGHT", kDefaultEmbeddingWeight);
+        g_defaults.lexical = parse_weight("RAG_LEXICAL_WEIGHT", kDefaultLexicalWeight);
+        g_defaults.reranker = parse_weight("RAG_RERANKER_WEIGHT", kDefaultRerankerWeight);
+        g_defaults.initial = parse_weight("RAG_INITIAL_SCORE_WEIGHT", kDefaultInitialWeight);
+    });
+    return g_defaults;
+}
+
+struct Cand {
+    uint64_t row;
+    float c, e, l;
+};
+
+// (combined desc, row asc), NaN last
+bool cand_before(const Cand &a, const Cand &b)
+{
+    const bool an = std::isnan(a.c), bn = std::isnan(b.c);
+    if (an || bn) {
+        if (an != bn)
+            return bn;
+        return a.row < b.row;
+    }
+    if (a.c != b.c)
+        return a.c > b.c;
+    return a.row < b.row;
+}
+
+float combine(const rlr_resolved_weights &w, float e, float l)
+{
+    const float t0 = w.embedding * e; // :531-532, two rounded products then one add
+    const float t1 = w.lexical * l;
+    return t0 + t1;
+}
+
+// query_embedding after `normalize` (:494), shaped to the index dim the way dot_product's
+// zip would see it (:1778): extra components are dropped, missing ones contribute 0.
+std::vector<float> prepare_query(const float *query_raw, uint32_t dq, uint32_t dim)
+{
+    std::vector<float> q(query_raw, query_raw + dq);
+    rlr_normalize(q.data(), q.size());
+    q.resize(dim, 0.0f);
+    return q;
+}
+
+int32_t search_impl(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_t top_k,
+                    const rlr_resolved_weights &w, const uint64_t *lex_rows, const float *lex_scores,
+                    uint32_t n_lex, int32_t stage, std::vector<Cand> &result)
+{
+    result.clear();
+    uint64_t N = 0;
+    uint32_t dim = 0;
+    int32_t st = rlr_index_info(idx, &N, &dim, nullptr, nullptr);
+    if (st != RLR_OK)
+        return st;
+    if (N == 0) // :476-478
+        return RLR_OK;
+    if (top_k < 1) // :490
+        top_k = 1;
+    const std::vector<float> q = prepare_query(query_raw, dq, dim);
+
+    // lexical map (:505-506) and max_lexical (:515-519)
+    std::unordered_map<uint64_t, float> lex;
+    float max_lex = 0.0f;
+    for (uint32_t i = 0; i < n_lex; ++i) {
+        max_lex = std::fmax(max_lex, lex_scores[i]);
+        if (lex_rows[i] < N)
+            lex[lex_rows[i]] = lex_scores[i];
+    }
+    if (!(max_lex >= 1.1920929e-07f))
+        max_lex = 1.1920929e-07f;
+    std::vector<uint64_t> lrows;
+    lrows.reserve(lex.size());
+    for (const auto &kv : lex)
+        lrows.push_back(kv.first);
+    std::sort(lrows.begin(), lrows.end());
+    std::vector<float> lcos(lrows.size());
+    if (!lrows.empty()) {
+        st = rlr_score_rows(idx, q.data(), lrows.data(), static_cast<uint32_t>(lrows.size()), lcos.data());
+        if (st != RLR_OK)
+            return st;
+    }
+
+    const uint64_t want3 = static_cast<uint64_t>(top_k) * 3 > top_k ? static_cast<uint64_t>(top_k) * 3 : top_k;
+    const uint64_t initial_k = std::min<uint64_t>(N, want3);                              // :544
+    const uint64_t need = stage ? initial_k : std::min<uint64_t>(initial_k, top_k);       // :667-698
+
+    std::vector<Cand> cands;
+    if (w.embedding == 0.0f) {
+        // every non-lexical row scores 0*e + w_l*0 = 0 -> they tie and the build's tie rule
+        // (row asc) picks the lowest rows; no scan needed, only their cosines for reporting.
+        const uint64_t take = std::min<uint64_t>(N, need + lrows.size());
+        std::vector<uint64_t> rows(take);
+        for (uint64_t r = 0; r < take; ++r)
+            rows[r] = r;
+        std::vector<float> cosv(take);
+        st = rlr_score_rows(idx, q.data(), rows.data(), static_cast<uint32_t>(take), cosv.data());
+        if (st != RLR_OK)
+            return st;
+        for (uint64_t r = 0; r < take; ++r) {
+            auto it = lex.find(r);
+            const float l = it == lex.end() ? 0.0f : it->second / max_lex;
+            cands.push_back({r, combine(w, cosv[r], l), cosv[r], l});
+        }
+        for (size_t i = 0; i < lrows.size(); ++i)
+            if (lrows[i] >= take) {
+                const float l = lex[lrows[i]] / max_lex;
+                cands.push_back({lrows[i], combine(w, lcos[i], l), lcos[i], l});
+            }
+        std::sort(cands.begin(), cands.end(), cand_before);
+    } else {
+        // Non-lexical rows are ordered by cosine alone (w_e > 0 and rounding is monotone), so
+        // the device top-(need + n_lex + slack) by cosine, united with the lexical rows,
+        // contains the top-`need` by combined score.  Distinct cosines can round to the same
+        // combined score; if such a tie chain reaches the last fetched row the fetch is widened.
+        uint64_t fetch = std::min<uint64_t>(N, need + lrows.size() + 8);
+        std::vector<uint64_t> rows;
+        std::vector<float> cosv;
+        for (;;) {
+            rows.assign(fetch, 0);
+            cosv.assign(fetch, 0.0f);
+            uint32_t got = 0;
+            st = rlr_search_topk(idx, q.data(), 1, static_cast<uint32_t>(fetch), -1.0f, rows.data(), cosv.data(), &got);
+            if (st != RLR_OK)
+                return st;
+            cands.clear();
+            std::unordered_map<uint64_t, char> seen;
+            seen.reserve(got * 2);
+            for (uint32_t i = 0; i < got; ++i) {
+                auto it = lex.find(rows[i]);
+                const float l = it == lex.end() ? 0.0f : it->second / max_lex;
+                cands.push_back({rows[i], combine(w, cosv[i], l), cosv[i], l});
+                seen[rows[i]] = 1;
+            }
+            for (size_t i = 0; i < lrows.size(); ++i)
+                if (!seen.count(lrows[i])) {
+                    const float l = lex[lrows[i]] / max_lex;
+                    cands.push_back({lrows[i], combine(w, lcos[i], l), lcos[i], l});
+                }
+            std::sort(cands.begin(), cands.end(), cand_before);
+            if (got >= N || got == 0)
+                break;
+            const float c_tail = combine(w, cosv[got - 1], 0.0f); // bound on every unfetched row
+            if (cands.size() >= need && (std::isnan(c_tail) || cands[need - 1].c > c_tail))
+                break;
+            fetch = std::min<uint64_t>(N, fetch * 2);
+        }
+    }
+    if (cands.size() > need)
+        cands.resize(need);
+    result.swap(cands);
+    return RLR_OK;
+}
+
+void emit(const std::vector<Cand> &v, rlr_search_hit *out, uint32_t cap, uint32_t *n_out)
+{
+    const uint32_t n = static_cast<uint32_t>(std::min<size_t>(v.size(), cap));
+    for (uint32_t i = 0; i < n; ++i) {
+        out[i].row = v[i].row;
+        out[i].score = v[i].c;
+        out[i].embedding_score = v[i].e;
+        out[i].lexical_score = v[i].l;
+        out[i].initial_score = v[i].c;
+    }
+    *n_out = n;
+}
+
+} // namespace
+
+extern "C" {
+
+float rlr_resolve_weight(int32_t has_override, float w, float dflt)
+{
+    return (has_override && weight_ok(w)) ? w : dflt;
+}
+
+void rlr_resolve_weights(const rlr_query_weights *w, rlr_resolved_weights *out)
+{
+    const rlr_resolved_weights &d = cached_defaults();
+    out->embedding = rlr_resolve_weight(w ? w->has_embedding : 0, w ? w->embedding : 0.0f, d.embedding);
+    out->lexical = rlr_resolve_weight(w ? w->has_lexical : 0, w ? w->lexical : 0.0f, d.lexical);
+    out->reranker = rlr_resolve_weight(w ? w->has_reranker : 0, w ? w->reranker : 0.0f, d.reranker);
+    out->initial = rlr_resolve_weight(w ? w->has_initial : 0, w ? w->initial : 0.0f, d.initial);
+}
+
+void rlr_normalize(float *v, size_t n)
+{
+    float norm_sq = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const float p = v[i] * v[i];
+        norm_sq = norm_sq + p;
+    }
+    if (norm_sq > 1e-20f) {
+        const float norm = std::sqrt(norm_sq);
+        for (size_t i = 0; i < n; ++i)
+            v[i] = v[i] / norm;
+    }
+}
+
+int32_t rlr_engine_search(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_t top_k,
+                          const rlr_query_weights *weights, const uint64_t *lex_rows, const float *lex_scores,
+                          uint32_t n_lex, int32_t stage, rlr_search_hit *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!idx || !n_out || (!query_raw && dq) || (n_lex && (!lex_rows || !lex_scores)))
+        return RLR_E_INVALID;
+    *n_out = 0;
+    rlr_resolved_weights w;
+    rlr_resolve_weights(weights, &w);
+    std::vector<Cand> res;
+    const int32_t st = search_impl(idx, query_raw, dq, top_k, w, lex_rows, lex_scores, n_lex, stage, res);
+    if (st != RLR_OK)
+        return st;
+    if (!res.empty() && !out)
+        return RLR_E_INVALID;
+    emit(res, out, cap, n_out);
+    return RLR_OK;
+}
+
+int32_t rlr_engine_search_with_diversity(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_t top_k,
+                                         float diversity_factor, const rlr_query_weights *weights,
+                                         const uint64_t *lex_rows, const float *lex_scores, uint32_t n_lex,
+                                         rlr_search_hit *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!idx || !n_out || (!query_raw && dq) || (n_lex && (!lex_rows || !lex_scores)))
+        return RLR_E_INVALID;
+    *n_out = 0;
+    // f32::clamp(0.0, 1.0) (:725) -- NaN passes through and takes the MMR branch
+    if (diversity_factor < 0.0f) diversity_factor = 0.0f;
+    if (diversity_factor > 1.0f) diversity_factor = 1.0f;
+    rlr_resolved_weights w;
+    rlr_resolve_weights(weights, &w);
+    std::vector<Cand> pool;
+    if (diversity_factor == 0.0f) { // :728-730
+        const int32_t st = search_impl(idx, query_raw, dq, top_k, w, lex_rows, lex_scores, n_lex, 0, pool);
+        if (st != RLR_OK)
+            return st;
+        if (!pool.empty() && !out)
+            return RLR_E_INVALID;
+        emit(pool, out, cap, n_out);
+        return RLR_OK;
+    }
+    const uint64_t p3 = static_cast<uint64_t>(top_k) * 3, p10 = static_cast<uint64_t>(top_k) + 10;
+    const uint32_t pool_size = static_cast<uint32_t>(std::min<uint64_t>(std::max(p3, p10), 0xFFFFFFFFull)); // :734
+    int32_t st = search_impl(idx, query_raw, dq, pool_size, w, lex_rows, lex_scores, n_lex, 0, pool); // :735
+    if (st != RLR_OK)
+        return st;
+    if (pool.empty()) // :737-739
+        return RLR_OK;
+    const uint32_t P = static_cast<uint32_t>(pool.size());
+    std::vector<uint64_t> rows(P);
+    std::vector<float> scores(P);
+    for (uint32_t i = 0; i < P; ++i) {
+        rows[i] = pool[i].row;
+        scores[i] = pool[i].c;
+    }
+    std::vector<uint32_t> order(P);
+    uint32_t n_sel = 0;
+    st = rlr_mmr_select(idx, rows.data(), scores.data(), P, top_k, diversity_factor, order.data(), nullptr, &n_sel); // :756
+    if (st != RLR_OK)
+        return st;
+    std::vector<Cand> picked;
+    picked.reserve(n_sel);
+    for (uint32_t i = 0; i < n_sel; ++i)
+        picked.push_back(pool[order[i]]);
+    if (!picked.empty() && !out)
+        return RLR_E_INVALID;
+    emit(picked, out, cap, n_out);
+    return RLR_OK;
+}
+
+int32_t rlr_engine_embedding_candidates(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_t count,
+                                        uint64_t *rows_out, float *scores_out, uint32_t *n_out)
+{
+    if (!idx || !n_out || (!query_raw && dq))
+        return RLR_E_INVALID;
+    *n_out = 0;
+    uint64_t N = 0;
+    uint32_t dim = 0;
+    int32_t st = rlr_index_info(idx, &N, &dim, nullptr, nullptr);
+    if (st != RLR_OK)
+        return st;
+    if (N == 0 || count == 0)
+        return RLR_OK;
+    const std::vector<float> q = prepare_query(query_raw, dq, dim);
+    return rlr_search_topk(idx, q.data(), 1, count, -1.0f, rows_out, scores_out, n_out);
+}
+
+} // extern "C"

@@ -1,0 +1,517 @@
+// exact.hip -- kernels that reproduce the reference's arithmetic bit for bit:
+// strict left-to-right f32 accumulation, every product rounded before it is added, no
+// FMA (this file is compiled with -ffp-contract=off and spells no fmaf), IEEE division
+// and square root.  One lane owns one dot product, so the order inside a sum is the
+// reference's; parallelism is across rows / pairs.
+//
+//   dot_ref        /root/reference/src/rag_engine.rs:1777-1779  (dot_product)
+//   normalize      /root/reference/src/rag_engine.rs:1763-1771
+//   mmr greedy     /root/reference/src/rag_engine.rs:788-835
+#include "common.h"
+#include "kernels.h"
+#include "../../include/rlr_gpu.h"
+
+namespace rlr {
+
+namespace {
+
+// ---- reference-order dot of an LDS-resident query with one stored row -------------
+template <bool F16>
+__device__ inline float dot_ref_row(const float4 *__restrict__ row, const float *s_q, uint32_t dim)
+{
+    float s = 0.0f;
+    constexpr uint32_t EPU = F16 ? 8 : 4; // elements per 16-byte unit
+    const uint32_t full = dim / EPU;
+    uint32_t u = 0;
+    // 4 units (64 B) in flight per lane
+    for (; u + 4 <= full; u += 4) {
+        float4 x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            x[i] = row[u + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *q = s_q + (u + i) * EPU;
+            if constexpr (F16) {
+                const uint32_t w[4] = {__builtin_bit_cast(uint32_t, x[i].x), __builtin_bit_cast(uint32_t, x[i].y),
+                                       __builtin_bit_cast(uint32_t, x[i].z), __builtin_bit_cast(uint32_t, x[i].w)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float p0 = h2f(static_cast<uint16_t>(w[j] & 0xFFFF)) * q[2 * j];
+                    s = s + p0;
+                    float p1 = h2f(static_cast<uint16_t>(w[j] >> 16)) * q[2 * j + 1];
+                    s = s + p1;
+                }
+            } else {
+                float p;
+                p = x[i].x * q[0]; s = s + p;
+                p = x[i].y * q[1]; s = s + p;
+                p = x[i].z * q[2]; s = s + p;
+                p = x[i].w * q[3]; s = s + p;
+            }
+        }
+    }
+    // remaining elements one by one (also covers dim not a multiple of the unit)
+    if constexpr (F16) {
+        const uint16_t *h = reinterpret_cast<const uint16_t *>(row);
+        for (uint32_t e = u * EPU; e < dim; ++e) {
+            float p = h2f(h[e]) * s_q[e];
+            s = s + p;
+        }
+    } else {
+        const float *f = reinterpret_cast<const float *>(row);
+        for (uint32_t e = u * EPU; e < dim; ++e) {
+            float p = f[e] * s_q[e];
+            s = s + p;
+        }
+    }
+    return s;
+}
+
+__device__ inline void stage_query(float *s_q, const float *__restrict__ query, uint32_t dim)
+{
+    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x)
+        s_q[i] = query[i];
+    __syncthreads();
+}
+
+template <bool F16>
+__global__ __launch_bounds__(64) void rescore_kernel(const float4 *__restrict__ rows, uint32_t pitch16,
+                                                     uint32_t dim, const float *__restrict__ query,
+                                                     const uint32_t *__restrict__ cand,
+                                                     const SelectState *__restrict__ st,
+                                                     uint64_t *__restrict__ packed_out, uint32_t n_pad)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_q[];
+    stage_query(s_q, query, dim);
+    const uint32_t n = min(st->n_cand, st->cap);
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_pad)
+        return;
+    if (i >= n) {
+        packed_out[i] = 0;
+        return;
+    }
+    const uint32_t r = cand[i];
+    const float s = dot_ref_row<F16>(rows + static_cast<size_t>(r) * pitch16, s_q, dim);
+    packed_out[i] = pack_result(s, r);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(64) void score_rows_kernel(const float4 *__restrict__ rows, uint32_t pitch16,
+                                                        uint32_t dim, const float *__restrict__ query,
+                                                        const uint32_t *__restrict__ list, uint32_t n,
+                                                        float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_q[];
+    stage_query(s_q, query, dim);
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n)
+        return;
+    out[i] = dot_ref_row<F16>(rows + static_cast<size_t>(list[i]) * pitch16, s_q, dim);
+}
+
+// ---- normalize ---------------------------------------------------------------------
+// phase 1: one lane per row, sequential sum of squares (reference order)
+__global__ __launch_bounds__(64) void sumsq_kernel(const float *__restrict__ staging, uint32_t n,
+                                                   uint32_t dim, float *__restrict__ sumsq)
+{
+    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n)
+        return;
+    const float *v = staging + static_cast<size_t>(r) * dim;
+    float s = 0.0f;
+    for (uint32_t c = 0; c < dim; ++c) {
+        float p = v[c] * v[c];
+        s = s + p;
+    }
+    sumsq[r] = s;
+}
+
+__device__ inline float ref_scale(float v, float norm_sq, int do_normalize)
+{
+    // `if norm_sq > 1e-20 { x /= norm_sq.sqrt() }`  (rag_engine.rs:1765-1769)
+    if (do_normalize && norm_sq > 1e-20f)
+        return __fdiv_rn(v, __fsqrt_rn(norm_sq));
+    return v;
+}
+
+// phase 2: coalesced scale + store in the index dtype; pad columns get 0
+template <bool F16>
+__global__ __launch_bounds__(256) void scale_store_kernel(const float *__restrict__ staging,
+                                                          const float *__restrict__ sumsq, uint32_t n,
+                                                          uint32_t dim, int do_normalize,
+                                                          void *__restrict__ rows_out, uint32_t pitch16)
+{
+    const uint32_t pitch_e = F16 ? pitch16 * 8 : pitch16 * 4;
+    const size_t total = static_cast<size_t>(n) * pitch_e;
+    const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += stride) {
+        const uint32_t r = static_cast<uint32_t>(i / pitch_e);
+        const uint32_t c = static_cast<uint32_t>(i - static_cast<size_t>(r) * pitch_e);
+        float v = 0.0f;
+        if (c < dim)
+            v = ref_scale(staging[static_cast<size_t>(r) * dim + c], do_normalize ? sumsq[r] : 0.0f,
+                          do_normalize);
+        if constexpr (F16)
+            static_cast<_Float16 *>(rows_out)[i] = static_cast<_Float16>(v);
+        else
+            static_cast<float *>(rows_out)[i] = v;
+    }
+}
+
+// ---- synthetic corpus (twin of oracle/rlr_oracle.c: rlr_o_synth_raw) -----------------
+__device__ inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__device__ inline int32_t ih4(uint64_t h)
+{
+    return static_cast<int32_t>((h & 0xFFFF) + ((h >> 16) & 0xFFFF) + ((h >> 32) & 0xFFFF) + (h >> 48)) - 131070;
+}
+
+__device__ inline float synth_raw(uint64_t s, uint64_t row, uint32_t col, uint32_t d, uint32_t n_clusters)
+{
+    const uint64_t idx = row * static_cast<uint64_t>(d) + col;
+    int32_t t = ih4(mix64(s + (idx + 1) * 0x9E3779B97F4A7C15ULL));
+    if (n_clusters) {
+        const uint64_t cl = mix64(s ^ (row + 0x632BE59BD9B4E019ULL)) % n_clusters;
+        const uint64_t cidx = cl * static_cast<uint64_t>(d) + col;
+        const int32_t c = ih4(mix64((s ^ 0xC1A57E55C1A57E55ULL) + (cidx + 1) * 0x9E3779B97F4A7C15ULL));
+        t += 2 * c;
+    }
+    return static_cast<float>(t) * (1.0f / 65536.0f);
+}
+
+__global__ __launch_bounds__(64) void synth_sumsq_kernel(uint64_t s, uint64_t row0, uint32_t n, uint32_t dim,
+                                                         uint32_t n_clusters, float *__restrict__ sumsq)
+{
+    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n)
+        return;
+    float acc = 0.0f;
+    for (uint32_t c = 0; c < dim; ++c) {
+        const float v = synth_raw(s, row0 + r, c, dim, n_clusters);
+        float p = v * v;
+        acc = acc + p;
+    }
+    sumsq[r] = acc;
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void synth_store_kernel(uint64_t s, uint64_t row0, uint32_t n, uint32_t dim,
+                                                          uint32_t n_clusters, const float *__restrict__ sumsq,
+                                                          void *__restrict__ rows_out, uint32_t pitch16)
+{
+    const uint32_t pitch_e = F16 ? pitch16 * 8 : pitch16 * 4;
+    const size_t total = static_cast<size_t>(n) * pitch_e;
+    const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += stride) {
+        const uint32_t r = static_cast<uint32_t>(i / pitch_e);
+        const uint32_t c = static_cast<uint32_t>(i - static_cast<size_t>(r) * pitch_e);
+        float v = 0.0f;
+        if (c < dim)
+            v = ref_scale(synth_raw(s, row0 + r, c, dim, n_clusters), sumsq[r], 1);
+        if constexpr (F16)
+            static_cast<_Float16 *>(rows_out)[i] = static_cast<_Float16>(v);
+        else
+            static_cast<float *>(rows_out)[i] = v;
+    }
+}
+
+// ---- row movement ------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(256) void gather_f32_kernel(const void *__restrict__ rows, uint32_t pitch16,
+                                                         uint32_t dim, const uint32_t *__restrict__ list,
+                                                         uint32_t n, float *__restrict__ out)
+{
+    const size_t total = static_cast<size_t>(n) * dim;
+    const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += stride) {
+        const uint32_t k = static_cast<uint32_t>(i / dim);
+        const uint32_t c = static_cast<uint32_t>(i - static_cast<size_t>(k) * dim);
+        const size_t r = list[k];
+        if constexpr (F16)
+            out[i] = h2f(static_cast<const uint16_t *>(rows)[r * pitch16 * 8 + c]);
+        else
+            out[i] = static_cast<const float *>(rows)[r * pitch16 * 4 + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_rows_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                           uint32_t pitch16, const uint32_t *__restrict__ keep,
+                                                           uint32_t n_keep)
+{
+    const size_t total = static_cast<size_t>(n_keep) * pitch16;
+    const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += stride) {
+        const uint32_t k = static_cast<uint32_t>(i / pitch16);
+        const uint32_t u = static_cast<uint32_t>(i - static_cast<size_t>(k) * pitch16);
+        dst[i] = src[static_cast<size_t>(keep[k]) * pitch16 + u];
+    }
+}
+
+// ---- MMR ----------------------------------------------------------------------------
+// gram[i][j] = dot_ref(pool_i, pool_j), one lane per pair (j <= i computed, mirrored):
+// a*b is commutative and the summation order is the same, so dot(i,j) == dot(j,i) bitwise.
+__global__ __launch_bounds__(64) void gram_kernel(const float *__restrict__ pool, uint32_t P, uint32_t dim,
+                                                  float *__restrict__ gram)
+{
+    const uint32_t i = blockIdx.y;
+    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    if (j > i || i >= P)
+        return;
+    const float *a = pool + static_cast<size_t>(i) * dim;
+    const float *b = pool + static_cast<size_t>(j) * dim;
+    float s = 0.0f;
+    uint32_t c = 0;
+    if ((dim & 3u) == 0) {
+        const float4 *a4 = reinterpret_cast<const float4 *>(a);
+        const float4 *b4 = reinterpret_cast<const float4 *>(b);
+        for (; c + 16 <= dim; c += 16) {
+            float4 x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x[u] = a4[c / 4 + u];
+                y[u] = b4[c / 4 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float p;
+                p = x[u].x * y[u].x; s = s + p;
+                p = x[u].y * y[u].y; s = s + p;
+                p = x[u].z * y[u].z; s = s + p;
+                p = x[u].w * y[u].w; s = s + p;
+            }
+        }
+    }
+    for (; c < dim; ++c) {
+        float p = a[c] * b[c];
+        s = s + p;
+    }
+    gram[static_cast<size_t>(i) * P + j] = s;
+    gram[static_cast<size_t>(j) * P + i] = s;
+}
+
+__device__ inline bool finite_f(float x)
+{
+    return (__builtin_bit_cast(uint32_t, x) & 0x7F800000u) != 0x7F800000u;
+}
+
+// Greedy selection by one wavefront; `rem` replays the reference's Vec::swap_remove
+// bookkeeping so the visiting order (hence tie-breaking under strict `>`) is identical.
+__global__ __launch_bounds__(64) void mmr_greedy_kernel(const float *__restrict__ gram,
+                                                        const float *__restrict__ scores, uint32_t P,
+                                                        uint32_t k, float lambda, uint32_t *__restrict__ out_order,
+                                                        float *__restrict__ out_mmr, uint32_t *__restrict__ out_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    uint32_t *rem = reinterpret_cast<uint32_t *>(s_raw);          // P: position -> candidate
+    float *max_sim = reinterpret_cast<float *>(s_raw) + P;        // P: per candidate, fold(0.0, max)
+    float *rel = reinterpret_cast<float *>(s_raw) + 2 * P;        // P: relevance
+    const uint32_t lane = threadIdx.x;
+    if (P == 0) {
+        if (lane == 0)
+            *out_n = 0;
+        return;
+    }
+    for (uint32_t p = lane; p < P; p += 64) {
+        rem[p] = p;
+        max_sim[p] = 0.0f;
+        rel[p] = scores[p];
+    }
+    __syncthreads();
+    // selected.push(remaining.swap_remove(0))  -- unconditional (rag_engine.rs:782-785)
+    uint32_t n_rem = P, n_sel = 0;
+    uint32_t last = rem[0];
+    __syncthreads();
+    if (lane == 0) {
+        out_order[0] = last;
+        out_mmr[0] = __builtin_bit_cast(float, 0x7FC00000u);
+        rem[0] = rem[P - 1];
+    }
+    n_sel = 1;
+    n_rem = P - 1;
+    __syncthreads();
+
+    const float one_minus = 1.0f - lambda;
+    while (n_sel < k && n_rem > 0) {
+        const float *g_last = gram + static_cast<size_t>(last) * P; // row `last` == column `last`
+        uint64_t best = 0; // (key(mmr) << 32) | ~position ; 0 = no finite candidate
+        for (uint32_t p = lane; p < n_rem; p += 64) {
+            const uint32_t c = rem[p];
+            const float sim = g_last[c];
+            float ms = max_sim[c];
+            if (finite_f(sim))
+                ms = fmaxf(ms, sim);
+            max_sim[c] = ms;
+            const float r = rel[c];
+            if (!finite_f(r))
+                continue;
+            const float t0 = one_minus * r;
+            const float t1 = lambda * ms;
+            float m = t0 - t1;
+            if (!finite_f(m))
+                continue;
+            if (m == 0.0f)
+                m = 0.0f; // -0 and +0 compare equal in the reference
+            const uint64_t cand = (static_cast<uint64_t>(score_key(m)) << 32) | (0xFFFFFFFFu - p);
+            if (cand > best)
+                best = cand;
+        }
+        // wavefront argmax: larger mmr wins, equal mmr -> lower position (first visited)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t hi = __shfl_xor(static_cast<uint32_t>(best >> 32), off);
+            const uint32_t lo = __shfl_xor(static_cast<uint32_t>(best & 0xFFFFFFFFu), off);
+            const uint64_t other = (static_cast<uint64_t>(hi) << 32) | lo;
+            if (other > best)
+                best = other;
+        }
+        if (best == 0) // `if best_mmr_score == NEG_INFINITY { break }`
+            break;
+        const uint32_t best_p = 0xFFFFFFFFu - static_cast<uint32_t>(best & 0xFFFFFFFFu);
+        __syncthreads();
+        last = rem[best_p];
+        __syncthreads();
+        if (lane == 0) {
+            out_order[n_sel] = last;
+            out_mmr[n_sel] = key_score(static_cast<uint32_t>(best >> 32));
+            rem[best_p] = rem[n_rem - 1]; // swap_remove(best_idx)
+        }
+        n_sel++;
+        n_rem--;
+        __syncthreads();
+    }
+    if (lane == 0)
+        *out_n = n_sel;
+}
+
+uint32_t ew_blocks(size_t total)
+{
+    size_t b = (total + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    return b ? static_cast<uint32_t>(b) : 1u;
+}
+
+} // namespace
+
+hipError_t launch_rescore(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *query,
+                          const uint32_t *cand, const SelectState *st, uint64_t *packed_out, uint32_t n_pad,
+                          hipStream_t s)
+{
+    const uint32_t blocks = (n_pad + 63) / 64;
+    const size_t lds = static_cast<size_t>(dim) * sizeof(float);
+    const float4 *r4 = static_cast<const float4 *>(rows);
+    if (dtype == RLR_F16)
+        hipLaunchKernelGGL(rescore_kernel<true>, dim3(blocks), dim3(64), lds, s, r4, pitch16, dim, query, cand, st,
+                           packed_out, n_pad);
+    else
+        hipLaunchKernelGGL(rescore_kernel<false>, dim3(blocks), dim3(64), lds, s, r4, pitch16, dim, query, cand, st,
+                           packed_out, n_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_rows(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *query,
+                             const uint32_t *list, uint32_t n, float *cos_out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const uint32_t blocks = (n + 63) / 64;
+    const size_t lds = static_cast<size_t>(dim) * sizeof(float);
+    const float4 *r4 = static_cast<const float4 *>(rows);
+    if (dtype == RLR_F16)
+        hipLaunchKernelGGL(score_rows_kernel<true>, dim3(blocks), dim3(64), lds, s, r4, pitch16, dim, query, list, n,
+                           cos_out);
+    else
+        hipLaunchKernelGGL(score_rows_kernel<false>, dim3(blocks), dim3(64), lds, s, r4, pitch16, dim, query, list, n,
+                           cos_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_normalize_store(float *staging, uint32_t n, uint32_t dim, int do_normalize, void *rows_out,
+                                  uint32_t pitch16, int dtype, float *norm_tmp, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    if (do_normalize)
+        hipLaunchKernelGGL(sumsq_kernel, dim3((n + 63) / 64), dim3(64), 0, s, staging, n, dim, norm_tmp);
+    const size_t total = static_cast<size_t>(n) * pitch16 * (dtype == RLR_F16 ? 8 : 4);
+    if (dtype == RLR_F16)
+        hipLaunchKernelGGL(scale_store_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, s, staging, norm_tmp, n,
+                           dim, do_normalize, rows_out, pitch16);
+    else
+        hipLaunchKernelGGL(scale_store_kernel<false>, dim3(ew_blocks(total)), dim3(256), 0, s, staging, norm_tmp, n,
+                           dim, do_normalize, rows_out, pitch16);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(void *rows_out, uint32_t pitch16, uint32_t dim, int dtype, uint64_t row0, uint32_t n,
+                        uint64_t seed, uint32_t n_clusters, float *norm_tmp, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    // same seed pre-hash as the oracle
+    uint64_t z = seed ^ 0x5EED5EED5EED5EEDULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    hipLaunchKernelGGL(synth_sumsq_kernel, dim3((n + 63) / 64), dim3(64), 0, s, z, row0, n, dim, n_clusters,
+                       norm_tmp);
+    const size_t total = static_cast<size_t>(n) * pitch16 * (dtype == RLR_F16 ? 8 : 4);
+    if (dtype == RLR_F16)
+        hipLaunchKernelGGL(synth_store_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, s, z, row0, n, dim,
+                           n_clusters, norm_tmp, rows_out, pitch16);
+    else
+        hipLaunchKernelGGL(synth_store_kernel<false>, dim3(ew_blocks(total)), dim3(256), 0, s, z, row0, n, dim,
+                           n_clusters, norm_tmp, rows_out, pitch16);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_f32(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const uint32_t *list,
+                             uint32_t n, float *out, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const size_t total = static_cast<size_t>(n) * dim;
+    if (dtype == RLR_F16)
+        hipLaunchKernelGGL(gather_f32_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, s, rows, pitch16, dim, list,
+                           n, out);
+    else
+        hipLaunchKernelGGL(gather_f32_kernel<false>, dim3(ew_blocks(total)), dim3(256), 0, s, rows, pitch16, dim,
+                           list, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_rows(const void *src, void *dst, uint32_t pitch16, const uint32_t *keep, uint32_t n_keep,
+                               hipStream_t s)
+{
+    if (n_keep == 0)
+        return hipSuccess;
+    const size_t total = static_cast<size_t>(n_keep) * pitch16;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(ew_blocks(total)), dim3(256), 0, s,
+                       static_cast<const float4 *>(src), static_cast<float4 *>(dst), pitch16, keep, n_keep);
+    return hipGetLastError();
+}
+
+hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram, hipStream_t s)
+{
+    if (P == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(gram_kernel, dim3((P + 63) / 64, P), dim3(64), 0, s, pool, P, dim, gram);
+    return hipGetLastError();
+}
+
+hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P, uint32_t k, float lambda,
+                             uint32_t *out_order, float *out_mmr, uint32_t *out_n, hipStream_t s)
+{
+    const size_t lds = static_cast<size_t>(P ? P : 1) * 12;
+    hipLaunchKernelGGL(mmr_greedy_kernel, dim3(1), dim3(64), lds, s, gram, scores, P, k, lambda, out_order, out_mmr,
+                       out_n);
+    return hipGetLastError();
+}
+
+} // namespace rlr

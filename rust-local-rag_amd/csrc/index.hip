@@ -1,0 +1,980 @@
+// index.hip -- the C ABI of include/rlr_gpu.h: device-resident chunk-embedding matrix,
+// per-call search contexts (stream + workspace), and the kernel pipeline
+//   scan (+hist1) -> find1 -> hist2 -> find2 -> collect -> rescore -> sort -> D2H
+// There is no CPU compute path in this file: without a HIP device every compute entry
+// point fails with RLR_E_NO_DEVICE.
+#include "../../include/rlr_gpu.h"
+#include "common.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+using namespace rlr;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int32_t fail(int32_t code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define RLR_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? RLR_E_OOM : RLR_E_HIP, "%s failed: %s (%s:%d)", \
+                        #call, hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+#define RLR_TRY(call)                                                                              \
+    do {                                                                                           \
+        int32_t s_ = (call);                                                                       \
+        if (s_ != RLR_OK)                                                                          \
+            return s_;                                                                             \
+    } while (0)
+
+constexpr uint32_t kLdsSortCap = 4096; // candidates the single-workgroup sort can take
+constexpr uint32_t kMaxDim = 8192;
+
+uint32_t next_pow2(uint32_t v)
+{
+    uint32_t p = 1;
+    while (p < v)
+        p <<= 1;
+    return p;
+}
+
+// -------- per-call context ---------------------------------------------------------
+struct Ctx {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // device
+    float *d_query = nullptr;      // q_cap x q_pitch floats
+    uint32_t q_cap = 0;
+    float *d_scores = nullptr;     // score_cap floats
+    uint64_t score_cap = 0;
+    uint32_t *d_hist = nullptr;    // 2 * kHistBins
+    SelectState *d_state = nullptr; // q_cap states
+    uint32_t *d_cand = nullptr;    // cand_cap
+    uint64_t *d_packed = nullptr;  // cand_cap (power of two)
+    uint32_t cand_cap = 0;
+    uint64_t *d_out = nullptr;     // out_cap packed results
+    uint64_t out_cap = 0;
+    uint32_t *d_list = nullptr;    // row lists (score_rows / fetch / mmr)
+    float *d_vals = nullptr;       // float outputs for lists / mmr
+    uint32_t list_cap = 0;
+    float *d_pool = nullptr;       // mmr pool P x dim, then gram P x P
+    uint64_t pool_cap = 0;         // floats
+    // pinned host
+    void *h_pin = nullptr;
+    size_t h_pin_bytes = 0;
+};
+
+} // namespace
+
+struct rlr_index {
+    uint32_t dim = 0;
+    int32_t dtype = RLR_F32;
+    int32_t device = 0;
+    uint32_t pitch16 = 0;   // row pitch in 16-byte units
+    uint32_t q_pitch = 0;   // floats per staged query (row pitch in elements)
+    uint64_t n_rows = 0;
+    uint64_t cap_rows = 0;
+    void *d_rows = nullptr;
+    int n_cu = 256;
+    int scan_variant = 0;
+    std::mutex mu;
+    std::vector<Ctx *> free_ctx;
+    bool profiling = false;
+    rlr_profile prof{};
+};
+
+namespace {
+
+size_t row_bytes(const rlr_index *ix)
+{
+    return static_cast<size_t>(ix->pitch16) * 16;
+}
+
+int32_t use_device(const rlr_index *ix)
+{
+    RLR_HIP(hipSetDevice(ix->device));
+    return RLR_OK;
+}
+
+template <typename T>
+int32_t grow(T **p, uint64_t *cap, uint64_t want, bool keep = false)
+{
+    if (*cap >= want && *p)
+        return RLR_OK;
+    T *n = nullptr;
+    RLR_HIP(hipMalloc(reinterpret_cast<void **>(&n), want * sizeof(T)));
+    if (keep && *p && *cap)
+        RLR_HIP(hipMemcpy(n, *p, *cap * sizeof(T), hipMemcpyDeviceToDevice));
+    if (*p)
+        (void)hipFree(*p);
+    *p = n;
+    *cap = want;
+    return RLR_OK;
+}
+
+template <typename T>
+int32_t grow32(T **p, uint32_t *cap, uint32_t want)
+{
+    uint64_t c = *cap;
+    int32_t s = grow(p, &c, want);
+    *cap = static_cast<uint32_t>(c);
+    return s;
+}
+
+int32_t pin_reserve(Ctx *c, size_t bytes)
+{
+    if (c->h_pin_bytes >= bytes)
+        return RLR_OK;
+    if (c->h_pin)
+        (void)hipHostFree(c->h_pin);
+    c->h_pin = nullptr;
+    c->h_pin_bytes = 0;
+    size_t want = std::max<size_t>(bytes, 1 << 16);
+    RLR_HIP(hipHostMalloc(&c->h_pin, want, hipHostMallocDefault));
+    c->h_pin_bytes = want;
+    return RLR_OK;
+}
+
+void ctx_free(Ctx *c)
+{
+    if (!c)
+        return;
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    (void)hipFree(c->d_query);
+    (void)hipFree(c->d_scores);
+    (void)hipFree(c->d_hist);
+    (void)hipFree(c->d_state);
+    (void)hipFree(c->d_cand);
+    (void)hipFree(c->d_packed);
+    (void)hipFree(c->d_out);
+    (void)hipFree(c->d_list);
+    (void)hipFree(c->d_vals);
+    (void)hipFree(c->d_pool);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    delete c;
+}
+
+int32_t ctx_acquire(rlr_index *ix, Ctx **out)
+{
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (!ix->free_ctx.empty()) {
+            *out = ix->free_ctx.back();
+            ix->free_ctx.pop_back();
+            return RLR_OK;
+        }
+    }
+    Ctx *c = new (std::nothrow) Ctx();
+    if (!c)
+        return fail(RLR_E_OOM, "host allocation failed");
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void **>(&c->d_hist), 2 * kHistBins * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        ctx_free(c);
+        return fail(RLR_E_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return RLR_OK;
+}
+
+void ctx_release(rlr_index *ix, Ctx *c)
+{
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->free_ctx.push_back(c);
+}
+
+struct CtxLease {
+    rlr_index *ix;
+    Ctx *c = nullptr;
+    explicit CtxLease(rlr_index *i) : ix(i) {}
+    ~CtxLease()
+    {
+        if (c)
+            ctx_release(ix, c);
+    }
+};
+
+int32_t check_handle(const rlr_index *ix)
+{
+    if (!ix)
+        return fail(RLR_E_INVALID, "null index handle");
+    return RLR_OK;
+}
+
+int32_t ensure_rows(rlr_index *ix, uint64_t want_rows)
+{
+    if (want_rows <= ix->cap_rows)
+        return RLR_OK;
+    if (want_rows > 0xFFFFFFF0ull)
+        return fail(RLR_E_INVALID, "an index shard holds at most 2^32-16 rows");
+    uint64_t cap = std::max<uint64_t>(want_rows, ix->cap_rows + ix->cap_rows / 2);
+    cap = std::max<uint64_t>(cap, 1024);
+    void *n = nullptr;
+    hipError_t e = hipMalloc(&n, cap * row_bytes(ix));
+    if (e != hipSuccess && cap > want_rows) {
+        cap = want_rows;
+        e = hipMalloc(&n, cap * row_bytes(ix));
+    }
+    if (e != hipSuccess)
+        return fail(RLR_E_OOM, "hipMalloc of %llu rows x %zu B failed: %s",
+                    static_cast<unsigned long long>(cap), row_bytes(ix), hipGetErrorString(e));
+    if (ix->d_rows && ix->n_rows)
+        RLR_HIP(hipMemcpy(n, ix->d_rows, ix->n_rows * row_bytes(ix), hipMemcpyDeviceToDevice));
+    if (ix->d_rows)
+        (void)hipFree(ix->d_rows);
+    ix->d_rows = n;
+    ix->cap_rows = cap;
+    return RLR_OK;
+}
+
+// Copy host rows in, normalise (optionally) and store them at row `first`.
+int32_t ingest(rlr_index *ix, const float *rows, uint64_t n, uint64_t first, int normalize)
+{
+    if (n == 0)
+        return RLR_OK;
+    const uint64_t chunk_rows = std::max<uint64_t>(1, (64ull << 20) / (static_cast<uint64_t>(ix->dim) * 4));
+    float *d_stage = nullptr, *d_norm = nullptr;
+    const uint64_t cr = std::min(chunk_rows, n);
+    RLR_HIP(hipMalloc(reinterpret_cast<void **>(&d_stage), cr * ix->dim * sizeof(float)));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_norm), cr * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(d_stage);
+        return fail(RLR_E_OOM, "staging allocation failed");
+    }
+    int32_t st = RLR_OK;
+    for (uint64_t r0 = 0; r0 < n && st == RLR_OK; r0 += cr) {
+        const uint64_t m = std::min(cr, n - r0);
+        e = hipMemcpy(d_stage, rows + r0 * ix->dim, m * ix->dim * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = launch_normalize_store(d_stage, static_cast<uint32_t>(m), ix->dim, normalize,
+                                       static_cast<char *>(ix->d_rows) + (first + r0) * row_bytes(ix), ix->pitch16,
+                                       ix->dtype, d_norm, nullptr);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess)
+            st = fail(RLR_E_HIP, "row ingest failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_stage);
+    (void)hipFree(d_norm);
+    return st;
+}
+
+// ---- the search pipeline ------------------------------------------------------------
+struct SearchPlan {
+    uint32_t k;        // per query, already clamped to n_rows
+    uint32_t cap;      // candidate capacity
+    float two_eps;
+};
+
+int32_t ctx_prepare(rlr_index *ix, Ctx *c, uint32_t nq, const SearchPlan &p)
+{
+    if (c->q_cap < nq || !c->d_query) {
+        if (c->d_query) (void)hipFree(c->d_query);
+        if (c->d_state) (void)hipFree(c->d_state);
+        c->d_query = nullptr;
+        c->d_state = nullptr;
+        c->q_cap = 0;
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_query), static_cast<size_t>(nq) * ix->q_pitch * sizeof(float)));
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_state), static_cast<size_t>(nq) * sizeof(SelectState)));
+        c->q_cap = nq;
+    }
+    RLR_TRY(grow(&c->d_scores, &c->score_cap, std::max<uint64_t>(ix->n_rows, 4)));
+    if (c->cand_cap < p.cap) {
+        if (c->d_cand) (void)hipFree(c->d_cand);
+        if (c->d_packed) (void)hipFree(c->d_packed);
+        c->d_cand = nullptr;
+        c->d_packed = nullptr;
+        c->cand_cap = 0;
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cand), static_cast<size_t>(p.cap) * sizeof(uint32_t)));
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_packed), static_cast<size_t>(p.cap) * sizeof(uint64_t)));
+        c->cand_cap = p.cap;
+    }
+    RLR_TRY(grow(&c->d_out, &c->out_cap, std::max<uint64_t>(static_cast<uint64_t>(nq) * p.k, 1)));
+    return RLR_OK;
+}
+
+} // namespace
+
+namespace rlr {
+// device-side: sort the re-scored candidates (<= kLdsSortCap) and emit the best k.
+__global__ __launch_bounds__(1024) void sort_emit_kernel(uint64_t *__restrict__ packed, const SelectState *__restrict__ st,
+                                                         uint64_t *__restrict__ out, uint32_t k)
+{
+    __shared__ uint64_t s[4096];
+    const uint32_t n_raw = st->n_cand;
+    if (n_raw > st->cap || n_raw > 4096)
+        return; // band overflow: the host re-runs this query on the large-candidate path
+    uint32_t n_pad = 1;
+    while (n_pad < n_raw)
+        n_pad <<= 1;
+    for (uint32_t i = threadIdx.x; i < n_pad; i += 1024)
+        s[i] = i < n_raw ? packed[i] : 0ull;
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= n_pad; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n_pad; i += 1024) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = s[i], b = s[ixj];
+                    const bool desc = (i & kk) == 0;
+                    if (desc ? (a < b) : (a > b)) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < k; i += 1024)
+        out[i] = i < n_raw ? s[i] : 0ull;
+}
+
+__global__ void emit_kernel(const uint64_t *__restrict__ packed, uint32_t n, uint64_t *__restrict__ out, uint32_t k)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k)
+        out[i] = i < n ? packed[i] : 0ull;
+}
+} // namespace rlr
+
+namespace {
+
+// Enqueue the whole pipeline for query `qi` on the context's stream.
+hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint64_t *d_out_q, bool timed)
+{
+    hipStream_t s = c->stream;
+    hipError_t e;
+    const uint32_t n = static_cast<uint32_t>(ix->n_rows);
+    uint32_t *hist1 = c->d_hist, *hist2 = c->d_hist + kHistBins;
+    SelectState *st = c->d_state + qi;
+    const float *dq = c->d_query + static_cast<size_t>(qi) * ix->q_pitch;
+
+    if ((e = hipMemsetAsync(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), s)) != hipSuccess) return e;
+    if (timed && (e = hipEventRecord(c->ev[0], s)) != hipSuccess) return e;
+    ScanArgs sa;
+    sa.rows = ix->d_rows;
+    sa.query = dq;
+    sa.scores = c->d_scores;
+    sa.hist = hist1;
+    sa.n_rows = n;
+    sa.dim = ix->dim;
+    sa.pitch16 = ix->pitch16;
+    sa.dtype = ix->dtype;
+    sa.n_cu = ix->n_cu;
+    sa.variant = ix->scan_variant;
+    if ((e = launch_scan(sa, s)) != hipSuccess) return e;
+    if (timed && (e = hipEventRecord(c->ev[1], s)) != hipSuccess) return e;
+    if ((e = launch_find1(hist1, st, s)) != hipSuccess) return e;
+    if ((e = launch_hist2(c->d_scores, n, st, hist2, ix->n_cu, s)) != hipSuccess) return e;
+    if ((e = launch_find2(hist2, st, p.two_eps, s)) != hipSuccess) return e;
+    if ((e = launch_collect(c->d_scores, n, st, c->d_cand, ix->n_cu, s)) != hipSuccess) return e;
+    if (timed && (e = hipEventRecord(c->ev[2], s)) != hipSuccess) return e;
+    const uint32_t n_pad = std::min<uint32_t>(p.cap, kLdsSortCap);
+    if ((e = launch_rescore(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st, c->d_packed, n_pad, s)) !=
+        hipSuccess)
+        return e;
+    hipLaunchKernelGGL(rlr::sort_emit_kernel, dim3(1), dim3(1024), 0, s, c->d_packed, st, d_out_q, p.k);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (timed && (e = hipEventRecord(c->ev[3], s)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+// Large-candidate path for one query whose band overflowed the LDS sort (massive ties /
+// duplicated chunks, or k > kLdsSortCap).  Re-uses the scores still resident from the scan
+// only when the query was the last one scanned; otherwise re-scans.
+int32_t big_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint32_t n_cand, bool rescan,
+                  uint64_t *d_out_q)
+{
+    hipStream_t s = c->stream;
+    const uint32_t n = static_cast<uint32_t>(ix->n_rows);
+    const uint32_t cap = next_pow2(std::max<uint32_t>(n_cand, p.k));
+    SearchPlan big = p;
+    big.cap = cap;
+    if (c->cand_cap < cap) {
+        if (c->d_cand) (void)hipFree(c->d_cand);
+        if (c->d_packed) (void)hipFree(c->d_packed);
+        c->d_cand = nullptr;
+        c->d_packed = nullptr;
+        c->cand_cap = 0;
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cand), static_cast<size_t>(cap) * sizeof(uint32_t)));
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_packed), static_cast<size_t>(cap) * sizeof(uint64_t)));
+        c->cand_cap = cap;
+    }
+    SelectState *st = c->d_state + qi;
+    const float *dq = c->d_query + static_cast<size_t>(qi) * ix->q_pitch;
+    if (rescan) {
+        ScanArgs sa;
+        sa.rows = ix->d_rows;
+        sa.query = dq;
+        sa.scores = c->d_scores;
+        sa.hist = nullptr;
+        sa.n_rows = n;
+        sa.dim = ix->dim;
+        sa.pitch16 = ix->pitch16;
+        sa.dtype = ix->dtype;
+        sa.n_cu = ix->n_cu;
+        sa.variant = ix->scan_variant;
+        RLR_HIP(launch_scan(sa, s));
+    }
+    // key_lo is still valid in the state; reset the counter and the capacity
+    SelectState h;
+    RLR_HIP(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, s));
+    RLR_HIP(hipStreamSynchronize(s));
+    h.n_cand = 0;
+    h.cap = cap;
+    RLR_HIP(hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    RLR_HIP(launch_collect(c->d_scores, n, st, c->d_cand, ix->n_cu, s));
+    RLR_HIP(launch_rescore(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st, c->d_packed, cap, s));
+    RLR_HIP(launch_sort_desc(c->d_packed, cap, s));
+    hipLaunchKernelGGL(rlr::emit_kernel, dim3((p.k + 255) / 256), dim3(256), 0, s, c->d_packed, n_cand, d_out_q, p.k);
+    RLR_HIP(hipGetLastError());
+    RLR_HIP(hipStreamSynchronize(s));
+    return RLR_OK;
+}
+
+// Runs nq queries; results (packed, k per query) end up in d_out (context buffer or the
+// caller's device buffer).  h_states receives the final per-query states.
+int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uint32_t k_req, float guard_eps,
+                   uint64_t *d_out_user, SearchPlan *plan_out)
+{
+    const uint32_t n = static_cast<uint32_t>(ix->n_rows);
+    SearchPlan p;
+    p.k = std::min<uint32_t>(k_req, n);
+    const float eps = guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim);
+    p.two_eps = 2.0f * eps;
+    p.cap = kLdsSortCap;
+    *plan_out = p;
+    if (p.k == 0 || nq == 0)
+        return RLR_OK;
+    RLR_TRY(ctx_prepare(ix, c, nq, p));
+    uint64_t *d_out = d_out_user ? d_out_user : c->d_out;
+
+    // stage queries (zero padded to the row pitch) and the initial select states
+    const size_t q_bytes = static_cast<size_t>(nq) * ix->q_pitch * sizeof(float);
+    const size_t st_bytes = static_cast<size_t>(nq) * sizeof(SelectState);
+    RLR_TRY(pin_reserve(c, q_bytes + 2 * st_bytes));
+    float *h_q = static_cast<float *>(c->h_pin);
+    SelectState *h_st = reinterpret_cast<SelectState *>(static_cast<char *>(c->h_pin) + q_bytes);
+    SelectState *h_st_back = h_st + nq;
+    std::memset(h_q, 0, q_bytes);
+    for (uint32_t q = 0; q < nq; ++q)
+        std::memcpy(h_q + static_cast<size_t>(q) * ix->q_pitch, queries + static_cast<size_t>(q) * ix->dim,
+                    ix->dim * sizeof(float));
+    for (uint32_t q = 0; q < nq; ++q) {
+        std::memset(&h_st[q], 0, sizeof(SelectState));
+        h_st[q].k = p.k;
+        h_st[q].cap = p.cap;
+    }
+    hipStream_t s = c->stream;
+    RLR_HIP(hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s));
+    RLR_HIP(hipMemcpyAsync(c->d_state, h_st, st_bytes, hipMemcpyHostToDevice, s));
+
+    const bool timed = ix->profiling;
+    double scan_ms = 0, select_ms = 0, rescore_ms = 0, total_ms = 0;
+    uint64_t n_cand_total = 0, n_retry = 0;
+    if (!timed) {
+        for (uint32_t q = 0; q < nq; ++q)
+            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, false));
+        RLR_HIP(hipMemcpyAsync(h_st_back, c->d_state, st_bytes, hipMemcpyDeviceToHost, s));
+        RLR_HIP(hipStreamSynchronize(s));
+    } else {
+        // one query at a time so the four events can be read back per query
+        for (uint32_t q = 0; q < nq; ++q) {
+            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, true));
+            RLR_HIP(hipStreamSynchronize(s));
+            float a = 0, b = 0, d = 0;
+            RLR_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+            RLR_HIP(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+            RLR_HIP(hipEventElapsedTime(&d, c->ev[2], c->ev[3]));
+            scan_ms += a;
+            select_ms += b;
+            rescore_ms += d;
+            total_ms += a + b + d;
+        }
+        RLR_HIP(hipMemcpyAsync(h_st_back, c->d_state, st_bytes, hipMemcpyDeviceToHost, s));
+        RLR_HIP(hipStreamSynchronize(s));
+    }
+    // band overflow -> large-candidate path (rare: massive exact ties, or k > 2048)
+    for (uint32_t q = 0; q < nq; ++q) {
+        const uint32_t nc = h_st_back[q].n_cand;
+        n_cand_total += nc;
+        if (nc > p.cap || nc > kLdsSortCap) {
+            n_retry++;
+            RLR_TRY(big_query(ix, c, q, p, nc, /*rescan=*/nq > 1, d_out + static_cast<size_t>(q) * p.k));
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        ix->prof.n_searches += nq;
+        ix->prof.n_candidates += n_cand_total;
+        ix->prof.n_retries += n_retry;
+        if (timed) {
+            ix->prof.n_scan_launches += nq;
+            ix->prof.scan_ms += scan_ms;
+            ix->prof.select_ms += select_ms;
+            ix->prof.rescore_ms += rescore_ms;
+            ix->prof.total_ms += total_ms;
+            ix->prof.scan_bytes += static_cast<uint64_t>(nq) * ix->n_rows * ix->dim * (ix->dtype == RLR_F16 ? 2 : 4);
+        }
+    }
+    return RLR_OK;
+}
+
+int32_t upload_list(rlr_index *ix, Ctx *c, const uint64_t *rows, uint32_t n)
+{
+    if (c->list_cap < n || !c->d_list) {
+        if (c->d_list) (void)hipFree(c->d_list);
+        if (c->d_vals) (void)hipFree(c->d_vals);
+        c->d_list = nullptr;
+        c->d_vals = nullptr;
+        c->list_cap = 0;
+        const uint32_t cap = std::max<uint32_t>(next_pow2(n), 1024);
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_list), static_cast<size_t>(cap) * sizeof(uint32_t)));
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_vals), static_cast<size_t>(cap) * sizeof(float)));
+        c->list_cap = cap;
+    }
+    RLR_TRY(pin_reserve(c, static_cast<size_t>(n) * 8 + 64));
+    uint32_t *h = static_cast<uint32_t *>(c->h_pin);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (rows[i] >= ix->n_rows)
+            return fail(RLR_E_RANGE, "row %llu out of range (index holds %llu rows)",
+                        static_cast<unsigned long long>(rows[i]), static_cast<unsigned long long>(ix->n_rows));
+        h[i] = static_cast<uint32_t>(rows[i]);
+    }
+    RLR_HIP(hipMemcpyAsync(c->d_list, h, static_cast<size_t>(n) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    return RLR_OK;
+}
+
+} // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+int32_t rlr_version(void)
+{
+    return RLR_VERSION;
+}
+
+int32_t rlr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+const char *rlr_last_error(void)
+{
+    return g_err;
+}
+
+float rlr_default_guard_eps(uint32_t dim)
+{
+    // |seq_sum - tree_sum| <= (dim + reduction depth) * 2^-24 * sum|x_i y_i| <= that * |x||y|
+    // for unit-norm operands; 64 covers the 12-deep lane chain + 6 DPP levels with margin,
+    // and the final 1/16 absorbs norms that are 1 +- a few ulp.
+    return (static_cast<float>(dim) + 64.0f) * 5.9604645e-8f * 1.0625f;
+}
+
+int32_t rlr_index_create(uint32_t dim, int32_t dtype, int32_t device_id, rlr_index **out)
+{
+    if (!out)
+        return fail(RLR_E_INVALID, "out is null");
+    *out = nullptr;
+    if (dim == 0 || dim > kMaxDim)
+        return fail(RLR_E_INVALID, "dim must be in [1, %u]", kMaxDim);
+    if (dtype != RLR_F32 && dtype != RLR_F16)
+        return fail(RLR_E_INVALID, "unknown dtype %d", dtype);
+    int n_dev = rlr_device_count();
+    if (n_dev <= 0)
+        return fail(RLR_E_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
+    if (device_id < 0 || device_id >= n_dev)
+        return fail(RLR_E_NO_DEVICE, "device %d out of range (%d visible)", device_id, n_dev);
+    rlr_index *ix = new (std::nothrow) rlr_index();
+    if (!ix)
+        return fail(RLR_E_OOM, "host allocation failed");
+    ix->dim = dim;
+    ix->dtype = dtype;
+    ix->device = device_id;
+    const uint32_t elem = dtype == RLR_F16 ? 2 : 4;
+    ix->pitch16 = (dim * elem + 15) / 16;
+    ix->q_pitch = ix->pitch16 * (16 / elem);
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+        delete ix;
+        return fail(RLR_E_HIP, "cannot query device %d", device_id);
+    }
+    ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *v = getenv("RLR_SCAN_VARIANT"))
+        ix->scan_variant = static_cast<int>(strtol(v, nullptr, 0));
+    *out = ix;
+    return RLR_OK;
+}
+
+int32_t rlr_index_destroy(rlr_index *ix)
+{
+    if (!ix)
+        return RLR_OK;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    for (Ctx *c : ix->free_ctx)
+        ctx_free(c);
+    if (ix->d_rows)
+        (void)hipFree(ix->d_rows);
+    delete ix;
+    return RLR_OK;
+}
+
+int32_t rlr_index_info(const rlr_index *ix, uint64_t *n_rows, uint32_t *dim, int32_t *dtype, int32_t *device_id)
+{
+    RLR_TRY(check_handle(ix));
+    if (n_rows) *n_rows = ix->n_rows;
+    if (dim) *dim = ix->dim;
+    if (dtype) *dtype = ix->dtype;
+    if (device_id) *device_id = ix->device;
+    return RLR_OK;
+}
+
+int32_t rlr_index_reserve(rlr_index *ix, uint64_t n_rows)
+{
+    RLR_TRY(check_handle(ix));
+    RLR_TRY(use_device(ix));
+    return ensure_rows(ix, n_rows);
+}
+
+int32_t rlr_index_upload(rlr_index *ix, const float *rows, uint64_t n_rows, int32_t normalize_on_device)
+{
+    RLR_TRY(check_handle(ix));
+    if (n_rows && !rows)
+        return fail(RLR_E_INVALID, "rows is null");
+    RLR_TRY(use_device(ix));
+    ix->n_rows = 0;
+    RLR_TRY(ensure_rows(ix, n_rows));
+    RLR_TRY(ingest(ix, rows, n_rows, 0, normalize_on_device));
+    ix->n_rows = n_rows;
+    return RLR_OK;
+}
+
+int32_t rlr_index_append(rlr_index *ix, const float *rows, uint64_t n_rows, int32_t normalize_on_device,
+                         uint64_t *first_row_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (n_rows && !rows)
+        return fail(RLR_E_INVALID, "rows is null");
+    RLR_TRY(use_device(ix));
+    const uint64_t first = ix->n_rows;
+    RLR_TRY(ensure_rows(ix, first + n_rows));
+    RLR_TRY(ingest(ix, rows, n_rows, first, normalize_on_device));
+    ix->n_rows = first + n_rows;
+    if (first_row_out)
+        *first_row_out = first;
+    return RLR_OK;
+}
+
+int32_t rlr_index_delete_rows(rlr_index *ix, const uint64_t *rows, uint64_t n)
+{
+    RLR_TRY(check_handle(ix));
+    if (n == 0)
+        return RLR_OK;
+    if (!rows)
+        return fail(RLR_E_INVALID, "rows is null");
+    RLR_TRY(use_device(ix));
+    const uint64_t N = ix->n_rows;
+    std::vector<uint8_t> dead(N, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (rows[i] >= N)
+            return fail(RLR_E_RANGE, "row %llu out of range (index holds %llu rows)",
+                        static_cast<unsigned long long>(rows[i]), static_cast<unsigned long long>(N));
+        dead[rows[i]] = 1;
+    }
+    uint64_t first_dead = 0;
+    while (first_dead < N && !dead[first_dead])
+        ++first_dead;
+    std::vector<uint32_t> keep;
+    keep.reserve(N - first_dead);
+    for (uint64_t r = first_dead; r < N; ++r)
+        if (!dead[r])
+            keep.push_back(static_cast<uint32_t>(r));
+    // stable in-place compaction through a bounce buffer: destination rows
+    // [first_dead + i0, first_dead + i1) only overwrite rows below every source still to move.
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / row_bytes(ix));
+    void *d_bounce = nullptr;
+    uint32_t *d_keep = nullptr;
+    const uint64_t cr = std::min<uint64_t>(chunk, std::max<size_t>(keep.size(), 1));
+    RLR_HIP(hipMalloc(&d_bounce, cr * row_bytes(ix)));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_keep), cr * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(d_bounce);
+        return fail(RLR_E_OOM, "compaction buffer allocation failed");
+    }
+    int32_t st = RLR_OK;
+    for (uint64_t i0 = 0; i0 < keep.size() && st == RLR_OK; i0 += cr) {
+        const uint64_t m = std::min<uint64_t>(cr, keep.size() - i0);
+        e = hipMemcpy(d_keep, keep.data() + i0, m * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = launch_compact_rows(ix->d_rows, d_bounce, ix->pitch16, d_keep, static_cast<uint32_t>(m), nullptr);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(static_cast<char *>(ix->d_rows) + (first_dead + i0) * row_bytes(ix), d_bounce,
+                               m * row_bytes(ix), hipMemcpyDeviceToDevice, nullptr);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess)
+            st = fail(RLR_E_HIP, "row compaction failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_bounce);
+    (void)hipFree(d_keep);
+    if (st == RLR_OK)
+        ix->n_rows = first_dead + keep.size();
+    return st;
+}
+
+int32_t rlr_index_fill_synthetic(rlr_index *ix, uint64_t n_rows, uint64_t row0, uint64_t seed, uint32_t n_clusters)
+{
+    RLR_TRY(check_handle(ix));
+    RLR_TRY(use_device(ix));
+    ix->n_rows = 0;
+    RLR_TRY(ensure_rows(ix, n_rows));
+    const uint64_t chunk = 1ull << 20;
+    float *d_norm = nullptr;
+    RLR_HIP(hipMalloc(reinterpret_cast<void **>(&d_norm), std::min(chunk, std::max<uint64_t>(n_rows, 1)) * sizeof(float)));
+    int32_t st = RLR_OK;
+    for (uint64_t r0 = 0; r0 < n_rows && st == RLR_OK; r0 += chunk) {
+        const uint64_t m = std::min(chunk, n_rows - r0);
+        hipError_t e = launch_synth(static_cast<char *>(ix->d_rows) + r0 * row_bytes(ix), ix->pitch16, ix->dim, ix->dtype,
+                                    row0 + r0, static_cast<uint32_t>(m), seed, n_clusters, d_norm, nullptr);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess)
+            st = fail(RLR_E_HIP, "synthetic fill failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_norm);
+    if (st == RLR_OK)
+        ix->n_rows = n_rows;
+    return st;
+}
+
+int32_t rlr_search_topk(rlr_index *ix, const float *queries, uint32_t n_queries, uint32_t k, float guard_eps,
+                        uint64_t *rows_out, float *cos_out, uint32_t *n_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (n_queries && (!queries || !n_out))
+        return fail(RLR_E_INVALID, "queries / n_out is null");
+    if (n_queries && k && (!rows_out || !cos_out))
+        return fail(RLR_E_INVALID, "output buffers are null");
+    RLR_TRY(use_device(ix));
+    if (ix->n_rows == 0 || k == 0) {
+        for (uint32_t q = 0; q < n_queries; ++q)
+            n_out[q] = 0;
+        return RLR_OK;
+    }
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    SearchPlan p;
+    RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, nullptr, &p));
+    const size_t bytes = static_cast<size_t>(n_queries) * p.k * sizeof(uint64_t);
+    RLR_TRY(pin_reserve(c, bytes));
+    RLR_HIP(hipMemcpyAsync(c->h_pin, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    RLR_HIP(hipStreamSynchronize(c->stream));
+    const uint64_t *h = static_cast<const uint64_t *>(c->h_pin);
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        n_out[q] = p.k;
+        for (uint32_t i = 0; i < p.k; ++i) {
+            float sc;
+            uint32_t r;
+            unpack_result(h[static_cast<size_t>(q) * p.k + i], &sc, &r);
+            rows_out[static_cast<size_t>(q) * k + i] = r;
+            cos_out[static_cast<size_t>(q) * k + i] = sc;
+        }
+    }
+    return RLR_OK;
+}
+
+int32_t rlr_search_topk_device(rlr_index *ix, const float *queries, uint32_t n_queries, uint32_t k, float guard_eps,
+                               void *d_packed_out, void *stream)
+{
+    RLR_TRY(check_handle(ix));
+    if (n_queries && k && (!queries || !d_packed_out))
+        return fail(RLR_E_INVALID, "queries / d_packed_out is null");
+    RLR_TRY(use_device(ix));
+    if (n_queries == 0 || k == 0)
+        return RLR_OK;
+    hipStream_t user = static_cast<hipStream_t>(stream);
+    if (ix->n_rows == 0) {
+        RLR_HIP(hipMemsetAsync(d_packed_out, 0, static_cast<size_t>(n_queries) * k * sizeof(uint64_t), user));
+        return RLR_OK;
+    }
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    SearchPlan p;
+    if (k <= ix->n_rows) {
+        RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, static_cast<uint64_t *>(d_packed_out), &p));
+    } else {
+        // fewer rows than k: produce the n_rows results, then spread them into k-strided slots
+        RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, nullptr, &p));
+        RLR_HIP(hipMemsetAsync(d_packed_out, 0, static_cast<size_t>(n_queries) * k * sizeof(uint64_t), c->stream));
+        RLR_HIP(hipMemcpy2DAsync(d_packed_out, static_cast<size_t>(k) * 8, c->d_out, static_cast<size_t>(p.k) * 8,
+                                 static_cast<size_t>(p.k) * 8, n_queries, hipMemcpyDeviceToDevice, c->stream));
+        RLR_HIP(hipStreamSynchronize(c->stream));
+    }
+    // run_search has synchronised the context stream, so the results are complete; a later
+    // enqueue on `user` is ordered after them.
+    (void)user;
+    return RLR_OK;
+}
+
+uint64_t rlr_pack_result(float score, uint32_t row)
+{
+    return pack_result(score, row);
+}
+
+void rlr_unpack_result(uint64_t packed, float *score, uint32_t *row)
+{
+    float s;
+    uint32_t r;
+    unpack_result(packed, &s, &r);
+    if (score) *score = s;
+    if (row) *row = r;
+}
+
+int32_t rlr_score_rows(rlr_index *ix, const float *query, const uint64_t *rows, uint32_t n, float *cos_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (n == 0)
+        return RLR_OK;
+    if (!query || !rows || !cos_out)
+        return fail(RLR_E_INVALID, "null argument");
+    RLR_TRY(use_device(ix));
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    RLR_TRY(upload_list(ix, c, rows, n));
+    if (c->q_cap < 1) {
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_query), static_cast<size_t>(ix->q_pitch) * sizeof(float)));
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_state), sizeof(SelectState)));
+        c->q_cap = 1;
+    }
+    RLR_HIP(hipMemcpyAsync(c->d_query, query, ix->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    RLR_HIP(launch_score_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_query, c->d_list, n, c->d_vals,
+                              c->stream));
+    RLR_HIP(hipMemcpyAsync(cos_out, c->d_vals, static_cast<size_t>(n) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RLR_HIP(hipStreamSynchronize(c->stream));
+    return RLR_OK;
+}
+
+int32_t rlr_fetch_rows(rlr_index *ix, const uint64_t *rows, uint32_t n, float *out)
+{
+    RLR_TRY(check_handle(ix));
+    if (n == 0)
+        return RLR_OK;
+    if (!rows || !out)
+        return fail(RLR_E_INVALID, "null argument");
+    RLR_TRY(use_device(ix));
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    RLR_TRY(upload_list(ix, c, rows, n));
+    RLR_TRY(grow(&c->d_pool, &c->pool_cap, static_cast<uint64_t>(n) * ix->dim));
+    RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, n, c->d_pool, c->stream));
+    RLR_HIP(hipMemcpyAsync(out, c->d_pool, static_cast<size_t>(n) * ix->dim * sizeof(float), hipMemcpyDeviceToHost,
+                           c->stream));
+    RLR_HIP(hipStreamSynchronize(c->stream));
+    return RLR_OK;
+}
+
+int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *pool_scores, uint32_t P, uint32_t k,
+                       float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (!n_out)
+        return fail(RLR_E_INVALID, "n_out is null");
+    *n_out = 0;
+    if (P == 0)
+        return RLR_OK; // `if candidates.is_empty() { return vec![] }`
+    if (!pool_rows || !pool_scores || !order_out)
+        return fail(RLR_E_INVALID, "null argument");
+    if (P > 4096)
+        return fail(RLR_E_INVALID, "pool of %u exceeds the supported 4096 candidates", P);
+    RLR_TRY(use_device(ix));
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    hipStream_t s = c->stream;
+    RLR_TRY(upload_list(ix, c, pool_rows, P));
+    // pool (P x dim) followed by gram (P x P), scores (P), order (P), mmr (P), n (1)
+    const uint64_t floats = static_cast<uint64_t>(P) * ix->dim + static_cast<uint64_t>(P) * P + 3ull * P + 4;
+    RLR_TRY(grow(&c->d_pool, &c->pool_cap, floats));
+    float *d_pool = c->d_pool;
+    float *d_gram = d_pool + static_cast<uint64_t>(P) * ix->dim;
+    float *d_sc = d_gram + static_cast<uint64_t>(P) * P;
+    uint32_t *d_order = reinterpret_cast<uint32_t *>(d_sc + P);
+    float *d_mmr = d_sc + 2ull * P;
+    uint32_t *d_n = reinterpret_cast<uint32_t *>(d_sc + 3ull * P);
+    RLR_HIP(hipMemcpyAsync(d_sc, pool_scores, static_cast<size_t>(P) * sizeof(float), hipMemcpyHostToDevice, s));
+    RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_pool, s));
+    RLR_HIP(launch_gram(d_pool, P, ix->dim, d_gram, s));
+    RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, s));
+    // one D2H: order | mmr | n are contiguous
+    RLR_TRY(pin_reserve(c, (2ull * P + 4) * 4));
+    RLR_HIP(hipMemcpyAsync(c->h_pin, d_order, (2ull * P + 1) * 4, hipMemcpyDeviceToHost, s));
+    RLR_HIP(hipStreamSynchronize(s));
+    const uint32_t *h_order = static_cast<const uint32_t *>(c->h_pin);
+    const float *h_mmr = reinterpret_cast<const float *>(h_order + P);
+    const uint32_t n_sel = h_order[2 * P];
+    for (uint32_t i = 0; i < n_sel; ++i) {
+        order_out[i] = h_order[i];
+        if (mmr_out)
+            mmr_out[i] = h_mmr[i];
+    }
+    *n_out = n_sel;
+    return RLR_OK;
+}
+
+int32_t rlr_profile_enable(rlr_index *ix, int32_t enable)
+{
+    RLR_TRY(check_handle(ix));
+    ix->profiling = enable != 0;
+    return RLR_OK;
+}
+
+int32_t rlr_profile_read(rlr_index *ix, rlr_profile *out, int32_t reset)
+{
+    RLR_TRY(check_handle(ix));
+    if (!out)
+        return fail(RLR_E_INVALID, "out is null");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    *out = ix->prof;
+    if (reset)
+        ix->prof = rlr_profile{};
+    return RLR_OK;
+}
+
+} // extern "C"

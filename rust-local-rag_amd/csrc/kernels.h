@@ -1,0 +1,82 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (definitions in *.hip).
+// Host-callable; every wrapper only enqueues work on `stream`.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rlr {
+
+struct DeviceInfo {
+    int n_cu = 256;
+};
+
+// ---- scan.hip : wavefront-order candidate scan (HBM-bound) ----------------
+struct ScanArgs {
+    const void *rows;     // n_rows x pitch16 x 16 B, row-major
+    const float *query;   // device, q_pitch floats (zero padded to the row pitch)
+    float *scores;        // n_rows
+    uint32_t *hist;       // kHistBins bins of score_key >> 21, pre-zeroed; may be null
+    uint32_t n_rows;
+    uint32_t dim;         // logical elements per row
+    uint32_t pitch16;     // row pitch in 16-byte units
+    int dtype;            // RLR_F32 / RLR_F16
+    int n_cu;
+    int variant;          // tuning knob, 0 = default
+};
+hipError_t launch_scan(const ScanArgs &a, hipStream_t stream);
+const char *scan_kernel_name(const ScanArgs &a);
+
+// ---- select.hip : radix select / collect / sort -------------------------
+// Selection state kept on the device between the stages of one query.
+struct SelectState {
+    uint32_t k;          // in : rank wanted (1-based), <= n
+    uint32_t bin1;       // out of find1: digit of the k-th key, bits 31..21
+    uint32_t k2;         // rank inside bin1
+    uint32_t bin2;       // out of find2: bits 20..10
+    uint32_t key_lo;     // collect threshold (guard band applied)
+    uint32_t n_cand;     // collect counter (may exceed cap)
+    uint32_t cap;        // in : candidate buffer capacity
+    uint32_t pad;
+};
+hipError_t launch_hist1(const float *scores, uint32_t n, uint32_t *hist1, int n_cu, hipStream_t s);
+hipError_t launch_find1(const uint32_t *hist1, SelectState *st, hipStream_t s);
+hipError_t launch_hist2(const float *scores, uint32_t n, const SelectState *st, uint32_t *hist2,
+                        int n_cu, hipStream_t s);
+hipError_t launch_find2(const uint32_t *hist2, SelectState *st, float two_eps, hipStream_t s);
+hipError_t launch_collect(const float *scores, uint32_t n, SelectState *st, uint32_t *cand,
+                          int n_cu, hipStream_t s);
+// sort `n_pad` (power of two) packed u64 descending in place; entries >= n are 0.
+hipError_t launch_sort_desc(uint64_t *packed, uint32_t n_pad, hipStream_t s);
+
+// ---- exact.hip : reference-order arithmetic --------------------------------
+// packed_out[i] = pack(dot_ref(query, row[cand[i]]), cand[i]) for i < min(n_cand, cap);
+// entries up to n_pad are zero-filled.  n_cand is read from the device (st->n_cand).
+hipError_t launch_rescore(const void *rows, uint32_t pitch16, uint32_t dim, int dtype,
+                          const float *query, const uint32_t *cand, const SelectState *st,
+                          uint64_t *packed_out, uint32_t n_pad, hipStream_t s);
+// cos_out[i] = dot_ref(query, row[list[i]]) for an explicit row list.
+hipError_t launch_score_rows(const void *rows, uint32_t pitch16, uint32_t dim, int dtype,
+                             const float *query, const uint32_t *list, uint32_t n, float *cos_out,
+                             hipStream_t s);
+// Reference normalize() of n rows of f32 staging data (in place), then store as dtype.
+hipError_t launch_normalize_store(float *staging, uint32_t n, uint32_t dim, int do_normalize,
+                                  void *rows_out, uint32_t pitch16, int dtype, float *norm_tmp,
+                                  hipStream_t s);
+hipError_t launch_synth(void *rows_out, uint32_t pitch16, uint32_t dim, int dtype, uint64_t row0,
+                        uint32_t n, uint64_t seed, uint32_t n_clusters, float *norm_tmp,
+                        hipStream_t s);
+// out[i][0..dim) = widen(row[list[i]]), dense f32 with pitch `dim`.
+hipError_t launch_gather_f32(const void *rows, uint32_t pitch16, uint32_t dim, int dtype,
+                             const uint32_t *list, uint32_t n, float *out, hipStream_t s);
+// stable compaction: dst row i = src row keep[i]
+hipError_t launch_compact_rows(const void *src, void *dst, uint32_t pitch16, const uint32_t *keep,
+                               uint32_t n_keep, hipStream_t s);
+// gram[i*P + j] = dot_ref(pool[i], pool[j]) over a dense f32 P x dim pool.
+hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram, hipStream_t s);
+// greedy MMR over the gram matrix; out_order/out_mmr/out_n on the device.
+hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P, uint32_t k,
+                             float lambda, uint32_t *out_order, float *out_mmr, uint32_t *out_n,
+                             hipStream_t s);
+
+} // namespace rlr

@@ -1,0 +1,364 @@
+// scan.hip -- the HBM-bound hot loop: one pass over the chunk-embedding matrix,
+// one wavefront-order dot product per row (replaces HOT LOOP 1,
+// /root/reference/src/rag_engine.rs:524-541, `dot_product` :1777-1779).
+//
+// Shape of the work on gfx950
+//   * query staged in LDS once per workgroup, then held in VGPRs (3 x float4 per lane
+//     for 768-d) for the whole kernel;
+//   * a wave owns a group of <= 64 consecutive rows; each row is read with
+//     `global_load_dwordx4`, 64 lanes x 16 B = 1 KiB per instruction, fully coalesced,
+//     R rows (R x dim x 4 B) in flight per wave;
+//   * per-lane fmaf partials, DPP wavefront reduction (no LDS), the row's score is
+//     parked in lane (row % group) so the group's scores leave as one coalesced store;
+//   * the first radix-select histogram (top 11 key bits) is accumulated in LDS while
+//     the rows stream and flushed with one atomic per touched bin per workgroup.
+// Algorithmic traffic: dim x elem bytes per row read once, 4 B per row written.
+// There is no inter-workgroup reuse, so no XCD-aware remap is needed here (the query is
+// the only shared operand: 3 KB, resident in every XCD's L2).
+//
+// The summation order differs from the reference's strict left-to-right order, so these
+// scores only NOMINATE candidates (guard band, select.hip); exact.hip re-scores them.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/rlr_gpu.h"
+
+namespace rlr {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ inline float4 ld16(const float4 *p)
+{
+    if constexpr (NT) {
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+
+__device__ inline float dot4(float4 x, float4 q, float acc)
+{
+    acc = __builtin_fmaf(x.x, q.x, acc);
+    acc = __builtin_fmaf(x.y, q.y, acc);
+    acc = __builtin_fmaf(x.z, q.z, acc);
+    acc = __builtin_fmaf(x.w, q.w, acc);
+    return acc;
+}
+
+// 8 binary16 values (one 16-byte load) against 8 f32 query values.
+__device__ inline float dot8h(float4 raw, float4 q0, float4 q1, float acc)
+{
+    uint32_t w0 = __builtin_bit_cast(uint32_t, raw.x), w1 = __builtin_bit_cast(uint32_t, raw.y);
+    uint32_t w2 = __builtin_bit_cast(uint32_t, raw.z), w3 = __builtin_bit_cast(uint32_t, raw.w);
+    acc = __builtin_fmaf(h2f(static_cast<uint16_t>(w0 & 0xFFFF)), q0.x, acc);
+    acc = __builtin_fmaf(h2f(static_cast<uint16_t>(w0 >> 16)), q0.y, acc);
+    acc = __builtin_fmaf(h2f(static_cast<uint16_t>(w1 & 0xFFFF)), q0.z, acc);
+    acc = __builtin_fmaf(h2f(static_cast<uint16_t>(w1 >> 16)), q0.w, acc);
+    acc = __builtin_fmaf(h2f(static_cast<uint16_t>(w2 & 0xFFFF)), q1.x, acc);
+    acc = __builtin_fmaf(h2f(static_cast<uint16_t>(w2 >> 16)), q1.y, acc);
+    acc = __builtin_fmaf(h2f(static_cast<uint16_t>(w3 & 0xFFFF)), q1.z, acc);
+    acc = __builtin_fmaf(h2f(static_cast<uint16_t>(w3 >> 16)), q1.w, acc);
+    return acc;
+}
+
+__device__ inline void hist_flush(const uint32_t *s_hist, uint32_t *g_hist)
+{
+    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) {
+        uint32_t c = s_hist[i];
+        if (c)
+            atomicAdd(&g_hist[i], c);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fixed-shape kernel: pitch16 == CH * 64 (f32: dim = 256*CH; f16: dim = 512*CH), so a
+// row is exactly CH wave-wide 16-byte loads and the query lives in registers.
+// ---------------------------------------------------------------------------
+template <int CH, int R, bool F16, bool NT>
+__global__ __launch_bounds__(256) void scan_fixed_kernel(const float4 *__restrict__ rows,
+                                                         const float *__restrict__ query,
+                                                         float *__restrict__ scores,
+                                                         uint32_t *__restrict__ g_hist,
+                                                         uint32_t n_rows, uint32_t group_rows)
+{
+    constexpr int P16 = CH * 64;                  // 16-byte units per row
+    constexpr int QF4 = F16 ? 2 * P16 : P16;      // float4 units of query
+    __shared__ float4 s_q[QF4];
+    __shared__ uint32_t s_hist[kHistBins];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform -> scalar row addressing
+    for (int i = tid; i < QF4; i += 256)
+        s_q[i] = reinterpret_cast<const float4 *>(query)[i];
+    for (int i = tid; i < kHistBins; i += 256)
+        s_hist[i] = 0;
+    __syncthreads();
+
+    float4 qv[F16 ? 2 * CH : CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if constexpr (F16) {
+            qv[2 * c] = s_q[2 * (c * 64 + lane)];
+            qv[2 * c + 1] = s_q[2 * (c * 64 + lane) + 1];
+        } else {
+            qv[c] = s_q[c * 64 + lane];
+        }
+    }
+
+    const uint32_t n_groups = (n_rows + group_rows - 1) / group_rows;
+    const uint32_t n_waves = gridDim.x * 4;
+    for (uint32_t g = blockIdx.x * 4 + wave; g < n_groups; g += n_waves) {
+        const uint32_t row0 = g * group_rows;
+        const uint32_t nr = min(group_rows, n_rows - row0);
+        float mine = 0.0f;
+        for (uint32_t r = 0; r < nr; r += R) {
+            float4 x[R][CH];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                // rows past the group end are clamped to its last row: a valid address
+                // whose result lands in a lane that is never stored.
+                const uint32_t row = min(row0 + r + rr, row0 + nr - 1);
+                const float4 *p = rows + static_cast<size_t>(row) * P16 + lane;
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    x[rr][c] = ld16<NT>(p + c * 64);
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if constexpr (F16)
+                        acc = dot8h(x[rr][c], qv[2 * c], qv[2 * c + 1], acc);
+                    else
+                        acc = dot4(x[rr][c], qv[c], acc);
+                }
+                const float tot = wave_sum(acc);
+                if (static_cast<uint32_t>(lane) == r + rr)
+                    mine = tot;
+            }
+        }
+        if (static_cast<uint32_t>(lane) < nr) {
+            scores[row0 + lane] = mine;
+            if (g_hist)
+                atomicAdd(&s_hist[score_key(mine) >> 21], 1u);
+        }
+    }
+    if (g_hist) {
+        __syncthreads();
+        hist_flush(s_hist, g_hist);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Generic kernel: any dim (row pitch padded to 16 B, pad = 0), query read from LDS.
+// ---------------------------------------------------------------------------
+template <int R, bool F16>
+__global__ __launch_bounds__(256) void scan_generic_kernel(const float4 *__restrict__ rows,
+                                                           const float *__restrict__ query,
+                                                           float *__restrict__ scores,
+                                                           uint32_t *__restrict__ g_hist,
+                                                           uint32_t n_rows, uint32_t group_rows,
+                                                           uint32_t pitch16)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_raw);                       // kHistBins
+    float4 *s_q = reinterpret_cast<float4 *>(s_raw + kHistBins * sizeof(uint32_t)); // query
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform -> scalar row addressing
+    const uint32_t qf4 = F16 ? 2 * pitch16 : pitch16;
+    for (uint32_t i = tid; i < qf4; i += 256)
+        s_q[i] = reinterpret_cast<const float4 *>(query)[i];
+    for (int i = tid; i < kHistBins; i += 256)
+        s_hist[i] = 0;
+    __syncthreads();
+
+    const uint32_t n_groups = (n_rows + group_rows - 1) / group_rows;
+    const uint32_t n_waves = gridDim.x * 4;
+    for (uint32_t g = blockIdx.x * 4 + wave; g < n_groups; g += n_waves) {
+        const uint32_t row0 = g * group_rows;
+        const uint32_t nr = min(group_rows, n_rows - row0);
+        float mine = 0.0f;
+        for (uint32_t r = 0; r < nr; r += R) {
+            float acc[R];
+            const float4 *p[R];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                acc[rr] = 0.0f;
+                const uint32_t row = min(row0 + r + rr, row0 + nr - 1);
+                p[rr] = rows + static_cast<size_t>(row) * pitch16;
+            }
+            for (uint32_t c = lane; c < pitch16; c += 64) {
+                float4 x[R];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+                    x[rr] = p[rr][c];
+                if constexpr (F16) {
+                    const float4 q0 = s_q[2 * c], q1 = s_q[2 * c + 1];
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr)
+                        acc[rr] = dot8h(x[rr], q0, q1, acc[rr]);
+                } else {
+                    const float4 q0 = s_q[c];
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr)
+                        acc[rr] = dot4(x[rr], q0, acc[rr]);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const float tot = wave_sum(acc[rr]);
+                if (static_cast<uint32_t>(lane) == r + rr)
+                    mine = tot;
+            }
+        }
+        if (static_cast<uint32_t>(lane) < nr) {
+            scores[row0 + lane] = mine;
+            if (g_hist)
+                atomicAdd(&s_hist[score_key(mine) >> 21], 1u);
+        }
+    }
+    if (g_hist) {
+        __syncthreads();
+        hist_flush(s_hist, g_hist);
+    }
+}
+
+struct ScanPlan {
+    uint32_t group_rows;
+    uint32_t blocks;
+    int r;
+    bool nt;
+};
+
+ScanPlan plan_scan(const ScanArgs &a)
+{
+    ScanPlan p;
+    const int v = a.variant;
+    const int r_code = v & 0xF;
+    p.r = r_code == 0 ? 4 : r_code;
+    p.nt = (v >> 4) & 1;
+    int blocks_per_cu = (v >> 8) & 0xFF;
+    if (blocks_per_cu == 0)
+        blocks_per_cu = 8;
+    uint32_t group = (v >> 16) & 0xFF;
+    const uint32_t max_blocks = static_cast<uint32_t>(a.n_cu) * blocks_per_cu;
+    if (group == 0) {
+        // enough groups to give every resident wave several, but never below 16 rows
+        group = 64;
+        while (group > 16 && (a.n_rows + group - 1) / group < max_blocks * 4 * 4)
+            group >>= 1;
+    }
+    if (group > 64)
+        group = 64;
+    group = (group / p.r) * p.r;
+    if (group == 0)
+        group = p.r;
+    p.group_rows = group;
+    const uint32_t n_groups = (a.n_rows + group - 1) / group;
+    uint32_t blocks = (n_groups + 3) / 4;
+    if (blocks > max_blocks)
+        blocks = max_blocks;
+    if (blocks == 0)
+        blocks = 1;
+    p.blocks = blocks;
+    return p;
+}
+
+template <int CH, bool F16>
+hipError_t launch_fixed(const ScanArgs &a, const ScanPlan &p, hipStream_t s)
+{
+    const float4 *rows = static_cast<const float4 *>(a.rows);
+#define RLR_SCAN_CASE(RV, NTV)                                                                    \
+    hipLaunchKernelGGL((scan_fixed_kernel<CH, RV, F16, NTV>), dim3(p.blocks), dim3(256), 0, s,   \
+                       rows, a.query, a.scores, a.hist, a.n_rows, p.group_rows)
+    if (p.nt) {
+        switch (p.r) {
+        case 1: RLR_SCAN_CASE(1, true); break;
+        case 2: RLR_SCAN_CASE(2, true); break;
+        case 8: RLR_SCAN_CASE(8, true); break;
+        default: RLR_SCAN_CASE(4, true); break;
+        }
+    } else {
+        switch (p.r) {
+        case 1: RLR_SCAN_CASE(1, false); break;
+        case 2: RLR_SCAN_CASE(2, false); break;
+        case 8: RLR_SCAN_CASE(8, false); break;
+        default: RLR_SCAN_CASE(4, false); break;
+        }
+    }
+#undef RLR_SCAN_CASE
+    return hipGetLastError();
+}
+
+bool fixed_shape(const ScanArgs &a, int *ch)
+{
+    if (a.pitch16 % 64 != 0)
+        return false;
+    const int c = a.pitch16 / 64;
+    const uint32_t elems = a.dtype == RLR_F16 ? a.pitch16 * 8 : a.pitch16 * 4;
+    if (elems != a.dim)
+        return false;
+    if (a.dtype == RLR_F16) {
+        if (c != 1 && c != 2)
+            return false;
+    } else if (c < 1 || c > 4) {
+        return false;
+    }
+    *ch = c;
+    return true;
+}
+
+} // namespace
+
+const char *scan_kernel_name(const ScanArgs &a)
+{
+    int ch;
+    return fixed_shape(a, &ch) ? "scan_fixed_kernel" : "scan_generic_kernel";
+}
+
+hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
+{
+    if (a.n_rows == 0)
+        return hipSuccess;
+    ScanPlan p = plan_scan(a);
+    int ch = 0;
+    if (fixed_shape(a, &ch)) {
+        if (a.dtype == RLR_F16) {
+            if (p.r == 8) {
+                p.r = 4;
+                p.group_rows = (p.group_rows / 4) * 4;
+            }
+            return ch == 1 ? launch_fixed<1, true>(a, p, s) : launch_fixed<2, true>(a, p, s);
+        }
+        switch (ch) {
+        case 1: return launch_fixed<1, false>(a, p, s);
+        case 2: return launch_fixed<2, false>(a, p, s);
+        case 3: return launch_fixed<3, false>(a, p, s);
+        default: return launch_fixed<4, false>(a, p, s);
+        }
+    }
+    // generic path
+    const uint32_t qf4 = a.dtype == RLR_F16 ? 2 * a.pitch16 : a.pitch16;
+    const size_t lds = kHistBins * sizeof(uint32_t) + static_cast<size_t>(qf4) * 16;
+    const float4 *rows = static_cast<const float4 *>(a.rows);
+    p.r = 2;
+    p.group_rows = (p.group_rows / 2) * 2;
+    if (p.group_rows == 0)
+        p.group_rows = 2;
+    if (a.dtype == RLR_F16)
+        hipLaunchKernelGGL((scan_generic_kernel<2, true>), dim3(p.blocks), dim3(256), lds, s, rows,
+                           a.query, a.scores, a.hist, a.n_rows, p.group_rows, a.pitch16);
+    else
+        hipLaunchKernelGGL((scan_generic_kernel<2, false>), dim3(p.blocks), dim3(256), lds, s, rows,
+                           a.query, a.scores, a.hist, a.n_rows, p.group_rows, a.pitch16);
+    return hipGetLastError();
+}
+
+} // namespace rlr

@@ -1,0 +1,299 @@
+// select.hip -- top-k nomination over the score array: two 11-bit radix-select passes
+// locate the 22-bit key prefix of the k-th largest score, the guard band is subtracted,
+// and every row at or above the band floor is appended to the candidate list
+// (replaces the O(N log N) `scores.sort_by(..)` + `take(initial_k)` of
+// /root/reference/src/rag_engine.rs:543-548; the final ordering of the handful of
+// candidates happens in launch_sort_desc after the reference-order re-score).
+//
+// All of it is integer work on 4 bytes per row (0.13 % of the row bytes at 768-d f32);
+// the score array of a 10M-row shard is 40 MB and is served from the Infinity Cache.
+#include "common.h"
+#include "kernels.h"
+
+namespace rlr {
+
+namespace {
+
+constexpr int kSelThreads = 256;
+
+__device__ inline void block_hist_flush(const uint32_t *s_hist, uint32_t *g_hist)
+{
+    for (int i = threadIdx.x; i < kHistBins; i += blockDim.x) {
+        uint32_t c = s_hist[i];
+        if (c)
+            atomicAdd(&g_hist[i], c);
+    }
+}
+
+// digit 1: key bits 31..21 of every score
+__global__ __launch_bounds__(kSelThreads) void hist1_kernel(const float *__restrict__ scores,
+                                                            uint32_t n, uint32_t *__restrict__ g_hist)
+{
+    __shared__ uint32_t s_hist[kHistBins];
+    for (int i = threadIdx.x; i < kHistBins; i += kSelThreads)
+        s_hist[i] = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kSelThreads;
+    const uint32_t n4 = n / 4;
+    const float4 *s4 = reinterpret_cast<const float4 *>(scores);
+    for (uint32_t i = blockIdx.x * kSelThreads + threadIdx.x; i < n4; i += stride) {
+        const float4 v = s4[i];
+        atomicAdd(&s_hist[score_key(v.x) >> 21], 1u);
+        atomicAdd(&s_hist[score_key(v.y) >> 21], 1u);
+        atomicAdd(&s_hist[score_key(v.z) >> 21], 1u);
+        atomicAdd(&s_hist[score_key(v.w) >> 21], 1u);
+    }
+    for (uint32_t i = n4 * 4 + blockIdx.x * kSelThreads + threadIdx.x; i < n; i += stride)
+        atomicAdd(&s_hist[score_key(scores[i]) >> 21], 1u);
+    __syncthreads();
+    block_hist_flush(s_hist, g_hist);
+}
+
+// digit 2: key bits 20..10 of the scores whose digit 1 equals st->bin1
+__global__ __launch_bounds__(kSelThreads) void hist2_kernel(const float *__restrict__ scores,
+                                                            uint32_t n,
+                                                            const SelectState *__restrict__ st,
+                                                            uint32_t *__restrict__ g_hist)
+{
+    __shared__ uint32_t s_hist[kHistBins];
+    for (int i = threadIdx.x; i < kHistBins; i += kSelThreads)
+        s_hist[i] = 0;
+    __syncthreads();
+    const uint32_t bin1 = st->bin1;
+    const uint32_t stride = gridDim.x * kSelThreads;
+    const uint32_t n4 = n / 4;
+    const float4 *s4 = reinterpret_cast<const float4 *>(scores);
+    for (uint32_t i = blockIdx.x * kSelThreads + threadIdx.x; i < n4; i += stride) {
+        const float4 v = s4[i];
+        const uint32_t k0 = score_key(v.x), k1 = score_key(v.y), k2 = score_key(v.z),
+                       k3 = score_key(v.w);
+        if ((k0 >> 21) == bin1) atomicAdd(&s_hist[(k0 >> 10) & (kHistBins - 1)], 1u);
+        if ((k1 >> 21) == bin1) atomicAdd(&s_hist[(k1 >> 10) & (kHistBins - 1)], 1u);
+        if ((k2 >> 21) == bin1) atomicAdd(&s_hist[(k2 >> 10) & (kHistBins - 1)], 1u);
+        if ((k3 >> 21) == bin1) atomicAdd(&s_hist[(k3 >> 10) & (kHistBins - 1)], 1u);
+    }
+    for (uint32_t i = n4 * 4 + blockIdx.x * kSelThreads + threadIdx.x; i < n; i += stride) {
+        const uint32_t k0 = score_key(scores[i]);
+        if ((k0 >> 21) == bin1) atomicAdd(&s_hist[(k0 >> 10) & (kHistBins - 1)], 1u);
+    }
+    __syncthreads();
+    block_hist_flush(s_hist, g_hist);
+}
+
+// One workgroup: find the bin holding the `rank`-th largest key (rank is 1-based)
+// by a suffix sum from the top bin.  Returns (bin, rank inside the bin) to every thread.
+__device__ inline void find_rank_bin(const uint32_t *__restrict__ hist, uint32_t rank,
+                                     uint32_t *bin_out, uint32_t *rank_in_bin)
+{
+    constexpr int PER = kHistBins / kSelThreads; // 8 bins per thread
+    __shared__ uint32_t s_part[kSelThreads];
+    __shared__ uint32_t s_res[2];
+    const int t = threadIdx.x;
+    uint32_t loc[PER];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        loc[i] = hist[t * PER + i];
+        sum += loc[i];
+    }
+    s_part[t] = sum;
+    if (t == 0) {
+        s_res[0] = 0;
+        s_res[1] = 1;
+    }
+    __syncthreads();
+    // inclusive suffix sum over threads (Hillis-Steele, 8 steps)
+    for (int off = 1; off < kSelThreads; off <<= 1) {
+        uint32_t add = (t + off < kSelThreads) ? s_part[t + off] : 0;
+        __syncthreads();
+        s_part[t] += add;
+        __syncthreads();
+    }
+    // above = number of keys in bins owned by higher threads
+    uint32_t above = (t + 1 < kSelThreads) ? s_part[t + 1] : 0;
+#pragma unroll
+    for (int i = PER - 1; i >= 0; --i) {
+        const uint32_t with = above + loc[i];
+        if (above < rank && rank <= with) {
+            s_res[0] = t * PER + i;
+            s_res[1] = rank - above;
+        }
+        above = with;
+    }
+    __syncthreads();
+    *bin_out = s_res[0];
+    *rank_in_bin = s_res[1];
+}
+
+__global__ __launch_bounds__(kSelThreads) void find1_kernel(const uint32_t *__restrict__ hist1,
+                                                            SelectState *st)
+{
+    uint32_t bin, rk;
+    find_rank_bin(hist1, st->k, &bin, &rk);
+    if (threadIdx.x == 0) {
+        st->bin1 = bin;
+        st->k2 = rk;
+    }
+}
+
+__global__ __launch_bounds__(kSelThreads) void find2_kernel(const uint32_t *__restrict__ hist2,
+                                                            SelectState *st, float two_eps)
+{
+    uint32_t bin, rk;
+    find_rank_bin(hist2, st->k2, &bin, &rk);
+    if (threadIdx.x == 0) {
+        st->bin2 = bin;
+        // lower edge of the 22-bit prefix bin that holds the k-th largest score:
+        // floor <= k-th score, and the bin is 2^10 keys wide.
+        const uint32_t key_floor = (st->bin1 << 21) | (bin << 10);
+        uint32_t key_lo = 0;
+        if (key_floor != 0) {
+            const float floor_score = key_score(key_floor);
+            const float lo = floor_score - two_eps; // -inf stays -inf
+            key_lo = score_key(lo);
+            if (key_lo > key_floor)
+                key_lo = key_floor;
+        }
+        st->key_lo = key_lo;
+        st->n_cand = 0;
+    }
+}
+
+__global__ __launch_bounds__(kSelThreads) void collect_kernel(const float *__restrict__ scores,
+                                                              uint32_t n, SelectState *st,
+                                                              uint32_t *__restrict__ cand)
+{
+    const uint32_t key_lo = st->key_lo;
+    const uint32_t cap = st->cap;
+    const uint32_t stride = gridDim.x * kSelThreads;
+    const uint32_t n4 = n / 4;
+    const float4 *s4 = reinterpret_cast<const float4 *>(scores);
+    for (uint32_t i = blockIdx.x * kSelThreads + threadIdx.x; i < n4; i += stride) {
+        const float4 v = s4[i];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (score_key(e[j]) >= key_lo) {
+                const uint32_t slot = atomicAdd(&st->n_cand, 1u);
+                if (slot < cap)
+                    cand[slot] = i * 4 + j;
+            }
+        }
+    }
+    for (uint32_t i = n4 * 4 + blockIdx.x * kSelThreads + threadIdx.x; i < n; i += stride) {
+        if (score_key(scores[i]) >= key_lo) {
+            const uint32_t slot = atomicAdd(&st->n_cand, 1u);
+            if (slot < cap)
+                cand[slot] = i;
+        }
+    }
+}
+
+// ---- descending sort of packed u64 ------------------------------------------------
+constexpr int kSortLds = 4096; // entries sorted inside one workgroup's LDS (32 KB)
+
+__global__ __launch_bounds__(1024) void sort_lds_kernel(uint64_t *data, uint32_t n_pad)
+{
+    __shared__ uint64_t s[kSortLds];
+    for (uint32_t i = threadIdx.x; i < n_pad; i += 1024)
+        s[i] = data[i];
+    __syncthreads();
+    for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n_pad; i += 1024) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = s[i], b = s[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n_pad; i += 1024)
+        data[i] = s[i];
+}
+
+// one (k, j) step of a global-memory bitonic network (band-overflow path only)
+__global__ __launch_bounds__(256) void sort_global_step(uint64_t *data, uint32_t n_pad, uint32_t k,
+                                                        uint32_t j)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad)
+        return;
+    const uint32_t ixj = i ^ j;
+    if (ixj > i) {
+        const uint64_t a = data[i], b = data[ixj];
+        const bool desc = (i & k) == 0;
+        if (desc ? (a < b) : (a > b)) {
+            data[i] = b;
+            data[ixj] = a;
+        }
+    }
+}
+
+uint32_t sel_blocks(uint32_t n, int n_cu)
+{
+    uint32_t want = (n / 4 + kSelThreads - 1) / kSelThreads;
+    uint32_t cap = static_cast<uint32_t>(n_cu) * 8;
+    if (want > cap) want = cap;
+    return want ? want : 1;
+}
+
+} // namespace
+
+hipError_t launch_hist1(const float *scores, uint32_t n, uint32_t *hist1, int n_cu, hipStream_t s)
+{
+    hipLaunchKernelGGL(hist1_kernel, dim3(sel_blocks(n, n_cu)), dim3(kSelThreads), 0, s, scores, n,
+                       hist1);
+    return hipGetLastError();
+}
+
+hipError_t launch_find1(const uint32_t *hist1, SelectState *st, hipStream_t s)
+{
+    hipLaunchKernelGGL(find1_kernel, dim3(1), dim3(kSelThreads), 0, s, hist1, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_hist2(const float *scores, uint32_t n, const SelectState *st, uint32_t *hist2,
+                        int n_cu, hipStream_t s)
+{
+    hipLaunchKernelGGL(hist2_kernel, dim3(sel_blocks(n, n_cu)), dim3(kSelThreads), 0, s, scores, n,
+                       st, hist2);
+    return hipGetLastError();
+}
+
+hipError_t launch_find2(const uint32_t *hist2, SelectState *st, float two_eps, hipStream_t s)
+{
+    hipLaunchKernelGGL(find2_kernel, dim3(1), dim3(kSelThreads), 0, s, hist2, st, two_eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_collect(const float *scores, uint32_t n, SelectState *st, uint32_t *cand,
+                          int n_cu, hipStream_t s)
+{
+    hipLaunchKernelGGL(collect_kernel, dim3(sel_blocks(n, n_cu)), dim3(kSelThreads), 0, s, scores, n,
+                       st, cand);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_desc(uint64_t *packed, uint32_t n_pad, hipStream_t s)
+{
+    if (n_pad <= 1)
+        return hipSuccess;
+    if (n_pad <= kSortLds) {
+        hipLaunchKernelGGL(sort_lds_kernel, dim3(1), dim3(1024), 0, s, packed, n_pad);
+        return hipGetLastError();
+    }
+    const uint32_t blocks = (n_pad + 255) / 256;
+    for (uint32_t k = 2; k <= n_pad; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1)
+            hipLaunchKernelGGL(sort_global_step, dim3(blocks), dim3(256), 0, s, packed, n_pad, k, j);
+    return hipGetLastError();
+}
+
+} // namespace rlr

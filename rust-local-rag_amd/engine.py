@@ -1,0 +1,240 @@
+"""RagEngine: the reference's search-side operator interface over the GPU index.
+
+Mirrors rust-local-rag `RagEngine::{search, search_with_diversity,
+get_embedding_candidates}` (src/rag_engine.rs:470-701, :717-759, :415-461) and the API
+layer `search_documents` / `http_search` / `format_search_results`
+(src/mcp_server.rs:81-110, :371-389, :599-637) -- same names, argument meaning and
+edge-case behaviour.  The numerics run in librlr_gpu.so (csrc/engine.cpp + HIP kernels);
+this file only carries chunk metadata and marshals arguments.
+
+Outside this path and therefore passed IN by the caller: the query *embedding* (the
+reference obtains it from Ollama, embeddings.rs:91-102), BM25 candidates
+(`LexicalIndex::score`) as (chunk_id, score) pairs, and the LLM reranker.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import uuid
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+from .index import GpuIndex, _f32
+
+
+@dataclass
+class QueryWeights:  # rag_engine.rs:1846-1865
+    embedding: Optional[float] = None
+    lexical: Optional[float] = None
+    reranker: Optional[float] = None
+    initial: Optional[float] = None
+
+    def to_c(self) -> N.QueryWeightsC:
+        c = N.QueryWeightsC()
+        for name in ("embedding", "lexical", "reranker", "initial"):
+            v = getattr(self, name)
+            setattr(c, "has_" + name, int(v is not None))
+            setattr(c, name, float(v) if v is not None else 0.0)
+        return c
+
+
+@dataclass
+class ResolvedWeights:  # rag_engine.rs:1877-1896
+    embedding: float
+    lexical: float
+    reranker: float
+    initial: float
+
+    @staticmethod
+    def from_query_weights(weights: Optional[QueryWeights]) -> "ResolvedWeights":
+        out = N.ResolvedWeightsC()
+        if weights is None:
+            N.lib().rlr_resolve_weights(None, C.byref(out))
+        else:
+            c = weights.to_c()
+            N.lib().rlr_resolve_weights(C.byref(c), C.byref(out))
+        return ResolvedWeights(out.embedding, out.lexical, out.reranker, out.initial)
+
+
+def resolve_weight(override: Optional[float], default: float) -> float:
+    """rag_engine.rs:1869-1873"""
+    has = override is not None
+    return float(N.lib().rlr_resolve_weight(int(has), float(override) if has else 0.0, float(default)))
+
+
+def normalize(v) -> np.ndarray:
+    """rag_engine.rs:1763-1771 (host side, reference order)"""
+    a = _f32(v).copy()
+    N.lib().rlr_normalize(a.ctypes.data_as(N.f32p), a.size)
+    return a
+
+
+@dataclass
+class DocumentChunk:  # rag_engine.rs:46-59 (embedding lives in HBM, not here)
+    id: str
+    document_name: str
+    text: str
+    chunk_index: int
+    page_number: int = 0
+    section: Optional[str] = None
+
+
+@dataclass
+class SearchResult:  # rag_engine.rs:72-100
+    text: str
+    score: float
+    document: str
+    chunk_id: str
+    chunk_index: int
+    page_number: int
+    section: Optional[str] = None
+    embedding_score: Optional[float] = None
+    lexical_score: Optional[float] = None
+    initial_score: Optional[float] = None
+    reranker_score: Optional[float] = None
+    yes_logprob: Optional[float] = None
+    no_logprob: Optional[float] = None
+    row: int = -1  # position in the GPU matrix (not part of the reference struct)
+
+    def to_json(self) -> dict:
+        """serde shape incl. skip_serializing_if = Option::is_none (rag_engine.rs:83-99)"""
+        d = {"text": self.text, "score": self.score, "document": self.document, "chunk_id": self.chunk_id,
+             "chunk_index": self.chunk_index, "page_number": self.page_number, "section": self.section}
+        for k in ("embedding_score", "lexical_score", "initial_score", "reranker_score", "yes_logprob", "no_logprob"):
+            v = getattr(self, k)
+            if v is not None:
+                d[k] = v
+        return d
+
+
+@dataclass
+class SearchRequest:  # mcp_server.rs:17-31
+    query_embedding: Sequence[float]
+    top_k: Optional[int] = None
+    diversity_factor: Optional[float] = None
+    weights: Optional[QueryWeights] = None
+    lexical: Sequence[Tuple[str, float]] = field(default_factory=list)
+
+
+class RagEngine:
+    """Search half of the reference's RagEngine with the embeddings resident on one GPU."""
+
+    def __init__(self, dim: int, dtype: str = "f32", device: int = 0):
+        self.index = GpuIndex(dim, dtype, device)
+        self.dim = dim
+        self._chunks: List[DocumentChunk] = []       # row -> chunk
+        self._row_of: Dict[str, int] = {}            # chunk_id -> row
+
+    def close(self) -> None:
+        self.index.close()
+
+    # -- index mutation (sites rag_engine.rs:347-348, :358-384) --------------------------
+    def add_document(self, document_name: str, texts: Sequence[str], embeddings, pages: Optional[Sequence[int]] = None,
+                     sections: Optional[Sequence[Optional[str]]] = None) -> List[str]:
+        """Replace `document_name`'s chunks: drop its old rows, normalise and append the new ones."""
+        self.remove_document(document_name)
+        emb = _f32(embeddings).reshape(len(texts), self.dim)
+        first = self.index.append(emb, normalize=True)  # normalize(&mut embedding) :358-359, on the GPU
+        ids = []
+        for i, text in enumerate(texts):
+            cid = str(uuid.uuid4())
+            ch = DocumentChunk(cid, document_name, text, i, pages[i] if pages else 0, sections[i] if sections else None)
+            self._chunks.append(ch)
+            self._row_of[cid] = first + i
+            ids.append(cid)
+        return ids
+
+    def remove_document(self, document_name: str) -> int:
+        dead = [r for r, ch in enumerate(self._chunks) if ch.document_name == document_name]
+        if dead:
+            self.index.delete_rows(dead)  # chunks.retain(|_, c| c.document_name != filename)
+            dead_set = set(dead)
+            self._chunks = [ch for r, ch in enumerate(self._chunks) if r not in dead_set]
+            self._row_of = {ch.id: r for r, ch in enumerate(self._chunks)}
+        return len(dead)
+
+    def __len__(self) -> int:
+        return len(self._chunks)
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _lex(self, lexical: Sequence[Tuple[str, float]]):
+        rows = [self._row_of[cid] for cid, _ in lexical if cid in self._row_of]
+        scores = [s for cid, s in lexical if cid in self._row_of]
+        lr = np.ascontiguousarray(rows if rows else [0], dtype=np.uint64)
+        ls = np.ascontiguousarray(scores if scores else [0], dtype=np.float32)
+        return lr, ls, len(rows)
+
+    def _results(self, hits, n: int) -> List[SearchResult]:
+        out = []
+        for i in range(n):
+            h = hits[i]
+            ch = self._chunks[h.row]
+            out.append(SearchResult(ch.text, float(h.score), ch.document_name, ch.id, ch.chunk_index, ch.page_number,
+                                    ch.section, float(h.embedding_score), float(h.lexical_score),
+                                    float(h.initial_score), None, None, None, int(h.row)))
+        return out
+
+    # -- RagEngine::search (rag_engine.rs:470-701) -----------------------------------------
+    def search(self, query_embedding, top_k: int, weights: Optional[QueryWeights] = None,
+               lexical: Sequence[Tuple[str, float]] = (), stage: int = 0) -> List[SearchResult]:
+        q = _f32(query_embedding).ravel()
+        cap = max(3 * max(top_k, 1), 1)
+        hits = (N.SearchHitC * cap)()
+        n = C.c_uint32()
+        lr, ls, nl = self._lex(lexical)
+        wc = weights.to_c() if weights is not None else None
+        N.check(N.lib().rlr_engine_search(self.index.handle, q.ctypes.data_as(N.f32p), q.size, top_k,
+                                          C.byref(wc) if wc is not None else None, lr.ctypes.data_as(N.u64p),
+                                          ls.ctypes.data_as(N.f32p), nl, stage, hits, cap, C.byref(n)))
+        return self._results(hits, n.value)
+
+    # -- RagEngine::search_with_diversity (rag_engine.rs:717-759) --------------------------
+    def search_with_diversity(self, query_embedding, top_k: int, diversity_factor: float,
+                              weights: Optional[QueryWeights] = None,
+                              lexical: Sequence[Tuple[str, float]] = ()) -> List[SearchResult]:
+        q = _f32(query_embedding).ravel()
+        cap = max(3 * max(top_k, 1), top_k + 10)
+        hits = (N.SearchHitC * cap)()
+        n = C.c_uint32()
+        lr, ls, nl = self._lex(lexical)
+        wc = weights.to_c() if weights is not None else None
+        N.check(N.lib().rlr_engine_search_with_diversity(
+            self.index.handle, q.ctypes.data_as(N.f32p), q.size, top_k, float(diversity_factor),
+            C.byref(wc) if wc is not None else None, lr.ctypes.data_as(N.u64p), ls.ctypes.data_as(N.f32p), nl,
+            hits, cap, C.byref(n)))
+        return self._results(hits, n.value)
+
+    # -- RagEngine::get_embedding_candidates (rag_engine.rs:415-461) -----------------------
+    def get_embedding_candidates(self, query_embedding, count: int) -> List[Tuple[str, float]]:
+        q = _f32(query_embedding).ravel()
+        rows = np.zeros(max(count, 1), dtype=np.uint64)
+        sc = np.zeros(max(count, 1), dtype=np.float32)
+        n = C.c_uint32()
+        N.check(N.lib().rlr_engine_embedding_candidates(self.index.handle, q.ctypes.data_as(N.f32p), q.size, count,
+                                                        rows.ctypes.data_as(N.u64p), sc.ctypes.data_as(N.f32p),
+                                                        C.byref(n)))
+        return [(self._chunks[int(rows[i])].id, float(sc[i])) for i in range(n.value)]
+
+    # -- API layer: search_documents / http_search (mcp_server.rs:81-110, :371-389) --------
+    def search_documents(self, request: SearchRequest) -> List[SearchResult]:
+        top_k = min(request.top_k if request.top_k is not None else N.DEFAULT_TOP_K, N.MAX_TOP_K)
+        div = request.diversity_factor if request.diversity_factor is not None else N.DEFAULT_DIVERSITY
+        div = min(max(div, 0.0), 1.0)
+        return self.search_with_diversity(request.query_embedding, top_k, div, request.weights, request.lexical)
+
+
+def format_search_results(results: Sequence[SearchResult]) -> str:
+    """mcp_server.rs:599-637"""
+    if not results:
+        return "No results found."
+    parts = []
+    for i, r in enumerate(results):
+        provenance = f"{r.document} (page {r.page_number})" if r.page_number > 0 else r.document
+        section = f"*Section: {r.section}*\n" if r.section is not None else ""
+        x = float(np.float32(r.score) * np.float32(100.0))
+        # f32::round: half away from zero
+        percentage = int(np.floor(abs(x) + 0.5) * (1 if x >= 0 else -1))
+        parts.append(f"**{i + 1}. [{percentage}%] {provenance}**\n{section}\n{r.text}\n")
+    return "\n---\n\n".join(parts)

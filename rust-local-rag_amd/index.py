@@ -1,0 +1,161 @@
+"""GpuIndex: numpy-facing wrapper of the rlr_index C handle (include/rlr_gpu.h)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(N.f32p)
+
+
+def _up(a: np.ndarray):
+    return a.ctypes.data_as(N.u64p)
+
+
+@dataclass
+class Profile:
+    n_searches: int
+    n_scan_launches: int
+    scan_ms: float
+    select_ms: float
+    rescore_ms: float
+    total_ms: float
+    scan_bytes: int
+    n_candidates: int
+    n_retries: int
+
+
+class GpuIndex:
+    """Dense chunk-embedding matrix resident in HBM + the search entry points."""
+
+    def __init__(self, dim: int, dtype: str = "f32", device: int = 0):
+        self._L = N.lib()
+        self._h = C.c_void_p()
+        code = {"f32": N.RLR_F32, "f16": N.RLR_F16}[dtype]
+        N.check(self._L.rlr_index_create(dim, code, device, C.byref(self._h)))
+        self.dim = dim
+        self.dtype = dtype
+        self.device = device
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.rlr_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    def __len__(self) -> int:
+        n = C.c_uint64()
+        N.check(self._L.rlr_index_info(self._h, C.byref(n), None, None, None))
+        return int(n.value)
+
+    # -- mutation -----------------------------------------------------------
+    def upload(self, rows, normalize: bool = False) -> None:
+        rows = _f32(rows).reshape(-1, self.dim) if np.size(rows) else np.zeros((0, self.dim), np.float32)
+        N.check(self._L.rlr_index_upload(self._h, _fp(rows), rows.shape[0], int(normalize)))
+
+    def append(self, rows, normalize: bool = False) -> int:
+        rows = _f32(rows).reshape(-1, self.dim)
+        first = C.c_uint64()
+        N.check(self._L.rlr_index_append(self._h, _fp(rows), rows.shape[0], int(normalize), C.byref(first)))
+        return int(first.value)
+
+    def delete_rows(self, rows) -> None:
+        rows = _u64(rows).ravel()
+        if rows.size:
+            N.check(self._L.rlr_index_delete_rows(self._h, _up(rows), rows.size))
+
+    def reserve(self, n_rows: int) -> None:
+        N.check(self._L.rlr_index_reserve(self._h, n_rows))
+
+    def fill_synthetic(self, n_rows: int, seed: int, row0: int = 0, n_clusters: int = 0) -> None:
+        N.check(self._L.rlr_index_fill_synthetic(self._h, n_rows, row0, seed, n_clusters))
+
+    # -- hot path ------------------------------------------------------------
+    def search_topk(self, queries, k: int, guard_eps: float = -1.0):
+        """queries: [Q, dim] (or [dim]) already normalised -> (rows u64 [Q,k'], cos f32 [Q,k'])"""
+        q = _f32(queries).reshape(-1, self.dim)
+        nq = q.shape[0]
+        rows = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        cos = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        n_out = np.zeros(max(nq, 1), dtype=np.uint32)
+        N.check(self._L.rlr_search_topk(self._h, _fp(q), nq, k, guard_eps, _up(rows), _fp(cos),
+                                        n_out.ctypes.data_as(N.u32p)))
+        kk = int(n_out[0]) if nq else 0
+        return rows[:, :kk], cos[:, :kk]
+
+    def search_topk_device(self, queries, k: int, d_out_ptr: int, stream: int = 0, guard_eps: float = -1.0) -> None:
+        q = _f32(queries).reshape(-1, self.dim)
+        N.check(self._L.rlr_search_topk_device(self._h, _fp(q), q.shape[0], k, guard_eps,
+                                               C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def score_rows(self, query, rows) -> np.ndarray:
+        q = _f32(query).ravel()
+        rows = _u64(rows).ravel()
+        out = np.zeros(rows.size, dtype=np.float32)
+        if rows.size:
+            N.check(self._L.rlr_score_rows(self._h, _fp(q), _up(rows), rows.size, _fp(out)))
+        return out
+
+    def fetch_rows(self, rows) -> np.ndarray:
+        rows = _u64(rows).ravel()
+        out = np.zeros((rows.size, self.dim), dtype=np.float32)
+        if rows.size:
+            N.check(self._L.rlr_fetch_rows(self._h, _up(rows), rows.size, _fp(out)))
+        return out
+
+    def mmr_select(self, pool_rows, pool_scores, k: int, lam: float):
+        pool_rows = _u64(pool_rows).ravel()
+        pool_scores = _f32(pool_scores).ravel()
+        P = pool_rows.size
+        order = np.zeros(max(P, 1), dtype=np.uint32)
+        mmr = np.zeros(max(P, 1), dtype=np.float32)
+        n = C.c_uint32()
+        N.check(self._L.rlr_mmr_select(self._h, _up(pool_rows), _fp(pool_scores), P, k, lam,
+                                       order.ctypes.data_as(N.u32p), _fp(mmr), C.byref(n)))
+        return order[: n.value], mmr[: n.value]
+
+    # -- measurement ---------------------------------------------------------
+    def profile_enable(self, on: bool = True) -> None:
+        N.check(self._L.rlr_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset: bool = False) -> Profile:
+        p = N.ProfileC()
+        N.check(self._L.rlr_profile_read(self._h, C.byref(p), int(reset)))
+        return Profile(*(getattr(p, f) for f, _ in N.ProfileC._fields_))
+
+
+def default_guard_eps(dim: int) -> float:
+    return float(N.lib().rlr_default_guard_eps(dim))
+
+
+def device_count() -> int:
+    return int(N.lib().rlr_device_count())

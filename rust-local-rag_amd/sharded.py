@@ -1,0 +1,124 @@
+"""Row-sharded search across the GPUs of one node: one process per GPU, one RCCL
+all-gather of the per-shard partial top-k per query batch.
+
+Each rank owns a contiguous row range of the corpus in its own GpuIndex.  A query runs
+the full local pipeline (scan -> select -> reference-order re-score -> sort) on every
+rank, the k best (score, local row) pairs stay in device memory in the packed u64 format
+of rlr_search_topk_device, `torch.distributed.all_gather_into_tensor` moves world x k x 8
+bytes over xGMI (3.2 KB for k=100 on 8 GPUs: latency-bound, never the per-link
+bandwidth), and every rank merges the gathered lists.  Local scores are already the
+reference-order values, so the merge is exact: global order = (score desc, global row
+asc) -- shards are ascending row ranges, so (rank, local row) order is global row order.
+
+torch is used for device memory, the process group and the merge's sort only.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from .index import GpuIndex, _f32
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """rows [lo, hi) of rank `rank`: ceil(N/G)-sized contiguous blocks."""
+    per = (n_total + world - 1) // world
+    lo = min(n_total, rank * per)
+    hi = min(n_total, lo + per)
+    return lo, hi
+
+
+def merge_packed(gathered, bases, k: int):
+    """gathered: int64 tensor [world, Q, k] of packed results; bases: int64 tensor [world].
+    Returns (global_rows int64 [Q, k'], score_bits int64 [Q, k']) sorted (score desc, row asc)."""
+    import torch
+
+    world, nq, kk = gathered.shape
+    key = (gathered >> 32) & 0xFFFFFFFF                     # ordered score bits
+    local = 0xFFFFFFFF - (gathered & 0xFFFFFFFF)
+    valid = gathered != 0
+    glob = local + bases.view(world, 1, 1)
+    # one descending int64 per candidate: score key, then lower global row first
+    comp = (key << 31) | ((1 << 31) - 1 - glob)
+    comp = torch.where(valid, comp, torch.full_like(comp, -1))
+    comp = comp.permute(1, 0, 2).reshape(nq, world * kk)
+    top = torch.topk(comp, min(k, world * kk), dim=1, largest=True, sorted=True).values
+    ok = top >= 0
+    rows = torch.where(ok, (1 << 31) - 1 - (top & ((1 << 31) - 1)), torch.full_like(top, -1))
+    skey = torch.where(ok, top >> 31, torch.zeros_like(top))
+    return rows, skey
+
+
+def key_to_score(skey: np.ndarray) -> np.ndarray:
+    """inverse of csrc/common.h score_key for the merged keys (host, numpy)."""
+    k = skey.astype(np.uint64).astype(np.uint32)
+    b = np.where(k & np.uint32(0x80000000), k & np.uint32(0x7FFFFFFF), ~k)
+    out = b.astype(np.uint32).view(np.float32).copy()
+    out[k == 0] = np.nan
+    return out
+
+
+def gather_and_merge(local_packed, bases, k: int, dist=None, group=None, out=None):
+    """The exchange step: all-gather every rank's packed [Q, k] partial top-k (RCCL on GPU
+    tensors, gloo on CPU tensors in the tests) and merge.  Returns merge_packed's result."""
+    import torch
+
+    world = bases.numel()
+    nq, kk = local_packed.shape
+    if world > 1:
+        if out is None:
+            out = torch.zeros((world, nq, kk), dtype=torch.int64, device=local_packed.device)
+        dist.all_gather_into_tensor(out, local_packed.contiguous(), group=group)
+        gathered = out
+    else:
+        gathered = local_packed.view(1, nq, kk)
+    return merge_packed(gathered, bases, k)
+
+
+class ShardedIndex:
+    """One shard per process; collective search over a torch.distributed process group."""
+
+    def __init__(self, dim: int, n_total: int, dtype: str = "f32", device: int = 0, group=None,
+                 rank: Optional[int] = None, world: Optional[int] = None, index: Optional[GpuIndex] = None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.group = group
+        self.rank = rank if rank is not None else (self.dist.get_rank(group) if self.dist else 0)
+        self.world = world if world is not None else (self.dist.get_world_size(group) if self.dist else 1)
+        self.n_total = n_total
+        self.lo, self.hi = shard_range(n_total, self.rank, self.world)
+        if n_total >= (1 << 31):
+            raise ValueError("merge key packs the global row into 31 bits")
+        self.index = index if index is not None else GpuIndex(dim, dtype, device)
+        self.dim = dim
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        self.bases = torch.tensor([shard_range(n_total, r, self.world)[0] for r in range(self.world)],
+                                  dtype=torch.int64, device=self.dev)
+        self._local = None
+        self._gath = None
+
+    def fill_synthetic(self, seed: int, n_clusters: int = 0) -> None:
+        self.index.fill_synthetic(self.hi - self.lo, seed, row0=self.lo, n_clusters=n_clusters)
+
+    def upload_shard(self, rows_global) -> None:
+        self.index.upload(_f32(rows_global)[self.lo:self.hi])
+
+    def search_topk(self, queries, k: int):
+        """-> (global rows int64 [Q,k'], cos f32 [Q,k']) identical on every rank."""
+        torch = self.torch
+        q = _f32(queries).reshape(-1, self.dim)
+        nq = q.shape[0]
+        if self._local is None or self._local.shape != (nq, k):
+            self._local = torch.zeros((nq, k), dtype=torch.int64, device=self.dev)
+            self._gath = torch.zeros((self.world, nq, k), dtype=torch.int64, device=self.dev)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.index.search_topk_device(q, k, self._local.data_ptr(), stream)
+        rows, skey = gather_and_merge(self._local, self.bases, k, self.dist, self.group, self._gath)
+        both = torch.stack([rows, skey]).cpu().numpy()
+        rows_h, skey_h = both[0], both[1]
+        n_valid = int((rows_h[0] >= 0).sum()) if nq else 0
+        return rows_h[:, :n_valid], key_to_score(skey_h[:, :n_valid])

@@ -1,0 +1,292 @@
+"""Parity of the HIP path (through the C ABI) with the oracle -- the tests proper.
+Bit-exact: identical top-k row sets in identical order, scores equal as bit patterns."""
+import numpy as np
+import pytest
+
+from conftest import bits, pf
+from test_oracle_kats import check_mmr_case
+
+pytestmark = pytest.mark.gpu
+
+
+def make_index(rlr, rows, dtype="f32", normalize=False):
+    ix = rlr.GpuIndex(rows.shape[1], dtype)
+    ix.upload(rows, normalize=normalize)
+    return ix
+
+
+def oracle_topk(oracle, rows, qn, k):
+    e = oracle.scan(rows, qn)
+    key = np.where(np.isnan(e), -np.inf, e)
+    order = np.lexsort((np.arange(len(e)), -key.astype(np.float64)))[:k]
+    return order.astype(np.uint64), e[order]
+
+
+# ---------------------------------------------------------------- KATs through the ABI
+def test_cosine_kats_on_gpu(rlr, oracle, kats):
+    """dot of normalised == cosine (rag_engine.rs:2776-2799), evaluated by the GPU."""
+    for case in kats["cosine"]:
+        a, b = np.array(case["a"], np.float32), np.array(case["b"], np.float32)
+        if a.size != b.size or a.size == 0:
+            continue  # cosine_similarity's length/empty guards are host-only (dead code in production)
+        ix = make_index(rlr, b.reshape(1, -1), normalize=True)
+        got = float(ix.score_rows(rlr.normalize(a), [0])[0])
+        want = oracle.dot(oracle.normalize(a), oracle.normalize(b))
+        assert np.float32(got).view(np.uint32) == np.float32(want).view(np.uint32), case["name"]
+        if "approx" in case:
+            assert abs(got - case["approx"]) < case["tol"]
+        ix.close()
+    dim = kats["cosine_ramp"]["dim"]
+    a = np.arange(dim, dtype=np.float32) / np.float32(dim)
+    b = (np.arange(dim, dtype=np.float32) + np.float32(10)) / np.float32(dim)
+    ix = make_index(rlr, b.reshape(1, -1), normalize=True)
+    rows, cos = ix.search_topk(rlr.normalize(a), 1)
+    assert abs(float(cos[0, 0]) - oracle.cosine(a, b)) < 1e-6
+    ix.close()
+
+
+def test_mmr_kats_on_gpu(rlr, kats):
+    for case in kats["mmr"]:
+        cands = case["candidates"]
+        if not cands:
+            ix = rlr.GpuIndex(3)
+            order, _ = ix.mmr_select([], [], case["top_k"], case["lambda"])
+            assert len(order) == 0
+            continue
+        ids = [c[0] for c in cands]
+        emb = np.array([c[2] for c in cands], np.float32)
+        ix = make_index(rlr, emb)  # stored as given, like the test twin (no normalisation)
+        order, _ = ix.mmr_select(np.arange(len(ids)), [pf(c[1]) for c in cands], case["top_k"], case["lambda"])
+        check_mmr_case(case, [ids[i] for i in order])
+        ix.close()
+
+
+# ---------------------------------------------------------------- scan + top-k
+@pytest.mark.parametrize("n,dim,k", [(1000, 768, 5), (4096, 768, 100), (3000, 1024, 300), (777, 384, 50),
+                                     (513, 100, 17), (50, 768, 100), (20000, 768, 900)])
+def test_search_topk_bit_exact(rlr, oracle, n, dim, k):
+    rows = oracle.synth_rows(n, dim, seed=100 + n)
+    qn = oracle.normalize(oracle.synth_query(dim, seed=200 + n))
+    ix = make_index(rlr, rows)
+    got_rows, got_cos = ix.search_topk(qn, k)
+    want_rows, want_cos = oracle_topk(oracle, rows, qn, k)
+    assert got_rows.shape[1] == min(k, n)
+    assert np.array_equal(got_rows[0], want_rows)
+    assert np.array_equal(bits(got_cos[0]), bits(want_cos))
+    ix.close()
+
+
+def test_synthetic_fill_matches_oracle_generator(rlr, oracle):
+    for dim, dtype, ncl in ((768, "f32", 0), (1024, "f16", 0), (96, "f32", 5)):
+        ix = rlr.GpuIndex(dim, dtype)
+        ix.fill_synthetic(300, seed=42, row0=1000, n_clusters=ncl)
+        got = ix.fetch_rows(np.arange(300))
+        want = oracle.synth_rows(300, dim, seed=42, row0=1000, n_clusters=ncl, f16=(dtype == "f16"))
+        assert np.array_equal(bits(got), bits(want)), (dim, dtype)
+        ix.close()
+
+
+def test_upload_normalize_on_device_bit_exact(rlr, oracle):
+    rng = np.random.default_rng(5)
+    raw = (rng.standard_normal((500, 768)) * 3).astype(np.float32)
+    raw[7] = 0          # zero vector stays as it is (norm_sq <= 1e-20)
+    raw[8] = 1e-12      # tiny vector too
+    ix = make_index(rlr, raw, normalize=True)
+    want = np.stack([oracle.normalize(r) for r in raw])
+    assert np.array_equal(bits(ix.fetch_rows(np.arange(500))), bits(want))
+    ix.close()
+
+
+def test_batched_queries_equal_looped_single_queries(rlr, oracle):
+    rows = oracle.synth_rows(5000, 768, seed=9)
+    qs = np.stack([oracle.normalize(oracle.synth_query(768, seed=300 + i)) for i in range(7)])
+    ix = make_index(rlr, rows)
+    r, c = ix.search_topk(qs, 20)
+    for i in range(7):
+        wr, wc = oracle_topk(oracle, rows, qs[i], 20)
+        assert np.array_equal(r[i], wr) and np.array_equal(bits(c[i]), bits(wc))
+    ix.close()
+
+
+def test_duplicate_chunks_overflow_the_guard_band(rlr, oracle):
+    """Thousands of identical rows tie exactly at the top: the band holds > 4096
+    candidates and the large-candidate path must still return row-ascending ties."""
+    base = oracle.synth_rows(3000, 768, seed=21)
+    q = oracle.synth_query(768, seed=22)
+    dup = oracle.normalize(q + np.float32(0.01) * base[0])
+    rows = np.concatenate([base, np.repeat(dup[None, :], 6000, axis=0)])
+    ix = make_index(rlr, rows)
+    qn = oracle.normalize(q)
+    got_rows, got_cos = ix.search_topk(qn, 10)
+    assert list(got_rows[0]) == list(range(3000, 3010))
+    assert np.all(bits(got_cos[0]) == bits([oracle.dot(qn, dup)])[0])
+    assert ix.profile_read().n_retries >= 1
+    ix.close()
+
+
+def test_nan_and_zero_rows(rlr, oracle):
+    rows = oracle.synth_rows(300, 768, seed=31)
+    rows[5] = 0.0
+    rows[9, 3] = np.nan
+    qn = oracle.normalize(oracle.synth_query(768, seed=32))
+    ix = make_index(rlr, rows)
+    got_rows, got_cos = ix.search_topk(qn, 300)
+    assert got_rows[0, -1] == 9 and np.isnan(got_cos[0, -1])       # NaN orders last
+    wr, wc = oracle_topk(oracle, rows, qn, 300)
+    assert np.array_equal(got_rows[0], wr)
+    assert np.array_equal(bits(got_cos[0][:-1]), bits(wc[:-1]))
+    ix.close()
+
+
+def test_fp16_rows(rlr, oracle):
+    rows = oracle.synth_rows(4000, 1024, seed=41, f16=True)  # rounded to fp16 after normalisation
+    qn = oracle.normalize(oracle.synth_query(1024, seed=42))
+    ix = rlr.GpuIndex(1024, "f16")
+    ix.upload(oracle.synth_rows(4000, 1024, seed=41), normalize=False)  # the library rounds on store
+    got_rows, got_cos = ix.search_topk(qn, 100)
+    wr, wc = oracle_topk(oracle, rows, qn, 100)
+    assert np.array_equal(got_rows[0], wr) and np.array_equal(bits(got_cos[0]), bits(wc))
+    ix.close()
+
+
+# ---------------------------------------------------------------- mutation
+def test_append_and_delete_rows(rlr, oracle):
+    rows = oracle.synth_rows(1200, 768, seed=51)
+    ix = make_index(rlr, rows[:700])
+    assert ix.append(rows[700:]) == 700 and len(ix) == 1200
+    dead = np.array([0, 5, 5, 699, 700, 1199, 300], dtype=np.uint64)
+    ix.delete_rows(dead)
+    keep = np.setdiff1d(np.arange(1200), dead)
+    assert len(ix) == len(keep)
+    assert np.array_equal(bits(ix.fetch_rows(np.arange(len(keep)))), bits(rows[keep]))
+    qn = oracle.normalize(oracle.synth_query(768, seed=52))
+    got_rows, got_cos = ix.search_topk(qn, 25)
+    wr, wc = oracle_topk(oracle, rows[keep], qn, 25)
+    assert np.array_equal(got_rows[0], wr) and np.array_equal(bits(got_cos[0]), bits(wc))
+    with pytest.raises(rlr.RlrError):
+        ix.delete_rows([len(keep)])
+    ix.close()
+
+
+def test_empty_index_and_k_zero(rlr):
+    ix = rlr.GpuIndex(768)
+    r, c = ix.search_topk(np.zeros(768, np.float32), 5)
+    assert r.shape == (1, 0)
+    ix.upload(np.ones((3, 768), np.float32), normalize=True)
+    r, c = ix.search_topk(np.zeros(768, np.float32), 0)
+    assert r.shape == (1, 0)
+    ix.close()
+
+
+# ---------------------------------------------------------------- engine level
+def build_engine(rlr, rows, dtype="f32"):
+    eng = rlr.RagEngine(rows.shape[1], dtype)
+    ids = []
+    per_doc = 250
+    for d0 in range(0, rows.shape[0], per_doc):
+        part = rows[d0:d0 + per_doc]
+        ids += eng.add_document(f"doc{d0 // per_doc}.pdf", [f"chunk {d0 + i}" for i in range(len(part))], part,
+                                pages=[1 + i % 7 for i in range(len(part))])
+    return eng, ids
+
+
+def test_engine_search_matches_oracle_c1(rlr, oracle):
+    """BASELINE config 1: 1k x 768, single query, top_k=5, diversity 0.0."""
+    raw = (np.random.default_rng(61).standard_normal((1000, 768))).astype(np.float32)
+    eng, ids = build_engine(rlr, raw)
+    rows = np.stack([oracle.normalize(r) for r in raw])
+    q = oracle.synth_query(768, seed=62)
+    got = eng.search_with_diversity(q, 5, 0.0)
+    wr, wc, we, wl = oracle.search(rows, q, 5)
+    assert [g.row for g in got] == list(wr)
+    assert np.array_equal(bits([g.score for g in got]), bits(wc))
+    assert np.array_equal(bits([g.embedding_score for g in got]), bits(we))
+    assert all(g.chunk_id == ids[g.row] and g.document == f"doc{g.row // 250}.pdf" for g in got)
+    # stage 1: the 3*top_k reranker candidates
+    cand = eng.search(q, 5, stage=1)
+    assert [g.row for g in cand] == list(oracle.search(rows, q, 5, stage=1)[0])
+    eng.close()
+
+
+def test_engine_hybrid_lexical_and_weights(rlr, oracle):
+    rows = oracle.synth_rows(3000, 768, seed=71)
+    eng, ids = build_engine(rlr, rows)
+    q = oracle.synth_query(768, seed=72)
+    lex_rows = [(10, 3.5), (2999, 7.0), (1500, 0.25), (77, 7.0)]
+    lex = [(ids[r], s) for r, s in lex_rows]
+    for w, (we_, wl_) in ((None, (0.7, 0.3)), (rlr.QueryWeights(embedding=0.2, lexical=0.9), (0.2, 0.9)),
+                          (rlr.QueryWeights(embedding=0.0), (0.0, 0.3))):
+        got = eng.search(q, 10, weights=w, lexical=lex)
+        wr, wc, we, wl = oracle.search(rows, q, 10, w_e=we_, w_l=wl_, lex=lex_rows)
+        assert [g.row for g in got] == list(wr), w
+        assert np.array_equal(bits([g.score for g in got]), bits(wc))
+        assert np.array_equal(bits([g.lexical_score for g in got]), bits(wl))
+    eng.close()
+
+
+@pytest.mark.parametrize("n,dim,k,lam,ncl", [(3000, 768, 5, 0.3, 0), (20000, 768, 100, 0.3, 40),
+                                              (5000, 1024, 100, 0.7, 25), (40, 768, 100, 0.5, 3)])
+def test_engine_search_with_diversity_matches_oracle(rlr, oracle, n, dim, k, lam, ncl):
+    rows = oracle.synth_rows(n, dim, seed=81 + n, n_clusters=ncl)
+    ix_rows = rows
+    eng = rlr.RagEngine(dim)
+    eng.add_document("all.pdf", [str(i) for i in range(n)], ix_rows)  # re-normalising unit rows is what the reference does too
+    stored = eng.index.fetch_rows(np.arange(n))
+    q = oracle.synth_query(dim, seed=82 + n)
+    got = eng.search_with_diversity(q, k, lam)
+    wr, wc, we, wl = oracle.search_with_diversity(stored, q, k, lam)
+    assert [g.row for g in got] == list(wr)
+    assert np.array_equal(bits([g.score for g in got]), bits(wc))
+    eng.close()
+
+
+def test_mmr_select_values_bit_exact(rlr, oracle):
+    rows = oracle.synth_rows(2000, 768, seed=91, n_clusters=12)
+    ix = make_index(rlr, rows)
+    qn = oracle.normalize(oracle.synth_query(768, seed=92))
+    pr, pc = ix.search_topk(qn, 300)
+    scores = (np.float32(0.7) * pc[0]).astype(np.float32)
+    order, mmr = ix.mmr_select(pr[0], scores, 100, 0.3)
+    worder, wmmr = oracle.mmr(rows[pr[0].astype(np.int64)], scores, 100, 0.3)
+    assert np.array_equal(order, worder)
+    assert np.isnan(mmr[0]) and np.array_equal(bits(mmr[1:]), bits(wmmr[1:]))
+    # k = 0 still yields the first candidate
+    assert list(ix.mmr_select(pr[0], scores, 0, 0.3)[0]) == [0]
+    ix.close()
+
+
+def test_search_documents_defaults_and_caps(rlr, oracle):
+    rows = oracle.synth_rows(2000, 768, seed=95)
+    eng, _ = build_engine(rlr, rows)
+    stored = eng.index.fetch_rows(np.arange(2000))
+    q = oracle.synth_query(768, seed=96)
+    res = eng.search_documents(rlr.SearchRequest(q))           # top_k 5, diversity 0.3
+    assert [r.row for r in res] == list(oracle.search_with_diversity(stored, q, 5, 0.3)[0])
+    res = eng.search_documents(rlr.SearchRequest(q, top_k=5000, diversity_factor=7.0))  # cap 100, clamp 1.0
+    assert [r.row for r in res] == list(oracle.search_with_diversity(stored, q, 100, 1.0)[0])
+    text = rlr.format_search_results(res[:2])
+    assert text.startswith("**1. [") and "(page " in text
+    eng.close()
+
+
+def test_concurrent_readers(rlr, oracle):
+    import threading
+    rows = oracle.synth_rows(8000, 768, seed=97)
+    ix = make_index(rlr, rows)
+    qs = [oracle.normalize(oracle.synth_query(768, seed=400 + i)) for i in range(8)]
+    want = [oracle_topk(oracle, rows, q, 30) for q in qs]
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                r, c = ix.search_topk(qs[i], 30)
+                assert np.array_equal(r[0], want[i][0]) and np.array_equal(bits(c[0]), bits(want[i][1]))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    ix.close()
