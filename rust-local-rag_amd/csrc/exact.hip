@@ -128,11 +128,35 @@ __global__ __launch_bounds__(64) void sumsq_kernel(const float *__restrict__ sta
     sumsq[r] = s;
 }
 
+// Correctly rounded sqrtf for positive normal x.  gfx950's v_sqrt_f32 is accurate to 1 ulp,
+// not correctly rounded (and hipcc emits it bare for sqrtf/__fsqrt_rn), so the result is
+// checked against the two neighbouring rounding boundaries in exact arithmetic: a boundary
+// m = (y + y')/2 has <= 25 significant bits, so m*m is exact in binary64, and sqrt(x) can
+// never sit exactly on a boundary (m*m needs more than 24 bits).
+__device__ inline float sqrt_rn(float x)
+{
+    float y = __builtin_sqrtf(x);
+    const double xd = static_cast<double>(x);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const uint32_t yb = __builtin_bit_cast(uint32_t, y);
+        const float up = __builtin_bit_cast(float, yb + 1u);
+        const float dn = __builtin_bit_cast(float, yb - 1u);
+        const double m_hi = 0.5 * (static_cast<double>(y) + static_cast<double>(up));
+        const double m_lo = 0.5 * (static_cast<double>(y) + static_cast<double>(dn));
+        if (xd > m_hi * m_hi)
+            y = up;
+        else if (xd < m_lo * m_lo)
+            y = dn;
+    }
+    return y;
+}
+
 __device__ inline float ref_scale(float v, float norm_sq, int do_normalize)
 {
     // `if norm_sq > 1e-20 { x /= norm_sq.sqrt() }`  (rag_engine.rs:1765-1769)
     if (do_normalize && norm_sq > 1e-20f)
-        return __fdiv_rn(v, __fsqrt_rn(norm_sq));
+        return __fdiv_rn(v, sqrt_rn(norm_sq));
     return v;
 }
 

@@ -209,8 +209,8 @@ def test_engine_search_matches_oracle_c1(rlr, oracle):
 
 
 def test_engine_hybrid_lexical_and_weights(rlr, oracle):
-    rows = oracle.synth_rows(3000, 768, seed=71)
-    eng, ids = build_engine(rlr, rows)
+    eng, ids = build_engine(rlr, oracle.synth_rows(3000, 768, seed=71))
+    rows = eng.index.fetch_rows(np.arange(3000))  # add_document re-normalises (rag_engine.rs:358-359)
     q = oracle.synth_query(768, seed=72)
     lex_rows = [(10, 3.5), (2999, 7.0), (1500, 0.25), (77, 7.0)]
     lex = [(ids[r], s) for r, s in lex_rows]
