@@ -59,6 +59,25 @@ def queries_without_oracle(rlr, dim, n, seed):
     return np.stack([rlr.normalize(rng.standard_normal(dim).astype(np.float32)) for _ in range(n)])
 
 
+def pmc_traffic(bytes_per_launch):
+    """HBM bytes per launch of the scan kernel from the committed rocprofv3 --pmc passes of
+    this same command (profiles/rNN_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    separate passes).  PMC counters cannot be read from inside the process, so the figure is
+    quoted from the newest summary whose byte count matches this run's shape; else null."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+            t = float(d["pmc"]["hbm_bytes_per_launch"])
+        except Exception:
+            continue
+        if abs(t - bytes_per_launch) <= 0.05 * bytes_per_launch:
+            best = (t, os.path.basename(f))
+    return best
+
+
 def cpu_baseline(args, rlr):
     """Times the oracle (CPU port of the reference loops) on a bounded sample of the same
     corpus: rows [0, cpu_rows) of the synthetic stream, full search (scan + stable sort +
@@ -194,6 +213,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
+            "traffic_source": None,
             "kernel": "scan_fixed_kernel",
             "bytes_per_launch": bytes_per_launch,
             "kernel_ms": scan_ms,
@@ -204,6 +224,9 @@ def main():
         "band_retries": prof.n_retries,
         "fill_s": round(fill_s, 2),
     }
+    t = pmc_traffic(bytes_per_launch)
+    if t:
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t[0], f"profiles/{t[1]} (rocprofv3 --pmc)"
     if world == 1 and not args.no_cpu and O is not None:
         base, sample_rows, want = cpu_baseline(args, rlr)
         out["cpu_baseline"] = base
