@@ -69,7 +69,8 @@ def gather_and_merge(local_packed, bases, k: int, dist=None, group=None, out=Non
     if world > 1:
         if out is None:
             out = torch.zeros((world, nq, kk), dtype=torch.int64, device=local_packed.device)
-        dist.all_gather_into_tensor(out, local_packed.contiguous(), group=group)
+        # rank-major concatenation along dim 0: the layout both RCCL and gloo accept
+        dist.all_gather_into_tensor(out.view(world * nq, kk), local_packed.contiguous(), group=group)
         gathered = out
     else:
         gathered = local_packed.view(1, nq, kk)

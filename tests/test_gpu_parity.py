@@ -290,3 +290,29 @@ def test_concurrent_readers(rlr, oracle):
     [t.join() for t in th]
     assert not errs, errs
     ix.close()
+
+
+# ---------------------------------------------------------------- sharded path, one rank
+def test_sharded_index_world1_device_results(rlr, oracle):
+    """rlr_search_topk_device + the torch-side merge on the GPU (the N>1 collective itself is
+    covered by the gloo test in test_sharded_cpu.py)."""
+    import importlib
+    import torch  # noqa: F401
+    sharded = importlib.import_module("rust-local-rag_amd.sharded")
+    n, dim, k = 6000, 768, 40
+    sh = sharded.ShardedIndex(dim, n, "f32", device=0, rank=0, world=1)
+    sh.fill_synthetic(seed=505)
+    rows = oracle.synth_rows(n, dim, seed=505)
+    qs = np.stack([oracle.normalize(oracle.synth_query(dim, seed=600 + i)) for i in range(3)])
+    got_rows, got_cos = sh.search_topk(qs, k)
+    for i in range(3):
+        wr, wc = oracle_topk(oracle, rows, qs[i], k)
+        assert np.array_equal(got_rows[i].astype(np.uint64), wr)
+        assert np.array_equal(bits(got_cos[i]), bits(wc))
+    # k larger than the shard: padded tail is dropped
+    sh2 = sharded.ShardedIndex(dim, 30, "f32", device=0, rank=0, world=1)
+    sh2.fill_synthetic(seed=506)
+    r2, c2 = sh2.search_topk(qs[0], 100)
+    assert r2.shape == (1, 30)
+    wr, wc = oracle_topk(oracle, oracle.synth_rows(30, dim, seed=506), qs[0], 100)
+    assert np.array_equal(r2[0].astype(np.uint64), wr) and np.array_equal(bits(c2[0]), bits(wc))

@@ -1,0 +1,113 @@
+"""N>1 path on CPU: two processes, gloo, the same all-gather + merge code the GPU ranks run
+(rust-local-rag_amd/sharded.py: gather_and_merge).  Each rank's "local search" is played by
+the oracle over its own shard and packed with the library's rlr_pack_result, so what is under
+test is the exchange format, the collective and the exact merge (tie rule included)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, dim, k, seed, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rlr = importlib.import_module("rust-local-rag_amd")
+        sharded = importlib.import_module("rust-local-rag_amd.sharded")
+        from oracle import oracle as O
+
+        lo, hi = sharded.shard_range(n_total, rank, world)
+        rows = O.synth_rows(hi - lo, dim, seed, row0=lo)
+        if rank == 1:
+            rows[3] = O.synth_rows(1, dim, seed, row0=5)[0]  # duplicate of global row 5 -> exact cross-shard tie
+        qs = np.stack([O.normalize(O.synth_query(dim, seed + 1 + i)) for i in range(3)])
+        L = rlr.lib()
+        local = np.zeros((len(qs), k), dtype=np.uint64)
+        for qi, q in enumerate(qs):
+            e = O.scan(rows, q)
+            order = np.lexsort((np.arange(len(e)), -e.astype(np.float64)))[:k]
+            for j, r in enumerate(order):
+                local[qi, j] = L.rlr_pack_result(float(e[r]), int(r))
+        bases = torch.tensor([sharded.shard_range(n_total, r, world)[0] for r in range(world)], dtype=torch.int64)
+        t_local = torch.from_numpy(local.view(np.int64))
+        g_rows, g_key = sharded.gather_and_merge(t_local, bases, k, dist)
+        ret[rank] = (g_rows.numpy().copy(), sharded.key_to_score(g_key.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_allgather_merge_matches_global_oracle(oracle):
+    import torch.multiprocessing as mp
+
+    n_total, dim, k, seed, world = 1001, 64, 20, 77, 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, dim, k, seed, ret)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+    sharded = importlib.import_module("rust-local-rag_amd.sharded")
+    rows = oracle.synth_rows(n_total, dim, seed)
+    lo1, _ = sharded.shard_range(n_total, 1, world)
+    rows[lo1 + 3] = rows[5]
+    for qi in range(3):
+        q = oracle.normalize(oracle.synth_query(dim, seed + 1 + qi))
+        e = oracle.scan(rows, q)
+        order = np.lexsort((np.arange(n_total), -e.astype(np.float64)))[:k]
+        for rank in range(world):
+            g_rows, g_cos = ret[rank]
+            assert np.array_equal(g_rows[qi], order), (rank, qi)
+            assert np.array_equal(g_cos[qi].view(np.uint32), e[order].view(np.uint32))
+    # the duplicated row ties exactly with global row 5; the lower global row must come first
+    q0 = oracle.normalize(rows[5])
+    e = oracle.scan(rows, q0)
+    assert e[5] == e[lo1 + 3]
+
+
+def test_shard_ranges_cover_everything():
+    sharded = importlib.import_module("rust-local-rag_amd.sharded")
+    for n, w in ((10_000_000, 8), (1001, 2), (7, 8), (0, 4), (100_000_000, 8)):
+        spans = [sharded.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        per = (n + w - 1) // w
+        assert all(hi - lo <= per for lo, hi in spans)
+
+
+def test_merge_handles_short_shards_and_padding():
+    import torch
+    rlr = importlib.import_module("rust-local-rag_amd")
+    sharded = importlib.import_module("rust-local-rag_amd.sharded")
+    L = rlr.lib()
+    k = 4
+    # rank 0 has only 2 rows (rest zero padding), rank 1 has 4
+    g = np.zeros((2, 1, k), dtype=np.uint64)
+    g[0, 0, 0] = L.rlr_pack_result(0.5, 1)
+    g[0, 0, 1] = L.rlr_pack_result(-0.25, 0)
+    for j, (s, r) in enumerate(((0.9, 2), (0.5, 0), (0.1, 3), (-0.5, 1))):
+        g[1, 0, j] = L.rlr_pack_result(s, r)
+    bases = torch.tensor([0, 2], dtype=torch.int64)
+    rows, key = sharded.merge_packed(torch.from_numpy(g.view(np.int64)), bases, k)
+    assert rows[0].tolist() == [4, 1, 2, 5]          # 0.9@2+2, 0.5@1 (lower global row first), 0.5@0+2, 0.1@3+2
+    assert sharded.key_to_score(key.numpy())[0].tolist() == [np.float32(0.9), 0.5, 0.5, np.float32(0.1)]
+    rows6, _ = sharded.merge_packed(torch.from_numpy(g.view(np.int64)), bases, 8)
+    assert rows6[0].tolist() == [4, 1, 2, 5, 0, 3, -1, -1]
