@@ -94,6 +94,27 @@ PROTOTYPES = [
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP/HSA
+    runtimes in one process cannot both own the device, so when torch is installed its copy is
+    loaded first and librlr_gpu.so binds to it by SONAME -- whichever of torch / this package is
+    imported first, the process ends up with one runtime.  Without torch, /opt/rocm's is used."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> C.CDLL:
     """Load librlr_gpu.so (built in-tree by build.py). Raises if it is absent."""
     global _lib
@@ -102,6 +123,7 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{SO_PATH} is missing: build it with `python rust-local-rag_amd/build.py` "
                 "(there is no CPU implementation of the search path to fall back to)")
+        _preload_torch_hip_runtime()
         L = C.CDLL(SO_PATH)
         for name, res, args in PROTOTYPES:
             fn = getattr(L, name)  # AttributeError if the library does not export it
