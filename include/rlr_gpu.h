@@ -108,7 +108,11 @@ int32_t rlr_index_fill_synthetic(rlr_index *idx, uint64_t n_rows, uint64_t row0,
  * (score desc, row asc); NaN scores order last.  The wavefront-order scan only
  * nominates candidates (everything within the guard band of the k-th score); the
  * nominated rows are re-scored on the GPU in strict reference order before the final
- * ordering, so the band never leaks into the result. */
+ * ordering, so the band never leaks into the result.
+ * Batches of >= 16 queries (RLR_BATCH_MIN) on dims that are a multiple of 64 take the matrix-core
+ * path: Q x Corpus^T by v_mfma_f32_16x16x32_f16 on binary16-rounded operands nominates
+ * candidates (rigorous band), the same reference-order re-score finishes; the
+ * results are identical to looping single queries. */
 int32_t rlr_search_topk(rlr_index *idx, const float *queries, uint32_t n_queries, uint32_t k,
                         float guard_eps, uint64_t *rows_out, float *cos_out, uint32_t *n_out);
 
@@ -161,6 +165,14 @@ typedef struct rlr_profile {
     uint64_t scan_bytes;   /* algorithmic bytes the scan launches covered (rows*dim*elem) */
     uint64_t n_candidates; /* rows nominated by the guard band, summed */
     uint64_t n_retries;    /* band overflow retries */
+    /* batched (MFMA) path */
+    uint64_t n_batches;        /* batched pipelines run */
+    uint64_t n_batch_queries;  /* queries they carried */
+    double batch_gemm_ms;      /* sum of HIP-event durations of the GEMM nomination launches */
+    double batch_other_ms;     /* query prep + sample select + per-query finish */
+    uint64_t batch_gemm_bytes; /* algorithmic bytes: rows * dim * elem per batch of <= 256 queries */
+    double batch_gemm_flops;   /* 2 * queries * rows * dim */
+    uint64_t n_batch_fallbacks;/* queries re-run through the single-query pipeline */
 } rlr_profile;
 /* enable != 0: record HIP events around each stage on the stream it is launched on
  * (adds one event pair per stage).  Disabled by default. */

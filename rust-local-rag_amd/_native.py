@@ -52,7 +52,10 @@ class ProfileC(C.Structure):
     _fields_ = [("n_searches", C.c_uint64), ("n_scan_launches", C.c_uint64),
                 ("scan_ms", C.c_double), ("select_ms", C.c_double), ("rescore_ms", C.c_double),
                 ("total_ms", C.c_double), ("scan_bytes", C.c_uint64), ("n_candidates", C.c_uint64),
-                ("n_retries", C.c_uint64)]
+                ("n_retries", C.c_uint64),
+                ("n_batches", C.c_uint64), ("n_batch_queries", C.c_uint64), ("batch_gemm_ms", C.c_double),
+                ("batch_other_ms", C.c_double), ("batch_gemm_bytes", C.c_uint64), ("batch_gemm_flops", C.c_double),
+                ("n_batch_fallbacks", C.c_uint64)]
 
 
 # every symbol include/*.h declares: (name, restype, argtypes)

@@ -19,7 +19,7 @@ SO = os.path.join(HERE, "librlr_gpu.so")
 ROOT = os.path.dirname(HERE)
 
 SOURCES = ["scan.hip", "select.hip", "exact.hip", "gemm.hip", "index.hip", "engine.cpp"]
-HEADERS = ["common.h", "kernels.h", "engine.h", os.path.join(ROOT, "include", "rlr_gpu.h"),
+HEADERS = ["common.h", "kernels.h", "exact_dot.h", os.path.join(ROOT, "include", "rlr_gpu.h"),
            os.path.join(ROOT, "include", "rlr_engine.h")]
 
 # -ffp-contract=off: a*b+c in source is a rounded multiply then a rounded add (the

@@ -1,0 +1,441 @@
+// gemm.hip -- batched queries: Q x Corpus^T as a dense GEMM on the gfx950 matrix cores with a
+// fused top-k nomination epilogue (the additive batched entry point of SURVEY.md section 8; its
+// oracle is "loop the single-query reference over the batch").
+//
+// Role of the MFMA product: it NOMINATES.  Operands are rounded to binary16 (rows on the fly in
+// registers, queries once into a fragment-major image), accumulated in f32 by
+// v_mfma_f32_16x16x32_f16.  For unit-norm operands |nominated - reference dot| <= eps_nom
+// (2^-10 from the two operand roundings + accumulation terms, see nomination_eps()), so every
+// row of the true top-k lies within 2*eps_nom of the k-th nominated score; those rows are then
+// re-scored in strict reference order (exact_dot.h) and sorted, and the emitted rows/scores are
+// bit-identical to the single-query path and to the reference loop.
+//
+// Shape on gfx950 (HBM-bound: each corpus row is read once per 256 queries)
+//   * workgroup = 8 waves = 256 corpus rows x 256 queries; a wave owns 32 rows (2 MFMA row
+//     groups) x all 256 queries: 32 accumulator tiles of 16x16 = 128 VGPRs;
+//   * corpus rows (A operand) go HBM -> registers directly in MFMA fragment shape: lane
+//     (row = l&15, kgroup = l>>4) reads the 8 consecutive k it owns (32 B of f32, 16 B of f16);
+//     4 lanes cover one 128-B (64-B) line, no LDS round trip for the streamed operand;
+//   * queries (B operand) are pre-arranged [kstep][colblock][lane][8 halfs], so a K-chunk is one
+//     linear 32 KB copy into LDS (double buffered) and every fragment read is a conflict-free
+//     linear ds_read_b128;
+//   * workgroups sharing a row tile (Q > 256) get consecutive ids with equal id % 8, i.e. the
+//     same XCD, so the tile's second read is an L2 hit (speed only, never correctness);
+//   * epilogue: compare each accumulator with its query's threshold (from a materialised sample
+//     of the first S rows) and append (score, row) to that query's candidate list.
+#include "common.h"
+#include "exact_dot.h"
+#include "kernels.h"
+#include "../../include/rlr_gpu.h"
+
+namespace rlr {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kQB = 256;            // queries per workgroup tile
+constexpr int kNB = kQB / 16;       // 16-wide query column blocks
+constexpr int kRG = 2;              // 16-row groups per wave
+constexpr int kGemmWaves = 8;
+constexpr int kBM = kGemmWaves * kRG * 16; // 256 corpus rows per workgroup tile
+constexpr int kKsChunk = 2;         // MFMA k-steps (32 k each) per LDS chunk
+constexpr int kChunkFrags = kKsChunk * kNB * 64; // half8 entries per B chunk (32 KB)
+
+// queries f32 [n_queries x q_pitch] -> binary16, fragment-major:
+//   [qblock][kstep][colblock][lane][8]   with  query = qblock*256 + colblock*16 + (lane & 15)
+//                                              k     = kstep*32 + (lane >> 4)*8 + j
+__global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restrict__ q, uint32_t n_queries,
+                                                           uint32_t q_pitch, uint32_t dim, uint32_t n_ksteps,
+                                                           uint32_t n_qblocks, _Float16 *__restrict__ out)
+{
+    const size_t total = static_cast<size_t>(n_qblocks) * n_ksteps * kNB * 64 * 8;
+    for (size_t e = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<size_t>(gridDim.x) * 256) {
+        const uint32_t j = e & 7;
+        const uint32_t lane = (e >> 3) & 63;
+        const uint32_t nb = (e >> 9) & (kNB - 1);
+        const size_t rest = e >> 13; // qblock * n_ksteps + kstep
+        const uint32_t ks = static_cast<uint32_t>(rest % n_ksteps);
+        const uint32_t qb = static_cast<uint32_t>(rest / n_ksteps);
+        const uint32_t query = qb * kQB + nb * 16 + (lane & 15);
+        const uint32_t k = ks * 32 + (lane >> 4) * 8 + j;
+        float v = 0.0f;
+        if (query < n_queries && k < dim)
+            v = q[static_cast<size_t>(query) * q_pitch + k];
+        out[e] = static_cast<_Float16>(v); // round to nearest even
+    }
+}
+
+__device__ inline half8 cvt8(float4 lo, float4 hi)
+{
+    half8 r;
+    r[0] = static_cast<_Float16>(lo.x);
+    r[1] = static_cast<_Float16>(lo.y);
+    r[2] = static_cast<_Float16>(lo.z);
+    r[3] = static_cast<_Float16>(lo.w);
+    r[4] = static_cast<_Float16>(hi.x);
+    r[5] = static_cast<_Float16>(hi.y);
+    r[6] = static_cast<_Float16>(hi.z);
+    r[7] = static_cast<_Float16>(hi.w);
+    return r;
+}
+
+struct GemmArgs {
+    const unsigned char *rows; // index rows
+    uint32_t pitch_bytes;
+    uint32_t row_begin, row_end; // [begin, end) rows this launch covers
+    uint32_t n_ksteps;           // dim / 32 (even)
+    const half8 *qfrag;
+    uint32_t n_qblocks, n_queries;
+    const float *tau;            // filter mode: per-query threshold on the nominated score
+    uint64_t *cand;              // filter mode: [query][cand_stride] packed (score, row)
+    uint32_t cand_stride;
+    SelectState *st;             // filter mode: per-query counters / capacity
+    float *scores;               // materialise mode: [query][score_stride], column = row - row_begin
+    size_t score_stride;
+};
+
+template <bool F16ROWS, bool MATERIALISE>
+__global__ __launch_bounds__(512) void gemm_nominate_kernel(const GemmArgs a)
+{
+    __shared__ half8 s_b[2][kChunkFrags];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware tile map: the n_qblocks workgroups of one row tile share id % 8
+    const uint32_t bid = blockIdx.x;
+    const uint32_t rt = (bid / (8 * a.n_qblocks)) * 8 + (bid & 7);
+    const uint32_t qb = (bid >> 3) % a.n_qblocks;
+    const uint32_t n_rows = a.row_end - a.row_begin;
+    if (rt * kBM >= n_rows)
+        return;
+    const uint32_t row0 = a.row_begin + rt * kBM + wave * (kRG * 16);
+    const uint32_t last_row = a.row_end - 1;
+
+    // per-lane A pointers (fragment shape: row = l & 15, k-group = l >> 4)
+    const unsigned char *ap[kRG];
+#pragma unroll
+    for (int rg = 0; rg < kRG; ++rg) {
+        const uint32_t r = min(row0 + rg * 16 + (lane & 15), last_row);
+        ap[rg] = a.rows + static_cast<size_t>(r) * a.pitch_bytes + (lane >> 4) * (F16ROWS ? 16 : 32);
+    }
+    constexpr int kStepBytes = F16ROWS ? 64 : 128; // bytes of one row consumed per k-step
+
+    const uint32_t n_chunks = a.n_ksteps / kKsChunk;
+    const half8 *bsrc = a.qfrag + static_cast<size_t>(qb) * a.n_ksteps * kNB * 64;
+
+    f32x4 acc[kRG][kNB];
+#pragma unroll
+    for (int rg = 0; rg < kRG; ++rg)
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb)
+            acc[rg][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    half8 breg[4];
+    float4 araw[kRG][kKsChunk][2]; // f32 rows: two 16-B loads per fragment
+    half8 a_cur[kRG][kKsChunk];
+
+    auto load_b = [&](uint32_t c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            breg[i] = bsrc[static_cast<size_t>(c) * kChunkFrags + tid + 512 * i];
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            s_b[buf][tid + 512 * i] = breg[i];
+    };
+    auto load_a = [&](uint32_t c) {
+#pragma unroll
+        for (int rg = 0; rg < kRG; ++rg)
+#pragma unroll
+            for (int ks = 0; ks < kKsChunk; ++ks) {
+                const unsigned char *p = ap[rg] + static_cast<size_t>(c * kKsChunk + ks) * kStepBytes;
+                if constexpr (F16ROWS) {
+                    araw[rg][ks][0] = *reinterpret_cast<const float4 *>(p);
+                } else {
+                    araw[rg][ks][0] = *reinterpret_cast<const float4 *>(p);
+                    araw[rg][ks][1] = *reinterpret_cast<const float4 *>(p + 16);
+                }
+            }
+    };
+    auto convert_a = [&]() {
+#pragma unroll
+        for (int rg = 0; rg < kRG; ++rg)
+#pragma unroll
+            for (int ks = 0; ks < kKsChunk; ++ks) {
+                if constexpr (F16ROWS)
+                    a_cur[rg][ks] = __builtin_bit_cast(half8, araw[rg][ks][0]);
+                else
+                    a_cur[rg][ks] = cvt8(araw[rg][ks][0], araw[rg][ks][1]);
+            }
+    };
+
+    load_b(0);
+    load_a(0);
+    store_b(0);
+    convert_a();
+    __syncthreads();
+
+#pragma unroll 1
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const bool has_next = c + 1 < n_chunks;
+        if (has_next) {
+            load_b(c + 1);
+            load_a(c + 1);
+        }
+        const half8 *sb = s_b[c & 1];
+#pragma unroll
+        for (int ks = 0; ks < kKsChunk; ++ks) {
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) {
+                const half8 b = sb[(ks * kNB + nb) * 64 + lane];
+#pragma unroll
+                for (int rg = 0; rg < kRG; ++rg)
+                    acc[rg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[rg][ks], b, acc[rg][nb], 0, 0, 0);
+            }
+        }
+        if (has_next) {
+            store_b((c + 1) & 1);
+            convert_a();
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D layout is col = lane & 15 (query), row = 4*(lane >> 4) + reg ----------
+    const uint32_t qcol = qb * kQB + (lane & 15);
+    if constexpr (MATERIALISE) {
+#pragma unroll
+        for (int rg = 0; rg < kRG; ++rg) {
+            const uint32_t r = row0 + rg * 16 + 4 * (lane >> 4);
+            const uint32_t rel = r - a.row_begin;
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) {
+                const uint32_t q = qcol + nb * 16;
+                if (q >= a.n_queries)
+                    continue;
+                float *dst = a.scores + static_cast<size_t>(q) * a.score_stride + rel;
+                const f32x4 v = acc[rg][nb];
+                if (r + 3 <= last_row) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (r + i <= last_row)
+                            dst[i] = v[i];
+                }
+            }
+        }
+    } else {
+        float tau_l[kNB];
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb) {
+            const uint32_t q = qcol + nb * 16;
+            tau_l[nb] = q < a.n_queries ? a.tau[q] : __builtin_inff();
+        }
+#pragma unroll
+        for (int rg = 0; rg < kRG; ++rg) {
+            const uint32_t r = row0 + rg * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) {
+                const f32x4 v = acc[rg][nb];
+                const float t = tau_l[nb];
+                if (v[0] >= t || v[1] >= t || v[2] >= t || v[3] >= t) {
+                    const uint32_t q = qcol + nb * 16;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (v[i] >= t && r + i <= last_row) {
+                            const uint32_t slot = atomicAdd(&a.st[q].n_cand, 1u);
+                            if (slot < a.st[q].cap)
+                                a.cand[static_cast<size_t>(q) * a.cand_stride + slot] = pack_result(v[i], r + i);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-query finish: order the nominated candidates, cut the guard band at the k-th nominated
+// score, re-score the band in reference order, order again, emit k.  One workgroup per query.
+// status[q]: 0 ok, 1 = candidate or band overflow, 2 = fewer than k candidates (the host then
+// runs that query through the single-query pipeline).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kFinCap = 8192;   // candidates per query the finish kernel can order
+constexpr uint32_t kBandCap = 2048;  // rows re-scored per query at most
+
+__device__ inline void bitonic_desc_lds(uint64_t *s, uint32_t n_pad, uint32_t nthreads)
+{
+    for (uint32_t k = 2; k <= n_pad; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n_pad; i += nthreads) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = s[i], y = s[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) {
+                        s[i] = y;
+                        s[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <bool F16ROWS>
+__global__ __launch_bounds__(256) void batch_finish_kernel(const float4 *__restrict__ rows, uint32_t pitch16, uint32_t dim,
+                                                           const float *__restrict__ queries, uint32_t q_pitch,
+                                                           const uint64_t *__restrict__ cand, uint32_t cand_stride,
+                                                           const SelectState *__restrict__ st, uint32_t k, float two_eps,
+                                                           uint64_t *__restrict__ out, uint32_t *__restrict__ status)
+{
+    __shared__ uint64_t s_c[kFinCap];
+    __shared__ uint32_t s_band;
+    extern __shared__ __attribute__((aligned(16))) float s_q[];
+    const uint32_t q = blockIdx.x;
+    const uint32_t n_raw = st[q].n_cand;
+    uint64_t *o = out + static_cast<size_t>(q) * k;
+    if (n_raw > st[q].cap || n_raw > kFinCap || n_raw < k) {
+        if (threadIdx.x == 0)
+            status[q] = n_raw < k ? 2u : 1u;
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < dim; i += 256)
+        s_q[i] = queries[static_cast<size_t>(q) * q_pitch + i];
+    uint32_t n_pad = 1;
+    while (n_pad < n_raw)
+        n_pad <<= 1;
+    const uint64_t *c = cand + static_cast<size_t>(q) * cand_stride;
+    for (uint32_t i = threadIdx.x; i < n_pad; i += 256)
+        s_c[i] = i < n_raw ? c[i] : 0ull;
+    if (threadIdx.x == 0)
+        s_band = 0;
+    __syncthreads();
+    bitonic_desc_lds(s_c, n_pad, 256);
+    // guard band below the k-th nominated score
+    const float fk = key_score(static_cast<uint32_t>(s_c[k - 1] >> 32));
+    const uint32_t key_lo = score_key(fk - two_eps);
+    for (uint32_t i = threadIdx.x; i < n_raw; i += 256)
+        if (static_cast<uint32_t>(s_c[i] >> 32) >= key_lo)
+            atomicMax(&s_band, i + 1);
+    __syncthreads();
+    const uint32_t band = s_band;
+    if (band > kBandCap) {
+        if (threadIdx.x == 0)
+            status[q] = 1u;
+        return;
+    }
+    // reference-order re-score of the band, one lane per candidate
+    for (uint32_t i = threadIdx.x; i < band; i += 256) {
+        const uint32_t r = 0xFFFFFFFFu - static_cast<uint32_t>(s_c[i] & 0xFFFFFFFFu);
+        const float e = dot_ref_row<F16ROWS>(rows + static_cast<size_t>(r) * pitch16, s_q, dim);
+        s_c[i] = pack_result(e, r);
+    }
+    uint32_t b_pad = 1;
+    while (b_pad < band)
+        b_pad <<= 1;
+    for (uint32_t i = band + threadIdx.x; i < b_pad; i += 256)
+        s_c[i] = 0ull;
+    __syncthreads();
+    bitonic_desc_lds(s_c, b_pad, 256);
+    for (uint32_t i = threadIdx.x; i < k; i += 256)
+        o[i] = s_c[i];
+    if (threadIdx.x == 0)
+        status[q] = 0u;
+}
+
+} // namespace
+
+// upper bound of |nominated score - reference-order dot| for unit-norm operands
+float nomination_eps(uint32_t dim, int dtype)
+{
+    // operand roundings to binary16 (round to nearest even): 2^-11 relative each.  f32 rows:
+    // both operands rounded -> 2^-10 (+ cross term); f16 rows are already exact -> 2^-11.
+    // Products of two binary16 values are exact in f32; the f32 accumulation (MFMA k-order
+    // chain) and the reference's own left-to-right error add (dim + 64) * 2^-24 each; binary16
+    // subnormal flushes add < 2 * 2^-25 * sqrt(dim).
+    const float op = dtype == RLR_F16 ? 4.8828125e-4f : 9.765625e-4f;
+    const float acc = 2.0f * (static_cast<float>(dim) + 64.0f) * 5.9604645e-8f;
+    const float sub = 2.0f * 2.9802322e-8f * __builtin_sqrtf(static_cast<float>(dim));
+    return (op * 1.001f + acc + sub) * 1.0625f;
+}
+
+hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pitch, uint32_t dim, void *qfrag,
+                               hipStream_t s)
+{
+    const uint32_t n_ksteps = dim / 32;
+    const uint32_t n_qblocks = (n_queries + kQB - 1) / kQB;
+    const size_t total = static_cast<size_t>(n_qblocks) * n_ksteps * kNB * 64 * 8;
+    const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((total + 255) / 256, 4096));
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(blocks), dim3(256), 0, s, q, n_queries, q_pitch, dim, n_ksteps,
+                       n_qblocks, static_cast<_Float16 *>(qfrag));
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin,
+                                uint32_t row_end, const void *qfrag, uint32_t n_queries, const float *tau,
+                                uint64_t *cand, uint32_t cand_stride, SelectState *st, float *scores,
+                                size_t score_stride, hipStream_t s)
+{
+    if (row_end <= row_begin)
+        return hipSuccess;
+    GemmArgs a;
+    a.rows = static_cast<const unsigned char *>(rows);
+    a.pitch_bytes = pitch16 * 16;
+    a.row_begin = row_begin;
+    a.row_end = row_end;
+    a.n_ksteps = dim / 32;
+    a.qfrag = static_cast<const half8 *>(qfrag);
+    a.n_qblocks = (n_queries + kQB - 1) / kQB;
+    a.n_queries = n_queries;
+    a.tau = tau;
+    a.cand = cand;
+    a.cand_stride = cand_stride;
+    a.st = st;
+    a.scores = scores;
+    a.score_stride = score_stride;
+    const uint32_t n_rt = (row_end - row_begin + kBM - 1) / kBM;
+    const uint32_t grid = ((n_rt + 7) / 8) * 8 * a.n_qblocks;
+    const bool mat = scores != nullptr;
+    if (dtype == RLR_F16) {
+        if (mat)
+            hipLaunchKernelGGL((gemm_nominate_kernel<true, true>), dim3(grid), dim3(512), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_nominate_kernel<true, false>), dim3(grid), dim3(512), 0, s, a);
+    } else {
+        if (mat)
+            hipLaunchKernelGGL((gemm_nominate_kernel<false, true>), dim3(grid), dim3(512), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_nominate_kernel<false, false>), dim3(grid), dim3(512), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_finish(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *queries,
+                               uint32_t q_pitch, uint32_t n_queries, const uint64_t *cand, uint32_t cand_stride,
+                               const SelectState *st, uint32_t k, float two_eps, uint64_t *out, uint32_t *status,
+                               hipStream_t s)
+{
+    const size_t lds = static_cast<size_t>(dim) * sizeof(float);
+    const float4 *r4 = static_cast<const float4 *>(rows);
+    if (dtype == RLR_F16)
+        hipLaunchKernelGGL(batch_finish_kernel<true>, dim3(n_queries), dim3(256), lds, s, r4, pitch16, dim, queries,
+                           q_pitch, cand, cand_stride, st, k, two_eps, out, status);
+    else
+        hipLaunchKernelGGL(batch_finish_kernel<false>, dim3(n_queries), dim3(256), lds, s, r4, pitch16, dim, queries,
+                           q_pitch, cand, cand_stride, st, k, two_eps, out, status);
+    return hipGetLastError();
+}
+
+uint32_t batch_finish_capacity()
+{
+    return kFinCap;
+}
+
+} // namespace rlr

@@ -78,6 +78,19 @@ struct Ctx {
     uint32_t list_cap = 0;
     float *d_pool = nullptr;       // mmr pool P x dim, then gram P x P
     uint64_t pool_cap = 0;         // floats
+    // batched (MFMA) path workspace
+    void *d_qfrag = nullptr;        // binary16 fragment-major queries
+    uint64_t qfrag_cap = 0;         // bytes
+    float *d_tau = nullptr;         // per-query nomination threshold
+    SelectState *d_bstate = nullptr;
+    uint32_t *d_bhist = nullptr;    // q x 2 x kHistBins
+    uint32_t *d_bstatus = nullptr;
+    uint32_t bq_cap = 0;            // queries the four arrays above are sized for
+    uint64_t *d_bcand = nullptr;    // q x fin_cap packed candidates
+    uint64_t bcand_cap = 0;         // entries
+    float *d_sample = nullptr;      // q x S nominated scores of the sample rows
+    uint64_t sample_cap = 0;        // floats
+    hipEvent_t bev[4] = {nullptr, nullptr, nullptr, nullptr};
     // pinned host
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
@@ -96,6 +109,7 @@ struct rlr_index {
     void *d_rows = nullptr;
     int n_cu = 256;
     int scan_variant = 0;
+    uint32_t batch_min = 16;  // smallest batch that takes the matrix-core path (RLR_BATCH_MIN)
     std::mutex mu;
     std::vector<Ctx *> free_ctx;
     bool profiling = false;
@@ -171,6 +185,15 @@ void ctx_free(Ctx *c)
     (void)hipFree(c->d_list);
     (void)hipFree(c->d_vals);
     (void)hipFree(c->d_pool);
+    (void)hipFree(c->d_qfrag);
+    (void)hipFree(c->d_tau);
+    (void)hipFree(c->d_bstate);
+    (void)hipFree(c->d_bhist);
+    (void)hipFree(c->d_bstatus);
+    (void)hipFree(c->d_bcand);
+    (void)hipFree(c->d_sample);
+    for (auto &e : c->bev)
+        if (e) (void)hipEventDestroy(e);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     delete c;
 }
@@ -191,6 +214,8 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; ++i)
         e = hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        e = hipEventCreate(&c->bev[i]);
     if (e == hipSuccess)
         e = hipMalloc(reinterpret_cast<void **>(&c->d_hist), 2 * kHistBins * sizeof(uint32_t));
     if (e != hipSuccess) {
@@ -457,6 +482,119 @@ int32_t big_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint3
     return RLR_OK;
 }
 
+// ---- batched (matrix-core) pipeline ---------------------------------------------------
+constexpr uint32_t kBatchMaxQueries = 1024; // queries per batched pipeline run (bounds the workspace)
+
+bool batch_eligible(const rlr_index *ix, uint32_t nq, uint32_t k)
+{
+    return nq >= ix->batch_min && ix->batch_min > 0 && ix->dim % 64 == 0 && ix->n_rows >= 4096 &&
+           k * 8 <= batch_finish_capacity();
+}
+
+// Runs queries [q0, q0+nq) (already staged in c->d_query) through the GEMM nomination pipeline
+// and leaves k packed results per query in d_out; h_status[q] != 0 marks queries the caller must
+// re-run through the single-query pipeline.
+int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const SearchPlan &p, uint64_t *d_out,
+                    std::vector<uint32_t> &h_status)
+{
+    hipStream_t s = c->stream;
+    const uint32_t n = static_cast<uint32_t>(ix->n_rows);
+    const uint32_t fin_cap = batch_finish_capacity();
+    const uint32_t n_qblocks = (nq + 255) / 256;
+    const float eps_nom = nomination_eps(ix->dim, ix->dtype);
+    const float two_eps = 2.0f * eps_nom;
+    // sample rows [0, S): large enough that the expected number of later rows above the sample's
+    // k-th score (k * N / S) stays well inside the per-query candidate capacity.
+    uint64_t S = (static_cast<uint64_t>(p.k) * n * 5 / 2 + fin_cap - 1) / fin_cap;
+    S = std::max<uint64_t>(S, std::min<uint64_t>(n, 65536));
+    S = (S + 255) / 256 * 256;
+    if (S * 2 >= n)
+        S = n;
+    const uint64_t s_stride = (S + 3) / 4 * 4;
+
+    // workspace
+    const uint64_t qfrag_bytes = static_cast<uint64_t>(n_qblocks) * 256 * ix->dim * 2;
+    if (c->qfrag_cap < qfrag_bytes) {
+        if (c->d_qfrag) (void)hipFree(c->d_qfrag);
+        c->d_qfrag = nullptr;
+        c->qfrag_cap = 0;
+        RLR_HIP(hipMalloc(&c->d_qfrag, qfrag_bytes));
+        c->qfrag_cap = qfrag_bytes;
+    }
+    if (c->bq_cap < nq) {
+        (void)hipFree(c->d_tau);
+        (void)hipFree(c->d_bstate);
+        (void)hipFree(c->d_bhist);
+        (void)hipFree(c->d_bstatus);
+        c->d_tau = nullptr;
+        c->d_bstate = nullptr;
+        c->d_bhist = nullptr;
+        c->d_bstatus = nullptr;
+        c->bq_cap = 0;
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tau), static_cast<size_t>(nq) * sizeof(float)));
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_bstate), static_cast<size_t>(nq) * sizeof(SelectState)));
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_bhist), static_cast<size_t>(nq) * 2 * kHistBins * sizeof(uint32_t)));
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_bstatus), static_cast<size_t>(nq) * sizeof(uint32_t)));
+        c->bq_cap = nq;
+    }
+    RLR_TRY(grow(&c->d_bcand, &c->bcand_cap, static_cast<uint64_t>(nq) * fin_cap));
+    RLR_TRY(grow(&c->d_sample, &c->sample_cap, static_cast<uint64_t>(nq) * s_stride));
+
+    std::vector<SelectState> h_st(nq);
+    for (auto &st : h_st) {
+        std::memset(&st, 0, sizeof(st));
+        st.k = std::min<uint32_t>(p.k, static_cast<uint32_t>(S));
+        st.cap = fin_cap;
+    }
+    const float *dq = c->d_query + static_cast<size_t>(q0) * ix->q_pitch;
+    const bool timed = ix->profiling;
+    RLR_HIP(hipMemcpyAsync(c->d_bstate, h_st.data(), nq * sizeof(SelectState), hipMemcpyHostToDevice, s));
+    RLR_HIP(hipMemsetAsync(c->d_bhist, 0, static_cast<size_t>(nq) * 2 * kHistBins * sizeof(uint32_t), s));
+    RLR_HIP(hipMemsetAsync(c->d_bstatus, 0xFF, static_cast<size_t>(nq) * sizeof(uint32_t), s));
+    if (timed) RLR_HIP(hipEventRecord(c->bev[0], s));
+    RLR_HIP(launch_prep_queries(dq, nq, ix->q_pitch, ix->dim, c->d_qfrag, s));
+    // 1. nominated scores of the sample rows, materialised
+    RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, 0, static_cast<uint32_t>(S), c->d_qfrag, nq,
+                                 nullptr, nullptr, 0, nullptr, c->d_sample, s_stride, s));
+    if (timed) RLR_HIP(hipEventRecord(c->bev[1], s));
+    // 2. per-query k-th score of the sample -> threshold; the sample's own candidates
+    RLR_HIP(launch_batch_select(c->d_sample, static_cast<uint32_t>(S), s_stride, nq, c->d_bhist, c->d_bstate, two_eps,
+                                c->d_tau, c->d_bcand, fin_cap, ix->n_cu, s));
+    if (timed) RLR_HIP(hipEventRecord(c->bev[2], s));
+    // 3. the rest of the corpus, filtered in the GEMM epilogue
+    RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, static_cast<uint32_t>(S), n, c->d_qfrag, nq,
+                                 c->d_tau, c->d_bcand, fin_cap, c->d_bstate, nullptr, 0, s));
+    if (timed) RLR_HIP(hipEventRecord(c->bev[3], s));
+    // 4. per-query finish: band, reference-order re-score, order, emit
+    RLR_HIP(launch_batch_finish(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, ix->q_pitch, nq, c->d_bcand, fin_cap,
+                                c->d_bstate, p.k, two_eps, d_out, c->d_bstatus, s));
+    if (timed) RLR_HIP(hipEventRecord(c->ev[3], s));
+    h_status.assign(nq, 0);
+    RLR_HIP(hipMemcpyAsync(h_status.data(), c->d_bstatus, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RLR_HIP(hipStreamSynchronize(s));
+    uint64_t fallbacks = 0;
+    for (uint32_t v : h_status)
+        fallbacks += v != 0;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        ix->prof.n_batches += 1;
+        ix->prof.n_batch_queries += nq;
+        ix->prof.n_batch_fallbacks += fallbacks;
+        if (timed) {
+            float prep = 0, sel = 0, g2 = 0, fin = 0;
+            (void)hipEventElapsedTime(&prep, c->bev[0], c->bev[1]);
+            (void)hipEventElapsedTime(&sel, c->bev[1], c->bev[2]);
+            (void)hipEventElapsedTime(&g2, c->bev[2], c->bev[3]);
+            (void)hipEventElapsedTime(&fin, c->bev[3], c->ev[3]);
+            ix->prof.batch_gemm_ms += prep + g2; // prep is ~us; both GEMM launches are in here
+            ix->prof.batch_other_ms += sel + fin;
+            ix->prof.batch_gemm_bytes += static_cast<uint64_t>(n_qblocks) * n * ix->dim * (ix->dtype == RLR_F16 ? 2 : 4);
+            ix->prof.batch_gemm_flops += 2.0 * nq * static_cast<double>(n) * ix->dim;
+        }
+    }
+    return RLR_OK;
+}
+
 // Runs nq queries; results (packed, k per query) end up in d_out (context buffer or the
 // caller's device buffer).  h_states receives the final per-query states.
 int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uint32_t k_req, float guard_eps,
@@ -497,6 +635,34 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     const bool timed = ix->profiling;
     double scan_ms = 0, select_ms = 0, rescore_ms = 0, total_ms = 0;
     uint64_t n_cand_total = 0, n_retry = 0;
+    if (batch_eligible(ix, nq, p.k)) {
+        // matrix-core path in runs of <= kBatchMaxQueries; queries it hands back (overflow, or
+        // fewer than k finite candidates) go through the single-query pipeline below.
+        std::vector<uint32_t> redo;
+        std::vector<uint32_t> status;
+        for (uint32_t q0 = 0; q0 < nq; q0 += kBatchMaxQueries) {
+            const uint32_t m = std::min(kBatchMaxQueries, nq - q0);
+            RLR_TRY(run_batched(ix, c, q0, m, p, d_out + static_cast<size_t>(q0) * p.k, status));
+            for (uint32_t i = 0; i < m; ++i)
+                if (status[i] != 0)
+                    redo.push_back(q0 + i);
+        }
+        for (uint32_t q : redo) {
+            RLR_HIP(hipMemcpyAsync(c->d_state + q, &h_st[q], sizeof(SelectState), hipMemcpyHostToDevice, s));
+            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, false));
+            RLR_HIP(hipMemcpyAsync(&h_st_back[q], c->d_state + q, sizeof(SelectState), hipMemcpyDeviceToHost, s));
+            RLR_HIP(hipStreamSynchronize(s));
+            const uint32_t nc = h_st_back[q].n_cand;
+            if (nc > p.cap || nc > kLdsSortCap) {
+                n_retry++;
+                RLR_TRY(big_query(ix, c, q, p, nc, /*rescan=*/false, d_out + static_cast<size_t>(q) * p.k));
+            }
+        }
+        std::lock_guard<std::mutex> lk(ix->mu);
+        ix->prof.n_searches += nq;
+        ix->prof.n_retries += n_retry;
+        return RLR_OK;
+    }
     if (!timed) {
         for (uint32_t q = 0; q < nq; ++q)
             RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, false));
@@ -634,6 +800,8 @@ int32_t rlr_index_create(uint32_t dim, int32_t dtype, int32_t device_id, rlr_ind
     ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *v = getenv("RLR_SCAN_VARIANT"))
         ix->scan_variant = static_cast<int>(strtol(v, nullptr, 0));
+    if (const char *v = getenv("RLR_BATCH_MIN"))
+        ix->batch_min = static_cast<uint32_t>(strtoul(v, nullptr, 0));
     *out = ix;
     return RLR_OK;
 }

@@ -49,6 +49,26 @@ hipError_t launch_collect(const float *scores, uint32_t n, SelectState *st, uint
 // sort `n_pad` (power of two) packed u64 descending in place; entries >= n are 0.
 hipError_t launch_sort_desc(uint64_t *packed, uint32_t n_pad, hipStream_t s);
 
+hipError_t launch_batch_select(const float *scores, uint32_t n, size_t score_stride, uint32_t q_count,
+                               uint32_t *hist, SelectState *st, float two_eps, float *tau_out, uint64_t *cand,
+                               uint32_t cand_stride, int n_cu, hipStream_t s);
+
+// ---- gemm.hip : batched queries, MFMA nomination + per-query exact finish ----------------
+float nomination_eps(uint32_t dim, int dtype);
+uint32_t batch_finish_capacity();
+hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pitch, uint32_t dim, void *qfrag,
+                               hipStream_t s);
+// scores != null: materialise nominated scores of rows [row_begin,row_end) (column = row - row_begin);
+// scores == null: filter mode, append (score,row) >= tau[q] to cand[q].
+hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin,
+                                uint32_t row_end, const void *qfrag, uint32_t n_queries, const float *tau,
+                                uint64_t *cand, uint32_t cand_stride, SelectState *st, float *scores,
+                                size_t score_stride, hipStream_t s);
+hipError_t launch_batch_finish(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *queries,
+                               uint32_t q_pitch, uint32_t n_queries, const uint64_t *cand, uint32_t cand_stride,
+                               const SelectState *st, uint32_t k, float two_eps, uint64_t *out, uint32_t *status,
+                               hipStream_t s);
+
 // ---- exact.hip : reference-order arithmetic --------------------------------
 // packed_out[i] = pack(dot_ref(query, row[cand[i]]), cand[i]) for i < min(n_cand, cap);
 // entries up to n_pad are zero-filled.  n_cand is read from the device (st->n_cand).

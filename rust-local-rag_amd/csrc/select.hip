@@ -10,6 +10,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace rlr {
 
 namespace {
@@ -26,10 +28,14 @@ __device__ inline void block_hist_flush(const uint32_t *s_hist, uint32_t *g_hist
 }
 
 // digit 1: key bits 31..21 of every score
+// (all select kernels: blockIdx.y = query of a batch; strides are 0/unused for a single query)
 __global__ __launch_bounds__(kSelThreads) void hist1_kernel(const float *__restrict__ scores,
-                                                            uint32_t n, uint32_t *__restrict__ g_hist)
+                                                            uint32_t n, uint32_t *__restrict__ g_hist,
+                                                            size_t score_stride, uint32_t hist_stride)
 {
     __shared__ uint32_t s_hist[kHistBins];
+    scores += blockIdx.y * score_stride;
+    g_hist += blockIdx.y * hist_stride;
     for (int i = threadIdx.x; i < kHistBins; i += kSelThreads)
         s_hist[i] = 0;
     __syncthreads();
@@ -53,9 +59,13 @@ __global__ __launch_bounds__(kSelThreads) void hist1_kernel(const float *__restr
 __global__ __launch_bounds__(kSelThreads) void hist2_kernel(const float *__restrict__ scores,
                                                             uint32_t n,
                                                             const SelectState *__restrict__ st,
-                                                            uint32_t *__restrict__ g_hist)
+                                                            uint32_t *__restrict__ g_hist,
+                                                            size_t score_stride, uint32_t hist_stride)
 {
     __shared__ uint32_t s_hist[kHistBins];
+    scores += blockIdx.y * score_stride;
+    g_hist += blockIdx.y * hist_stride;
+    st += blockIdx.y;
     for (int i = threadIdx.x; i < kHistBins; i += kSelThreads)
         s_hist[i] = 0;
     __syncthreads();
@@ -126,8 +136,10 @@ __device__ inline void find_rank_bin(const uint32_t *__restrict__ hist, uint32_t
 }
 
 __global__ __launch_bounds__(kSelThreads) void find1_kernel(const uint32_t *__restrict__ hist1,
-                                                            SelectState *st)
+                                                            SelectState *st, uint32_t hist_stride)
 {
+    hist1 += blockIdx.x * hist_stride;
+    st += blockIdx.x;
     uint32_t bin, rk;
     find_rank_bin(hist1, st->k, &bin, &rk);
     if (threadIdx.x == 0) {
@@ -137,8 +149,11 @@ __global__ __launch_bounds__(kSelThreads) void find1_kernel(const uint32_t *__re
 }
 
 __global__ __launch_bounds__(kSelThreads) void find2_kernel(const uint32_t *__restrict__ hist2,
-                                                            SelectState *st, float two_eps)
+                                                            SelectState *st, float two_eps, uint32_t hist_stride,
+                                                            float *__restrict__ tau_out)
 {
+    hist2 += blockIdx.x * hist_stride;
+    st += blockIdx.x;
     uint32_t bin, rk;
     find_rank_bin(hist2, st->k2, &bin, &rk);
     if (threadIdx.x == 0) {
@@ -156,6 +171,29 @@ __global__ __launch_bounds__(kSelThreads) void find2_kernel(const uint32_t *__re
         }
         st->key_lo = key_lo;
         st->n_cand = 0;
+        if (tau_out) // batched path: the same floor as a float for the GEMM epilogue's compare
+            tau_out[blockIdx.x] = key_lo == 0 ? -__builtin_inff() : key_score(key_lo);
+    }
+}
+
+// batched collect over materialised sample scores: packed (score, row) per query
+__global__ __launch_bounds__(kSelThreads) void collect_packed_kernel(const float *__restrict__ scores, uint32_t n,
+                                                                     SelectState *st, uint64_t *__restrict__ cand,
+                                                                     size_t score_stride, uint32_t cand_stride)
+{
+    scores += blockIdx.y * score_stride;
+    cand += static_cast<size_t>(blockIdx.y) * cand_stride;
+    st += blockIdx.y;
+    const uint32_t key_lo = st->key_lo;
+    const uint32_t cap = st->cap;
+    const uint32_t stride = gridDim.x * kSelThreads;
+    for (uint32_t i = blockIdx.x * kSelThreads + threadIdx.x; i < n; i += stride) {
+        const float v = scores[i];
+        if (score_key(v) >= key_lo) {
+            const uint32_t slot = atomicAdd(&st->n_cand, 1u);
+            if (slot < cap)
+                cand[slot] = pack_result(v, i);
+        }
     }
 }
 
@@ -249,13 +287,34 @@ uint32_t sel_blocks(uint32_t n, int n_cu)
 hipError_t launch_hist1(const float *scores, uint32_t n, uint32_t *hist1, int n_cu, hipStream_t s)
 {
     hipLaunchKernelGGL(hist1_kernel, dim3(sel_blocks(n, n_cu)), dim3(kSelThreads), 0, s, scores, n,
-                       hist1);
+                       hist1, size_t(0), 0u);
+    return hipGetLastError();
+}
+
+// Batched two-pass select over q_count score rows of length n (stride score_stride):
+// leaves key_lo / tau per query and the sample's candidates in cand[q][...].
+hipError_t launch_batch_select(const float *scores, uint32_t n, size_t score_stride, uint32_t q_count,
+                               uint32_t *hist /* q_count x 2 x kHistBins, zeroed */, SelectState *st,
+                               float two_eps, float *tau_out, uint64_t *cand, uint32_t cand_stride, int n_cu,
+                               hipStream_t s)
+{
+    uint32_t bx = (n / 4 + kSelThreads - 1) / kSelThreads;
+    const uint32_t bx_cap = std::max<uint32_t>(1u, static_cast<uint32_t>(n_cu) * 8 / std::max(q_count, 1u));
+    bx = std::max(1u, std::min(bx, bx_cap));
+    const uint32_t hs = 2 * kHistBins;
+    hipLaunchKernelGGL(hist1_kernel, dim3(bx, q_count), dim3(kSelThreads), 0, s, scores, n, hist, score_stride, hs);
+    hipLaunchKernelGGL(find1_kernel, dim3(q_count), dim3(kSelThreads), 0, s, hist, st, hs);
+    hipLaunchKernelGGL(hist2_kernel, dim3(bx, q_count), dim3(kSelThreads), 0, s, scores, n, st, hist + kHistBins,
+                       score_stride, hs);
+    hipLaunchKernelGGL(find2_kernel, dim3(q_count), dim3(kSelThreads), 0, s, hist + kHistBins, st, two_eps, hs, tau_out);
+    hipLaunchKernelGGL(collect_packed_kernel, dim3(bx, q_count), dim3(kSelThreads), 0, s, scores, n, st, cand,
+                       score_stride, cand_stride);
     return hipGetLastError();
 }
 
 hipError_t launch_find1(const uint32_t *hist1, SelectState *st, hipStream_t s)
 {
-    hipLaunchKernelGGL(find1_kernel, dim3(1), dim3(kSelThreads), 0, s, hist1, st);
+    hipLaunchKernelGGL(find1_kernel, dim3(1), dim3(kSelThreads), 0, s, hist1, st, 0u);
     return hipGetLastError();
 }
 
@@ -263,13 +322,14 @@ hipError_t launch_hist2(const float *scores, uint32_t n, const SelectState *st, 
                         int n_cu, hipStream_t s)
 {
     hipLaunchKernelGGL(hist2_kernel, dim3(sel_blocks(n, n_cu)), dim3(kSelThreads), 0, s, scores, n,
-                       st, hist2);
+                       st, hist2, size_t(0), 0u);
     return hipGetLastError();
 }
 
 hipError_t launch_find2(const uint32_t *hist2, SelectState *st, float two_eps, hipStream_t s)
 {
-    hipLaunchKernelGGL(find2_kernel, dim3(1), dim3(kSelThreads), 0, s, hist2, st, two_eps);
+    hipLaunchKernelGGL(find2_kernel, dim3(1), dim3(kSelThreads), 0, s, hist2, st, two_eps, 0u,
+                       static_cast<float *>(nullptr));
     return hipGetLastError();
 }
 

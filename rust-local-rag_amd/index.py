@@ -36,6 +36,13 @@ class Profile:
     scan_bytes: int
     n_candidates: int
     n_retries: int
+    n_batches: int = 0
+    n_batch_queries: int = 0
+    batch_gemm_ms: float = 0.0
+    batch_other_ms: float = 0.0
+    batch_gemm_bytes: int = 0
+    batch_gemm_flops: float = 0.0
+    n_batch_fallbacks: int = 0
 
 
 class GpuIndex:

@@ -316,3 +316,69 @@ def test_sharded_index_world1_device_results(rlr, oracle):
     assert r2.shape == (1, 30)
     wr, wc = oracle_topk(oracle, oracle.synth_rows(30, dim, seed=506), qs[0], 100)
     assert np.array_equal(r2[0].astype(np.uint64), wr) and np.array_equal(bits(c2[0]), bits(wc))
+
+
+# ---------------------------------------------------------------- batched (matrix-core) path
+def _check_batch(rlr, oracle, ix, rows, qs, k):
+    ix.profile_read(reset=True)
+    r, c = ix.search_topk(qs, k)
+    prof = ix.profile_read()
+    for i in range(len(qs)):
+        wr, wc = oracle_topk(oracle, rows, qs[i], k)
+        assert np.array_equal(r[i], wr), f"query {i}: rows differ"
+        assert np.array_equal(bits(c[i]), bits(wc)), f"query {i}: scores differ"
+    return prof
+
+
+def test_batched_mfma_small_corpus_all_materialised(rlr, oracle):
+    rows = oracle.synth_rows(6000, 768, seed=111)
+    qs = np.stack([oracle.normalize(oracle.synth_query(768, seed=700 + i)) for i in range(40)])
+    ix = make_index(rlr, rows)
+    prof = _check_batch(rlr, oracle, ix, rows, qs, 100)
+    assert prof.n_batches == 1 and prof.n_batch_queries == 40 and prof.n_batch_fallbacks == 0
+    prof = _check_batch(rlr, oracle, ix, rows, qs[:17], 5)
+    assert prof.n_batches == 1 and prof.n_batch_fallbacks == 0
+    ix.close()
+
+
+def test_batched_mfma_sample_then_filter(rlr, oracle):
+    n = 200_000
+    rows = oracle.synth_rows(n, 768, seed=112)
+    qs = np.stack([oracle.normalize(oracle.synth_query(768, seed=800 + i)) for i in range(24)])
+    ix = rlr.GpuIndex(768)
+    ix.fill_synthetic(n, seed=112)
+    prof = _check_batch(rlr, oracle, ix, rows, qs, 100)
+    assert prof.n_batches == 1 and prof.n_batch_fallbacks == 0
+    ix.close()
+
+
+def test_batched_mfma_fp16_rows_1024d_more_than_256_queries(rlr, oracle):
+    n = 30_000
+    rows = oracle.synth_rows(n, 1024, seed=113, f16=True)
+    qs = np.stack([oracle.normalize(oracle.synth_query(1024, seed=900 + i)) for i in range(300)])
+    ix = rlr.GpuIndex(1024, "f16")
+    ix.fill_synthetic(n, seed=113)
+    ix.profile_read(reset=True)
+    r, c = ix.search_topk(qs, 20)
+    prof = ix.profile_read()
+    assert prof.n_batches == 1 and prof.n_batch_queries == 300 and prof.n_batch_fallbacks == 0
+    for i in range(0, 300, 7):  # spot-check every 7th query against the oracle (CPU time)
+        wr, wc = oracle_topk(oracle, rows, qs[i], 20)
+        assert np.array_equal(r[i], wr) and np.array_equal(bits(c[i]), bits(wc)), i
+    # and the batched path agrees with the single-query path on every query
+    for i in range(0, 300, 31):
+        r1, c1 = ix.search_topk(qs[i], 20)
+        assert np.array_equal(r1[0], r[i]) and np.array_equal(bits(c1[0]), bits(c[i]))
+    ix.close()
+
+
+def test_batched_mfma_falls_back_on_duplicate_flood(rlr, oracle):
+    base = oracle.synth_rows(5000, 768, seed=114)
+    q0 = oracle.synth_query(768, seed=115)
+    dup = oracle.normalize(q0 + np.float32(0.01) * base[0])
+    rows = np.concatenate([base, np.repeat(dup[None, :], 9000, axis=0)])
+    qs = np.stack([oracle.normalize(q0)] + [oracle.normalize(oracle.synth_query(768, seed=950 + i)) for i in range(19)])
+    ix = make_index(rlr, rows)
+    prof = _check_batch(rlr, oracle, ix, rows, qs, 10)
+    assert prof.n_batch_fallbacks >= 1          # query 0 overflows its band and is re-run alone
+    ix.close()
