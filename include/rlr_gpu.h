@@ -109,7 +109,7 @@ int32_t rlr_index_fill_synthetic(rlr_index *idx, uint64_t n_rows, uint64_t row0,
  * nominates candidates (everything within the guard band of the k-th score); the
  * nominated rows are re-scored on the GPU in strict reference order before the final
  * ordering, so the band never leaks into the result.
- * Batches of >= 16 queries (RLR_BATCH_MIN) on dims that are a multiple of 64 take the matrix-core
+ * Batches of >= 16 queries (RLR_BATCH_MIN) on dims that are a multiple of 128 take the matrix-core
  * path: Q x Corpus^T by v_mfma_f32_16x16x32_f16 on binary16-rounded operands nominates
  * candidates (rigorous band), the same reference-order re-score finishes; the
  * results are identical to looping single queries. */

@@ -46,10 +46,16 @@ constexpr int kChunkFrags = kKsChunk * kNB * 64; // half8 entries per B chunk (3
 
 // queries f32 [n_queries x q_pitch] -> binary16, fragment-major:
 //   [qblock][kstep][colblock][lane][8]   with  query = qblock*256 + colblock*16 + (lane & 15)
-//                                              k     = kstep*32 + (lane >> 4)*8 + j
+// The k a lane's element j stands for only has to agree between the A and B fragments, so it is
+// chosen for the A (corpus row) loads to be contiguous per instruction:
+//   f16 rows: k = kstep*32 + g*8 + j                       (one 16-B load, 4 lanes = 64 B of a row)
+//   f32 rows: k = kstep*32 + g*4 + j        for j < 4      (first 16-B load : bytes [g*16, +16))
+//             k = kstep*32 + 16 + g*4 + j-4 for j >= 4     (second 16-B load: bytes [64 + g*16, +16))
+// with g = lane >> 4: each load instruction covers 16 rows x 64 contiguous bytes.
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restrict__ q, uint32_t n_queries,
                                                            uint32_t q_pitch, uint32_t dim, uint32_t n_ksteps,
-                                                           uint32_t n_qblocks, _Float16 *__restrict__ out)
+                                                           uint32_t n_qblocks, int f16_rows,
+                                                           _Float16 *__restrict__ out)
 {
     const size_t total = static_cast<size_t>(n_qblocks) * n_ksteps * kNB * 64 * 8;
     for (size_t e = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<size_t>(gridDim.x) * 256) {
@@ -60,7 +66,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float *__restri
         const uint32_t ks = static_cast<uint32_t>(rest % n_ksteps);
         const uint32_t qb = static_cast<uint32_t>(rest / n_ksteps);
         const uint32_t query = qb * kQB + nb * 16 + (lane & 15);
-        const uint32_t k = ks * 32 + (lane >> 4) * 8 + j;
+        const uint32_t g = lane >> 4;
+        const uint32_t k = ks * 32 + (f16_rows ? g * 8 + j : (j < 4 ? g * 4 + j : 16 + g * 4 + (j - 4)));
         float v = 0.0f;
         if (query < n_queries && k < dim)
             v = q[static_cast<size_t>(query) * q_pitch + k];
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm_nominate_kernel(const GemmArgs a)
 #pragma unroll
     for (int rg = 0; rg < kRG; ++rg) {
         const uint32_t r = min(row0 + rg * 16 + (lane & 15), last_row);
-        ap[rg] = a.rows + static_cast<size_t>(r) * a.pitch_bytes + (lane >> 4) * (F16ROWS ? 16 : 32);
+        ap[rg] = a.rows + static_cast<size_t>(r) * a.pitch_bytes + (lane >> 4) * 16;
     }
     constexpr int kStepBytes = F16ROWS ? 64 : 128; // bytes of one row consumed per k-step
 
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(512) void gemm_nominate_kernel(const GemmArgs a)
                     araw[rg][ks][0] = *reinterpret_cast<const float4 *>(p);
                 } else {
                     araw[rg][ks][0] = *reinterpret_cast<const float4 *>(p);
-                    araw[rg][ks][1] = *reinterpret_cast<const float4 *>(p + 16);
+                    araw[rg][ks][1] = *reinterpret_cast<const float4 *>(p + 64);
                 }
             }
     };
@@ -366,15 +373,15 @@ float nomination_eps(uint32_t dim, int dtype)
     return (op * 1.001f + acc + sub) * 1.0625f;
 }
 
-hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pitch, uint32_t dim, void *qfrag,
-                               hipStream_t s)
+hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pitch, uint32_t dim, int dtype,
+                               void *qfrag, hipStream_t s)
 {
     const uint32_t n_ksteps = dim / 32;
     const uint32_t n_qblocks = (n_queries + kQB - 1) / kQB;
     const size_t total = static_cast<size_t>(n_qblocks) * n_ksteps * kNB * 64 * 8;
     const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((total + 255) / 256, 4096));
     hipLaunchKernelGGL(prep_queries_kernel, dim3(blocks), dim3(256), 0, s, q, n_queries, q_pitch, dim, n_ksteps,
-                       n_qblocks, static_cast<_Float16 *>(qfrag));
+                       n_qblocks, dtype == RLR_F16 ? 1 : 0, static_cast<_Float16 *>(qfrag));
     return hipGetLastError();
 }
 

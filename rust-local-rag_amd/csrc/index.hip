@@ -487,7 +487,7 @@ constexpr uint32_t kBatchMaxQueries = 1024; // queries per batched pipeline run 
 
 bool batch_eligible(const rlr_index *ix, uint32_t nq, uint32_t k)
 {
-    return nq >= ix->batch_min && ix->batch_min > 0 && ix->dim % 64 == 0 && ix->n_rows >= 4096 &&
+    return nq >= ix->batch_min && ix->batch_min > 0 && ix->dim % 128 == 0 && ix->n_rows >= 4096 &&
            k * 8 <= batch_finish_capacity();
 }
 
@@ -552,7 +552,7 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     RLR_HIP(hipMemsetAsync(c->d_bhist, 0, static_cast<size_t>(nq) * 2 * kHistBins * sizeof(uint32_t), s));
     RLR_HIP(hipMemsetAsync(c->d_bstatus, 0xFF, static_cast<size_t>(nq) * sizeof(uint32_t), s));
     if (timed) RLR_HIP(hipEventRecord(c->bev[0], s));
-    RLR_HIP(launch_prep_queries(dq, nq, ix->q_pitch, ix->dim, c->d_qfrag, s));
+    RLR_HIP(launch_prep_queries(dq, nq, ix->q_pitch, ix->dim, ix->dtype, c->d_qfrag, s));
     // 1. nominated scores of the sample rows, materialised
     RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, 0, static_cast<uint32_t>(S), c->d_qfrag, nq,
                                  nullptr, nullptr, 0, nullptr, c->d_sample, s_stride, s));

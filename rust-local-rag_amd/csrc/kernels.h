@@ -56,8 +56,8 @@ hipError_t launch_batch_select(const float *scores, uint32_t n, size_t score_str
 // ---- gemm.hip : batched queries, MFMA nomination + per-query exact finish ----------------
 float nomination_eps(uint32_t dim, int dtype);
 uint32_t batch_finish_capacity();
-hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pitch, uint32_t dim, void *qfrag,
-                               hipStream_t s);
+hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pitch, uint32_t dim, int dtype,
+                               void *qfrag, hipStream_t s);
 // scores != null: materialise nominated scores of rows [row_begin,row_end) (column = row - row_begin);
 // scores == null: filter mode, append (score,row) >= tau[q] to cand[q].
 hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin,
