@@ -218,6 +218,8 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
         e = hipEventCreate(&c->bev[i]);
     if (e == hipSuccess)
         e = hipMalloc(reinterpret_cast<void **>(&c->d_hist), 2 * kHistBins * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = hipMemset(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t));
     if (e != hipSuccess) {
         ctx_free(c);
         return fail(RLR_E_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -338,7 +340,7 @@ int32_t ctx_prepare(rlr_index *ix, Ctx *c, uint32_t nq, const SearchPlan &p)
         RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_packed), static_cast<size_t>(p.cap) * sizeof(uint64_t)));
         c->cand_cap = p.cap;
     }
-    RLR_TRY(grow(&c->d_out, &c->out_cap, std::max<uint64_t>(static_cast<uint64_t>(nq) * p.k, 1)));
+    RLR_TRY(grow(&c->d_out, &c->out_cap, static_cast<uint64_t>(nq) * p.k + nq)); // results + per-query counts
     return RLR_OK;
 }
 
@@ -347,10 +349,13 @@ int32_t ctx_prepare(rlr_index *ix, Ctx *c, uint32_t nq, const SearchPlan &p)
 namespace rlr {
 // device-side: sort the re-scored candidates (<= kLdsSortCap) and emit the best k.
 __global__ __launch_bounds__(1024) void sort_emit_kernel(uint64_t *__restrict__ packed, const SelectState *__restrict__ st,
-                                                         uint64_t *__restrict__ out, uint32_t k)
+                                                         uint64_t *__restrict__ out, uint32_t k,
+                                                         uint64_t *__restrict__ meta)
 {
     __shared__ uint64_t s[4096];
     const uint32_t n_raw = st->n_cand;
+    if (threadIdx.x == 0 && meta)
+        *meta = n_raw; // travels to the host with the results: one D2H per call
     if (n_raw > st->cap || n_raw > 4096)
         return; // band overflow: the host re-runs this query on the large-candidate path
     uint32_t n_pad = 1;
@@ -389,8 +394,13 @@ __global__ void emit_kernel(const uint64_t *__restrict__ packed, uint32_t n, uin
 
 namespace {
 
-// Enqueue the whole pipeline for query `qi` on the context's stream.
-hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint64_t *d_out_q, bool timed)
+// Enqueue the whole pipeline for query `qi` on the context's stream:
+//   scan (+digit-1 histogram) -> digit-2 histogram (bin search folded in) -> collect (bin search
+//   folded in) -> LDS-staged reference-order re-score (clears the histograms for the next query)
+//   -> sort + emit (+ candidate count into *d_meta_q).
+// The context's histograms are zero on entry (cleared at creation and by every re-score).
+hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint64_t *d_out_q, uint64_t *d_meta_q,
+                         bool timed)
 {
     hipStream_t s = c->stream;
     hipError_t e;
@@ -399,7 +409,6 @@ hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p
     SelectState *st = c->d_state + qi;
     const float *dq = c->d_query + static_cast<size_t>(qi) * ix->q_pitch;
 
-    if ((e = hipMemsetAsync(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(c->ev[0], s)) != hipSuccess) return e;
     ScanArgs sa;
     sa.rows = ix->d_rows;
@@ -414,16 +423,20 @@ hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p
     sa.variant = ix->scan_variant;
     if ((e = launch_scan(sa, s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(c->ev[1], s)) != hipSuccess) return e;
-    if ((e = launch_find1(hist1, st, s)) != hipSuccess) return e;
-    if ((e = launch_hist2(c->d_scores, n, st, hist2, ix->n_cu, s)) != hipSuccess) return e;
-    if ((e = launch_find2(hist2, st, p.two_eps, s)) != hipSuccess) return e;
-    if ((e = launch_collect(c->d_scores, n, st, c->d_cand, ix->n_cu, s)) != hipSuccess) return e;
+    if ((e = launch_hist2_find1(c->d_scores, n, hist1, hist2, st, p.k, p.cap, ix->n_cu, s)) != hipSuccess) return e;
+    if ((e = launch_collect_find2(c->d_scores, n, hist2, st, p.two_eps, c->d_cand, ix->n_cu, s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(c->ev[2], s)) != hipSuccess) return e;
-    const uint32_t n_pad = std::min<uint32_t>(p.cap, kLdsSortCap);
-    if ((e = launch_rescore(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st, c->d_packed, n_pad, s)) !=
-        hipSuccess)
-        return e;
-    hipLaunchKernelGGL(rlr::sort_emit_kernel, dim3(1), dim3(1024), 0, s, c->d_packed, st, d_out_q, p.k);
+    const uint32_t n_max = std::min<uint32_t>(p.cap, kLdsSortCap);
+    if (!launch_rescore_staged(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st, c->d_packed, n_max,
+                               c->d_hist, s, &e)) {
+        // rows too large for the staged layout: one lane per candidate, then clear the histograms
+        if ((e = launch_rescore(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st, c->d_packed, n_max, s)) !=
+            hipSuccess)
+            return e;
+        e = hipMemsetAsync(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), s);
+    }
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rlr::sort_emit_kernel, dim3(1), dim3(1024), 0, s, c->d_packed, st, d_out_q, p.k, d_meta_q);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(c->ev[3], s)) != hipSuccess) return e;
     return hipSuccess;
@@ -595,10 +608,12 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     return RLR_OK;
 }
 
-// Runs nq queries; results (packed, k per query) end up in d_out (context buffer or the
-// caller's device buffer).  h_states receives the final per-query states.
+// Runs nq queries.  Packed results (k per query) end up in d_out_user when given (device-resident
+// variant), else in the context buffer AND in pinned host memory (*h_results, nq x k u64) -- one
+// H2D (queries), one D2H (results + per-query candidate counts) and one stream synchronisation
+// per call on the common path.
 int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uint32_t k_req, float guard_eps,
-                   uint64_t *d_out_user, SearchPlan *plan_out)
+                   uint64_t *d_out_user, SearchPlan *plan_out, const uint64_t **h_results)
 {
     const uint32_t n = static_cast<uint32_t>(ix->n_rows);
     SearchPlan p;
@@ -607,34 +622,39 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     p.two_eps = 2.0f * eps;
     p.cap = kLdsSortCap;
     *plan_out = p;
+    if (h_results)
+        *h_results = nullptr;
     if (p.k == 0 || nq == 0)
         return RLR_OK;
     RLR_TRY(ctx_prepare(ix, c, nq, p));
+    const size_t n_res = static_cast<size_t>(nq) * p.k;
     uint64_t *d_out = d_out_user ? d_out_user : c->d_out;
+    uint64_t *d_meta = c->d_out + n_res; // per-query candidate counts, right behind the context's results
 
-    // stage queries (zero padded to the row pitch) and the initial select states
+    // stage queries (zero padded to the row pitch)
     const size_t q_bytes = static_cast<size_t>(nq) * ix->q_pitch * sizeof(float);
-    const size_t st_bytes = static_cast<size_t>(nq) * sizeof(SelectState);
-    RLR_TRY(pin_reserve(c, q_bytes + 2 * st_bytes));
+    const size_t res_bytes = (n_res + nq) * sizeof(uint64_t);
+    RLR_TRY(pin_reserve(c, q_bytes + res_bytes));
     float *h_q = static_cast<float *>(c->h_pin);
-    SelectState *h_st = reinterpret_cast<SelectState *>(static_cast<char *>(c->h_pin) + q_bytes);
-    SelectState *h_st_back = h_st + nq;
-    std::memset(h_q, 0, q_bytes);
+    uint64_t *h_res = reinterpret_cast<uint64_t *>(static_cast<char *>(c->h_pin) + q_bytes);
+    uint64_t *h_meta = h_res + n_res;
+    if (ix->q_pitch != ix->dim)
+        std::memset(h_q, 0, q_bytes);
     for (uint32_t q = 0; q < nq; ++q)
         std::memcpy(h_q + static_cast<size_t>(q) * ix->q_pitch, queries + static_cast<size_t>(q) * ix->dim,
                     ix->dim * sizeof(float));
-    for (uint32_t q = 0; q < nq; ++q) {
-        std::memset(&h_st[q], 0, sizeof(SelectState));
-        h_st[q].k = p.k;
-        h_st[q].cap = p.cap;
-    }
     hipStream_t s = c->stream;
     RLR_HIP(hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s));
-    RLR_HIP(hipMemcpyAsync(c->d_state, h_st, st_bytes, hipMemcpyHostToDevice, s));
 
     const bool timed = ix->profiling;
     double scan_ms = 0, select_ms = 0, rescore_ms = 0, total_ms = 0;
     uint64_t n_cand_total = 0, n_retry = 0;
+    auto fetch_results = [&](size_t first, size_t count) -> int32_t { // packed results -> pinned host
+        if (!d_out_user && count)
+            RLR_HIP(hipMemcpyAsync(h_res + first, c->d_out + first, count * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        return RLR_OK;
+    };
+
     if (batch_eligible(ix, nq, p.k)) {
         // matrix-core path in runs of <= kBatchMaxQueries; queries it hands back (overflow, or
         // fewer than k finite candidates) go through the single-query pipeline below.
@@ -648,30 +668,32 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
                     redo.push_back(q0 + i);
         }
         for (uint32_t q : redo) {
-            RLR_HIP(hipMemcpyAsync(c->d_state + q, &h_st[q], sizeof(SelectState), hipMemcpyHostToDevice, s));
-            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, false));
-            RLR_HIP(hipMemcpyAsync(&h_st_back[q], c->d_state + q, sizeof(SelectState), hipMemcpyDeviceToHost, s));
+            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, d_meta + q, false));
+            RLR_HIP(hipMemcpyAsync(h_meta + q, d_meta + q, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
             RLR_HIP(hipStreamSynchronize(s));
-            const uint32_t nc = h_st_back[q].n_cand;
+            const uint32_t nc = static_cast<uint32_t>(h_meta[q]);
             if (nc > p.cap || nc > kLdsSortCap) {
                 n_retry++;
                 RLR_TRY(big_query(ix, c, q, p, nc, /*rescan=*/false, d_out + static_cast<size_t>(q) * p.k));
             }
         }
+        RLR_TRY(fetch_results(0, n_res));
+        RLR_HIP(hipStreamSynchronize(s));
+        if (h_results)
+            *h_results = h_res;
         std::lock_guard<std::mutex> lk(ix->mu);
         ix->prof.n_searches += nq;
         ix->prof.n_retries += n_retry;
         return RLR_OK;
     }
+
     if (!timed) {
         for (uint32_t q = 0; q < nq; ++q)
-            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, false));
-        RLR_HIP(hipMemcpyAsync(h_st_back, c->d_state, st_bytes, hipMemcpyDeviceToHost, s));
-        RLR_HIP(hipStreamSynchronize(s));
+            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, d_meta + q, false));
     } else {
         // one query at a time so the four events can be read back per query
         for (uint32_t q = 0; q < nq; ++q) {
-            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, true));
+            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, d_meta + q, true));
             RLR_HIP(hipStreamSynchronize(s));
             float a = 0, b = 0, d = 0;
             RLR_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
@@ -682,18 +704,28 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
             rescore_ms += d;
             total_ms += a + b + d;
         }
-        RLR_HIP(hipMemcpyAsync(h_st_back, c->d_state, st_bytes, hipMemcpyDeviceToHost, s));
-        RLR_HIP(hipStreamSynchronize(s));
     }
-    // band overflow -> large-candidate path (rare: massive exact ties, or k > 2048)
+    if (!d_out_user) // results and counts are contiguous in the context buffer: one copy
+        RLR_HIP(hipMemcpyAsync(h_res, c->d_out, res_bytes, hipMemcpyDeviceToHost, s));
+    else
+        RLR_HIP(hipMemcpyAsync(h_meta, d_meta, nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    RLR_HIP(hipStreamSynchronize(s));
+    // band overflow -> large-candidate path (rare: massive exact ties, or k > 4096)
+    bool refetch = false;
     for (uint32_t q = 0; q < nq; ++q) {
-        const uint32_t nc = h_st_back[q].n_cand;
+        const uint32_t nc = static_cast<uint32_t>(h_meta[q]);
         n_cand_total += nc;
         if (nc > p.cap || nc > kLdsSortCap) {
             n_retry++;
             RLR_TRY(big_query(ix, c, q, p, nc, /*rescan=*/nq > 1, d_out + static_cast<size_t>(q) * p.k));
+            RLR_TRY(fetch_results(static_cast<size_t>(q) * p.k, p.k));
+            refetch = true;
         }
     }
+    if (refetch)
+        RLR_HIP(hipStreamSynchronize(s));
+    if (h_results)
+        *h_results = h_res;
     {
         std::lock_guard<std::mutex> lk(ix->mu);
         ix->prof.n_searches += nq;
@@ -966,12 +998,10 @@ int32_t rlr_search_topk(rlr_index *ix, const float *queries, uint32_t n_queries,
     RLR_TRY(ctx_acquire(ix, &lease.c));
     Ctx *c = lease.c;
     SearchPlan p;
-    RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, nullptr, &p));
-    const size_t bytes = static_cast<size_t>(n_queries) * p.k * sizeof(uint64_t);
-    RLR_TRY(pin_reserve(c, bytes));
-    RLR_HIP(hipMemcpyAsync(c->h_pin, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
-    RLR_HIP(hipStreamSynchronize(c->stream));
-    const uint64_t *h = static_cast<const uint64_t *>(c->h_pin);
+    const uint64_t *h = nullptr;
+    RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, nullptr, &p, &h));
+    if (!h)
+        return fail(RLR_E_INTERNAL, "search produced no result buffer");
     for (uint32_t q = 0; q < n_queries; ++q) {
         n_out[q] = p.k;
         for (uint32_t i = 0; i < p.k; ++i) {
@@ -1004,10 +1034,10 @@ int32_t rlr_search_topk_device(rlr_index *ix, const float *queries, uint32_t n_q
     Ctx *c = lease.c;
     SearchPlan p;
     if (k <= ix->n_rows) {
-        RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, static_cast<uint64_t *>(d_packed_out), &p));
+        RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, static_cast<uint64_t *>(d_packed_out), &p, nullptr));
     } else {
         // fewer rows than k: produce the n_rows results, then spread them into k-strided slots
-        RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, nullptr, &p));
+        RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, nullptr, &p, nullptr));
         RLR_HIP(hipMemsetAsync(d_packed_out, 0, static_cast<size_t>(n_queries) * k * sizeof(uint64_t), c->stream));
         RLR_HIP(hipMemcpy2DAsync(d_packed_out, static_cast<size_t>(k) * 8, c->d_out, static_cast<size_t>(p.k) * 8,
                                  static_cast<size_t>(p.k) * 8, n_queries, hipMemcpyDeviceToDevice, c->stream));

@@ -46,6 +46,11 @@ hipError_t launch_hist2(const float *scores, uint32_t n, const SelectState *st, 
 hipError_t launch_find2(const uint32_t *hist2, SelectState *st, float two_eps, hipStream_t s);
 hipError_t launch_collect(const float *scores, uint32_t n, SelectState *st, uint32_t *cand,
                           int n_cu, hipStream_t s);
+// single-query pipeline: bin searches folded into the kernels that need them
+hipError_t launch_hist2_find1(const float *scores, uint32_t n, const uint32_t *hist1, uint32_t *hist2,
+                              SelectState *st, uint32_t k, uint32_t cap, int n_cu, hipStream_t s);
+hipError_t launch_collect_find2(const float *scores, uint32_t n, const uint32_t *hist2, SelectState *st,
+                                float two_eps, uint32_t *cand, int n_cu, hipStream_t s);
 // sort `n_pad` (power of two) packed u64 descending in place; entries >= n are 0.
 hipError_t launch_sort_desc(uint64_t *packed, uint32_t n_pad, hipStream_t s);
 
@@ -75,6 +80,10 @@ hipError_t launch_batch_finish(const void *rows, uint32_t pitch16, uint32_t dim,
 hipError_t launch_rescore(const void *rows, uint32_t pitch16, uint32_t dim, int dtype,
                           const float *query, const uint32_t *cand, const SelectState *st,
                           uint64_t *packed_out, uint32_t n_pad, hipStream_t s);
+// LDS-staged variant for the fast path (no zero fill; also clears 2*kHistBins words at hist_clear).
+bool launch_rescore_staged(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *query,
+                           const uint32_t *cand, const SelectState *st, uint64_t *packed_out, uint32_t n_max,
+                           uint32_t *hist_clear, hipStream_t s, hipError_t *err);
 // cos_out[i] = dot_ref(query, row[list[i]]) for an explicit row list.
 hipError_t launch_score_rows(const void *rows, uint32_t pitch16, uint32_t dim, int dtype,
                              const float *query, const uint32_t *list, uint32_t n, float *cos_out,

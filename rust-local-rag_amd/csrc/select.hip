@@ -90,15 +90,17 @@ __global__ __launch_bounds__(kSelThreads) void hist2_kernel(const float *__restr
     block_hist_flush(s_hist, g_hist);
 }
 
-// One workgroup: find the bin holding the `rank`-th largest key (rank is 1-based)
-// by a suffix sum from the top bin.  Returns (bin, rank inside the bin) to every thread.
+// One workgroup: find the bin holding the `rank`-th largest key (rank is 1-based) by a suffix
+// sum from the top bin: 8 bins per thread, wavefront suffix scan with __shfl_down, the four wave
+// totals combined through LDS.  Returns (bin, rank inside the bin) to every thread.
 __device__ inline void find_rank_bin(const uint32_t *__restrict__ hist, uint32_t rank,
                                      uint32_t *bin_out, uint32_t *rank_in_bin)
 {
     constexpr int PER = kHistBins / kSelThreads; // 8 bins per thread
-    __shared__ uint32_t s_part[kSelThreads];
+    __shared__ uint32_t s_wave[kSelThreads / 64];
     __shared__ uint32_t s_res[2];
     const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
     uint32_t loc[PER];
     uint32_t sum = 0;
 #pragma unroll
@@ -106,21 +108,26 @@ __device__ inline void find_rank_bin(const uint32_t *__restrict__ hist, uint32_t
         loc[i] = hist[t * PER + i];
         sum += loc[i];
     }
-    s_part[t] = sum;
+    // inclusive suffix sum inside the wave: suf = sum over lanes >= lane
+    uint32_t suf = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_down(suf, off);
+        if (lane + off < 64)
+            suf += v;
+    }
+    if (lane == 0)
+        s_wave[wave] = suf;
     if (t == 0) {
         s_res[0] = 0;
         s_res[1] = 1;
     }
     __syncthreads();
-    // inclusive suffix sum over threads (Hillis-Steele, 8 steps)
-    for (int off = 1; off < kSelThreads; off <<= 1) {
-        uint32_t add = (t + off < kSelThreads) ? s_part[t + off] : 0;
-        __syncthreads();
-        s_part[t] += add;
-        __syncthreads();
-    }
-    // above = number of keys in bins owned by higher threads
-    uint32_t above = (t + 1 < kSelThreads) ? s_part[t + 1] : 0;
+    uint32_t above_waves = 0; // keys in bins owned by higher waves
+    for (int w = wave + 1; w < kSelThreads / 64; ++w)
+        above_waves += s_wave[w];
+    // above = number of keys in bins above this thread's highest bin
+    uint32_t above = above_waves + suf - sum;
 #pragma unroll
     for (int i = PER - 1; i >= 0; --i) {
         const uint32_t with = above + loc[i];
@@ -134,6 +141,8 @@ __device__ inline void find_rank_bin(const uint32_t *__restrict__ hist, uint32_t
     *bin_out = s_res[0];
     *rank_in_bin = s_res[1];
 }
+
+__device__ inline uint32_t band_floor_key(uint32_t bin1, uint32_t bin2, float two_eps);
 
 __global__ __launch_bounds__(kSelThreads) void find1_kernel(const uint32_t *__restrict__ hist1,
                                                             SelectState *st, uint32_t hist_stride)
@@ -158,17 +167,7 @@ __global__ __launch_bounds__(kSelThreads) void find2_kernel(const uint32_t *__re
     find_rank_bin(hist2, st->k2, &bin, &rk);
     if (threadIdx.x == 0) {
         st->bin2 = bin;
-        // lower edge of the 22-bit prefix bin that holds the k-th largest score:
-        // floor <= k-th score, and the bin is 2^10 keys wide.
-        const uint32_t key_floor = (st->bin1 << 21) | (bin << 10);
-        uint32_t key_lo = 0;
-        if (key_floor != 0) {
-            const float floor_score = key_score(key_floor);
-            const float lo = floor_score - two_eps; // -inf stays -inf
-            key_lo = score_key(lo);
-            if (key_lo > key_floor)
-                key_lo = key_floor;
-        }
+        const uint32_t key_lo = band_floor_key(st->bin1, bin, two_eps);
         st->key_lo = key_lo;
         st->n_cand = 0;
         if (tau_out) // batched path: the same floor as a float for the GEMM epilogue's compare
@@ -202,6 +201,94 @@ __global__ __launch_bounds__(kSelThreads) void collect_kernel(const float *__res
                                                               uint32_t *__restrict__ cand)
 {
     const uint32_t key_lo = st->key_lo;
+    const uint32_t cap = st->cap;
+    const uint32_t stride = gridDim.x * kSelThreads;
+    const uint32_t n4 = n / 4;
+    const float4 *s4 = reinterpret_cast<const float4 *>(scores);
+    for (uint32_t i = blockIdx.x * kSelThreads + threadIdx.x; i < n4; i += stride) {
+        const float4 v = s4[i];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (score_key(e[j]) >= key_lo) {
+                const uint32_t slot = atomicAdd(&st->n_cand, 1u);
+                if (slot < cap)
+                    cand[slot] = i * 4 + j;
+            }
+        }
+    }
+    for (uint32_t i = n4 * 4 + blockIdx.x * kSelThreads + threadIdx.x; i < n; i += stride) {
+        if (score_key(scores[i]) >= key_lo) {
+            const uint32_t slot = atomicAdd(&st->n_cand, 1u);
+            if (slot < cap)
+                cand[slot] = i;
+        }
+    }
+}
+
+// ---- single-query pipeline: find1 folded into the digit-2 histogram, find2 into the collect --
+// Every workgroup recomputes the (cheap) bin search from the 8 KB histogram in L2 instead of a
+// one-workgroup kernel in between: two launches and two dependent-launch gaps fewer per query.
+__global__ __launch_bounds__(kSelThreads) void hist2_find1_kernel(const float *__restrict__ scores, uint32_t n,
+                                                                  const uint32_t *__restrict__ hist1,
+                                                                  uint32_t *__restrict__ g_hist2, SelectState *st,
+                                                                  uint32_t k, uint32_t cap)
+{
+    __shared__ uint32_t s_hist[kHistBins];
+    uint32_t bin1, k2;
+    find_rank_bin(hist1, k, &bin1, &k2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->k = k;
+        st->bin1 = bin1;
+        st->k2 = k2;
+        st->n_cand = 0;
+        st->cap = cap;
+    }
+    for (int i = threadIdx.x; i < kHistBins; i += kSelThreads)
+        s_hist[i] = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kSelThreads;
+    const uint32_t n4 = n / 4;
+    const float4 *s4 = reinterpret_cast<const float4 *>(scores);
+    for (uint32_t i = blockIdx.x * kSelThreads + threadIdx.x; i < n4; i += stride) {
+        const float4 v = s4[i];
+        const uint32_t k0 = score_key(v.x), k1 = score_key(v.y), k2_ = score_key(v.z), k3 = score_key(v.w);
+        if ((k0 >> 21) == bin1) atomicAdd(&s_hist[(k0 >> 10) & (kHistBins - 1)], 1u);
+        if ((k1 >> 21) == bin1) atomicAdd(&s_hist[(k1 >> 10) & (kHistBins - 1)], 1u);
+        if ((k2_ >> 21) == bin1) atomicAdd(&s_hist[(k2_ >> 10) & (kHistBins - 1)], 1u);
+        if ((k3 >> 21) == bin1) atomicAdd(&s_hist[(k3 >> 10) & (kHistBins - 1)], 1u);
+    }
+    for (uint32_t i = n4 * 4 + blockIdx.x * kSelThreads + threadIdx.x; i < n; i += stride) {
+        const uint32_t k0 = score_key(scores[i]);
+        if ((k0 >> 21) == bin1) atomicAdd(&s_hist[(k0 >> 10) & (kHistBins - 1)], 1u);
+    }
+    __syncthreads();
+    block_hist_flush(s_hist, g_hist2);
+}
+
+__device__ inline uint32_t band_floor_key(uint32_t bin1, uint32_t bin2, float two_eps)
+{
+    // lower edge of the 22-bit prefix bin that holds the k-th largest score, minus the band
+    const uint32_t key_floor = (bin1 << 21) | (bin2 << 10);
+    if (key_floor == 0)
+        return 0;
+    const float lo = key_score(key_floor) - two_eps; // -inf stays -inf
+    const uint32_t key_lo = score_key(lo);
+    return key_lo > key_floor ? key_floor : key_lo;
+}
+
+__global__ __launch_bounds__(kSelThreads) void collect_find2_kernel(const float *__restrict__ scores, uint32_t n,
+                                                                    const uint32_t *__restrict__ hist2,
+                                                                    SelectState *st, float two_eps,
+                                                                    uint32_t *__restrict__ cand)
+{
+    uint32_t bin2, rk;
+    find_rank_bin(hist2, st->k2, &bin2, &rk);
+    const uint32_t key_lo = band_floor_key(st->bin1, bin2, two_eps);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->bin2 = bin2;
+        st->key_lo = key_lo;
+    }
     const uint32_t cap = st->cap;
     const uint32_t stride = gridDim.x * kSelThreads;
     const uint32_t n4 = n / 4;
@@ -338,6 +425,22 @@ hipError_t launch_collect(const float *scores, uint32_t n, SelectState *st, uint
 {
     hipLaunchKernelGGL(collect_kernel, dim3(sel_blocks(n, n_cu)), dim3(kSelThreads), 0, s, scores, n,
                        st, cand);
+    return hipGetLastError();
+}
+
+hipError_t launch_hist2_find1(const float *scores, uint32_t n, const uint32_t *hist1, uint32_t *hist2,
+                              SelectState *st, uint32_t k, uint32_t cap, int n_cu, hipStream_t s)
+{
+    hipLaunchKernelGGL(hist2_find1_kernel, dim3(sel_blocks(n, n_cu)), dim3(kSelThreads), 0, s, scores, n, hist1, hist2,
+                       st, k, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_collect_find2(const float *scores, uint32_t n, const uint32_t *hist2, SelectState *st,
+                                float two_eps, uint32_t *cand, int n_cu, hipStream_t s)
+{
+    hipLaunchKernelGGL(collect_find2_kernel, dim3(sel_blocks(n, n_cu)), dim3(kSelThreads), 0, s, scores, n, hist2, st,
+                       two_eps, cand);
     return hipGetLastError();
 }
 
