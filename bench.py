@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the same corpus the CPU baseline scans")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--check", type=int, default=1, help="queries verified against the oracle on the CPU sample")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="do not record HIP events in the timed region (roofline fields become null)")
     ap.add_argument("--batch", type=int, default=1,
                     help="queries per step; >= 16 takes the matrix-core (MFMA) batched path (BASELINE config 3 uses 256)")
     return ap.parse_args()
@@ -168,7 +170,7 @@ def main():
         step(i)
 
     ix.profile_read(reset=True)
-    ix.profile_enable(True)  # HIP events around each stage, on the stream the kernels run on
+    ix.profile_enable(not args.no_profile)  # HIP events around each stage, on the stream the kernels run on
     if dist:
         dist.barrier()
     torch.cuda.synchronize()

@@ -47,11 +47,54 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float4 *__restrict__ 
     packed_out[i] = pack_result(s, r);
 }
 
-// Re-score with the candidate rows staged through LDS: 256 threads fetch CPB rows with fully
-// coalesced 16-byte loads (all in flight at once), then CPB lanes run the strict left-to-right
-// chains out of LDS (row pitch padded by 16 B: conflict-free ds_read_b128).  ~6 us for the ~100
-// candidates of a top-100 query instead of ~39 us with one uncoalesced lane per row.  The same
-// launch clears the two radix histograms for the next query of this context.
+// Re-score with the work split the only way the reference order allows: the PRODUCTS x_i*q_i are
+// independent (each is rounded once, exactly as the reference rounds it), so all 256 threads
+// compute them straight from coalesced 16-byte row loads into LDS; only the ADDS are ordered, and
+// one lane per candidate then runs the strict left-to-right chain s = s + p_i out of LDS with the
+// reads software-pipelined two groups ahead.  ~6 us for the ~100 candidates of a top-100 query
+// (one uncoalesced lane per row took ~39 us).  The same launch clears the two radix histograms
+// for the next query of this context.
+__device__ inline float chain_sum_lds(const float4 *__restrict__ p4, const float *__restrict__ p, uint32_t dim)
+{
+    float s = 0.0f;
+    const uint32_t units = dim / 4;
+    uint32_t u = 0;
+    float4 a[4], b[4];
+    if (units >= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a[i] = p4[i];
+    }
+    for (; u + 8 <= units; u += 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            b[i] = p4[u + 4 + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s = s + a[i].x; s = s + a[i].y; s = s + a[i].z; s = s + a[i].w;
+        }
+        if (u + 12 <= units) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = p4[u + 8 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s = s + b[i].x; s = s + b[i].y; s = s + b[i].z; s = s + b[i].w;
+        }
+    }
+    if (u + 4 <= units) { // `a` holds units u..u+3 (loaded by the prologue or the last iteration)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s = s + a[i].x; s = s + a[i].y; s = s + a[i].z; s = s + a[i].w;
+        }
+        u += 4;
+    }
+    for (uint32_t e = u * 4; e < dim; ++e)
+        s = s + p[e];
+    return s;
+}
+
 template <bool F16>
 __global__ __launch_bounds__(256) void rescore_staged_kernel(const float4 *__restrict__ rows, uint32_t pitch16,
                                                              uint32_t dim, const float *__restrict__ query,
@@ -61,9 +104,10 @@ __global__ __launch_bounds__(256) void rescore_staged_kernel(const float4 *__res
                                                              uint32_t *__restrict__ hist_clear)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
-    const uint32_t q_floats = (dim + 3) & ~3u;
+    const uint32_t q_floats = (dim + 7) & ~7u;      // query, zero padded to a 16-byte unit of the row dtype
+    const uint32_t p_pitch = q_floats + 4;          // product row pitch in floats (+16 B: bank spread)
     float *s_q = s_mem;
-    float4 *s_rows = reinterpret_cast<float4 *>(s_mem + q_floats);
+    float *s_p = s_mem + q_floats;
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * 256 + tid;
     if (hist_clear && gid < 2 * kHistBins)
@@ -73,19 +117,66 @@ __global__ __launch_bounds__(256) void rescore_staged_kernel(const float4 *__res
     if (base >= n)
         return;
     const uint32_t cnt = min(cpb, n - base);
-    for (uint32_t i = tid; i < dim; i += 256)
-        s_q[i] = query[i];
-    const uint32_t lpitch = pitch16 + 1;
-    for (uint32_t idx = tid; idx < cnt * pitch16; idx += 256) {
-        const uint32_t ci = idx / pitch16;
-        const uint32_t u = idx - ci * pitch16;
-        s_rows[ci * lpitch + u] = rows[static_cast<size_t>(cand[base + ci]) * pitch16 + u];
+    __shared__ uint32_t s_cand[16];
+    for (uint32_t i = tid; i < q_floats; i += 256)
+        s_q[i] = i < dim ? query[i] : 0.0f;
+    if (tid < cnt)
+        s_cand[tid] = cand[base + tid];
+    __syncthreads();
+    // products: 16-byte units of the candidate rows, coalesced, kBatch independent loads in flight
+    // per thread before the first is consumed; pad columns multiply to 0 and are never summed
+    // (the chain stops at dim)
+    const uint32_t units = F16 ? q_floats / 8 : q_floats / 4; // units that hold real columns
+    const uint32_t total = cnt * units;
+    constexpr int kBatch = 6;
+    for (uint32_t idx0 = tid; idx0 < total; idx0 += 256 * kBatch) {
+        float4 x[kBatch];
+        uint32_t ci[kBatch], uu[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const uint32_t idx = idx0 + 256 * j;
+            ci[j] = idx / units;
+            uu[j] = idx - ci[j] * units;
+            if (idx < total)
+                x[j] = rows[static_cast<size_t>(s_cand[ci[j]]) * pitch16 + uu[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            if (idx0 + 256 * j >= total)
+                continue;
+            const uint32_t u = uu[j];
+            float *dst = s_p + ci[j] * p_pitch;
+            if constexpr (F16) {
+                const uint32_t w[4] = {__builtin_bit_cast(uint32_t, x[j].x), __builtin_bit_cast(uint32_t, x[j].y),
+                                       __builtin_bit_cast(uint32_t, x[j].z), __builtin_bit_cast(uint32_t, x[j].w)};
+                const float *q = s_q + u * 8;
+                float4 lo, hi;
+                lo.x = h2f(static_cast<uint16_t>(w[0] & 0xFFFF)) * q[0];
+                lo.y = h2f(static_cast<uint16_t>(w[0] >> 16)) * q[1];
+                lo.z = h2f(static_cast<uint16_t>(w[1] & 0xFFFF)) * q[2];
+                lo.w = h2f(static_cast<uint16_t>(w[1] >> 16)) * q[3];
+                hi.x = h2f(static_cast<uint16_t>(w[2] & 0xFFFF)) * q[4];
+                hi.y = h2f(static_cast<uint16_t>(w[2] >> 16)) * q[5];
+                hi.z = h2f(static_cast<uint16_t>(w[3] & 0xFFFF)) * q[6];
+                hi.w = h2f(static_cast<uint16_t>(w[3] >> 16)) * q[7];
+                reinterpret_cast<float4 *>(dst)[2 * u] = lo;
+                reinterpret_cast<float4 *>(dst)[2 * u + 1] = hi;
+            } else {
+                const float4 q = reinterpret_cast<const float4 *>(s_q)[u];
+                float4 pr;
+                pr.x = x[j].x * q.x;
+                pr.y = x[j].y * q.y;
+                pr.z = x[j].z * q.z;
+                pr.w = x[j].w * q.w;
+                reinterpret_cast<float4 *>(dst)[u] = pr;
+            }
+        }
     }
     __syncthreads();
     if (tid < cnt) {
-        const uint32_t r = cand[base + tid];
-        const float sc = dot_ref_row<F16>(s_rows + tid * lpitch, s_q, dim);
-        packed_out[base + tid] = pack_result(sc, r);
+        const float *pr = s_p + tid * p_pitch;
+        const float sc = chain_sum_lds(reinterpret_cast<const float4 *>(pr), pr, dim);
+        packed_out[base + tid] = pack_result(sc, s_cand[tid]);
     }
 }
 
@@ -436,9 +527,11 @@ bool launch_rescore_staged(const void *rows, uint32_t pitch16, uint32_t dim, int
                            const uint32_t *cand, const SelectState *st, uint64_t *packed_out, uint32_t n_max,
                            uint32_t *hist_clear, hipStream_t s, hipError_t *err)
 {
-    const size_t q_bytes = static_cast<size_t>((dim + 3) & ~3u) * sizeof(float);
-    const size_t row_bytes = static_cast<size_t>(pitch16 + 1) * 16;
-    uint32_t cpb = 16;
+    const size_t q_bytes = static_cast<size_t>((dim + 7) & ~7u) * sizeof(float);
+    const size_t row_bytes = q_bytes + 16; // f32 products of one candidate row (+16 B pad)
+    if (pitch16 * (dtype == RLR_F16 ? 8u : 4u) < ((dim + 7) & ~7u))
+        return false; // row pitch narrower than the 8-float rounding of dim (f32 rows, dim % 8 in 1..4)
+    uint32_t cpb = 8; // 8 rows x 3 KB per workgroup: ~13 workgroups share a top-100 re-score
     while (cpb > 1 && q_bytes + cpb * row_bytes > 60 * 1024)
         cpb >>= 1;
     if (q_bytes + cpb * row_bytes > 60 * 1024)

@@ -358,6 +358,24 @@ __global__ __launch_bounds__(1024) void sort_emit_kernel(uint64_t *__restrict__ 
         *meta = n_raw; // travels to the host with the results: one D2H per call
     if (n_raw > st->cap || n_raw > 4096)
         return; // band overflow: the host re-runs this query on the large-candidate path
+    if (n_raw <= 1024) {
+        // rank sort: keys are unique (the row number is part of the key), so the number of larger
+        // keys is the output position -- one pass, two barriers, instead of a log^2 network.
+        if (threadIdx.x < n_raw)
+            s[threadIdx.x] = packed[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x < n_raw) {
+            const uint64_t mine = s[threadIdx.x];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n_raw; ++j)
+                rank += s[j] > mine;
+            if (rank < k)
+                out[rank] = mine;
+        }
+        for (uint32_t i = n_raw + threadIdx.x; i < k; i += 1024)
+            out[i] = 0ull;
+        return;
+    }
     uint32_t n_pad = 1;
     while (n_pad < n_raw)
         n_pad <<= 1;
