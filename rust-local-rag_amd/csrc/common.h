@@ -71,6 +71,46 @@ __device__ inline float wave_sum(float v)
     v = dpp_add<0x143, 0xC, 0xF>(v); // row_bcast31 into rows 2,3 -> lane 63 = total
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+
+// DPP wavefront max (f32, no NaN inputs) / min (u32): same network as wave_sum, identity in `old`.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_fmax(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(static_cast<int>(0xFF800000u), __builtin_bit_cast(int, v), CTRL,
+                                                  ROW_MASK, 0xF, false);
+    return __builtin_fmaxf(v, __builtin_bit_cast(float, moved));
+}
+
+__device__ inline float wave_max_f32(float v)
+{
+    v = dpp_fmax<0x111, 0xF>(v);
+    v = dpp_fmax<0x112, 0xF>(v);
+    v = dpp_fmax<0x114, 0xF>(v);
+    v = dpp_fmax<0x118, 0xF>(v);
+    v = dpp_fmax<0x142, 0xA>(v);
+    v = dpp_fmax<0x143, 0xC>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_umin(uint32_t v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(static_cast<int>(0xFFFFFFFFu), static_cast<int>(v), CTRL, ROW_MASK,
+                                                  0xF, false);
+    const uint32_t m = static_cast<uint32_t>(moved);
+    return m < v ? m : v;
+}
+
+__device__ inline uint32_t wave_min_u32(uint32_t v)
+{
+    v = dpp_umin<0x111, 0xF>(v);
+    v = dpp_umin<0x112, 0xF>(v);
+    v = dpp_umin<0x114, 0xF>(v);
+    v = dpp_umin<0x118, 0xF>(v);
+    v = dpp_umin<0x142, 0xA>(v);
+    v = dpp_umin<0x143, 0xC>(v);
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
 #endif
 
 } // namespace rlr

@@ -497,6 +497,122 @@ __global__ __launch_bounds__(64) void mmr_greedy_kernel(const float *__restrict_
         *out_n = n_sel;
 }
 
+// Register-resident greedy MMR for pools of <= 64*J candidates: lane l owns candidates l, l+64, ...
+// with their relevance, running max-similarity and current position in the reference's
+// `remaining` vector held in VGPRs.  A step is one batch of independent L2 loads of the last
+// pick's Gram row, a handful of VALU ops, a DPP wavefront max over the MMR values and a DPP
+// wavefront min over the positions of the lanes that hold that max ("first in visiting order
+// wins" under the reference's strict `>`), and the swap_remove position update -- no LDS, no
+// barriers.  ~0.3 us per pick instead of ~2.2 us for the LDS version.
+template <int J>
+__global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__restrict__ gram,
+                                                             const float *__restrict__ scores, uint32_t P, uint32_t k,
+                                                             float lambda, uint32_t *__restrict__ out_order,
+                                                             float *__restrict__ out_mmr, uint32_t *__restrict__ out_n)
+{
+    // The Gram matrix was just written by other CUs (possibly other XCDs): its first touch from
+    // this CU is an Infinity-Cache/HBM miss (~0.4 us), and every pick reads a different row, so
+    // the greedy chain would pay that miss 99 times.  All four waves first sweep the matrix
+    // (P*P*4 bytes, 360 KB at P = 300) into this XCD's L2; the chain's loads then hit L2.
+    {
+        const float4 *g4 = reinterpret_cast<const float4 *>(gram);
+        const uint32_t n4 = (P * P) / 4;
+        float warm = 0.0f;
+        for (uint32_t i = threadIdx.x * 8; i < n4; i += 256 * 8) // one 128-B line per thread and step
+            warm += g4[i].x;
+        asm volatile("" ::"v"(warm));
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64)
+        return;
+    const uint32_t lane = threadIdx.x;
+    float rel[J], ms[J];
+    uint32_t pos[J];
+    bool alive[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const uint32_t c = lane + 64 * j;
+        alive[j] = c < P;
+        rel[j] = alive[j] ? scores[c] : 0.0f;
+        ms[j] = 0.0f;
+        pos[j] = c;
+    }
+    // selected.push(remaining.swap_remove(0)): candidate 0 goes first, the last one takes slot 0
+    uint32_t n_rem = P - 1, n_sel = 1, last = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const uint32_t c = lane + 64 * j;
+        if (c == 0)
+            alive[j] = false;
+        else if (alive[j] && pos[j] == P - 1)
+            pos[j] = 0;
+    }
+    if (lane == 0) {
+        out_order[0] = 0;
+        out_mmr[0] = __builtin_bit_cast(float, 0x7FC00000u);
+    }
+    const float one_minus = 1.0f - lambda;
+    const float neg_inf = -__builtin_inff();
+    while (n_sel < k && n_rem > 0) {
+        const float *g_last = gram + static_cast<size_t>(last) * P;
+        float sim[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            sim[j] = alive[j] ? g_last[lane + 64 * j] : 0.0f;
+        float best_m = neg_inf;
+        uint32_t best_pos = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (!alive[j])
+                continue;
+            if (finite_f(sim[j]))
+                ms[j] = fmaxf(ms[j], sim[j]);
+            if (!finite_f(rel[j]))
+                continue;
+            const float t0 = one_minus * rel[j];
+            const float t1 = lambda * ms[j];
+            float m = t0 - t1;
+            if (!finite_f(m))
+                continue;
+            if (m == 0.0f)
+                m = 0.0f; // -0 and +0 compare equal in the reference
+            if (m > best_m || (m == best_m && pos[j] < best_pos)) {
+                best_m = m;
+                best_pos = pos[j];
+            }
+        }
+        const float wm = wave_max_f32(best_m);
+        if (wm == neg_inf) // no finite candidate left
+            break;
+        const uint32_t wp = wave_min_u32(best_m == wm ? best_pos : 0xFFFFFFFFu);
+        uint32_t win = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (alive[j] && pos[j] == wp) {
+                win = lane + 64 * j + 1;
+                alive[j] = false;
+            }
+        }
+        // exactly one lane holds the winner: broadcast its candidate index
+        const unsigned long long ball = __ballot(win != 0);
+        const int src = __builtin_ctzll(ball);
+        last = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(win), src)) - 1;
+        // swap_remove(best_idx): the candidate in the last slot moves into the freed one
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (alive[j] && pos[j] == n_rem - 1)
+                pos[j] = wp;
+        if (lane == 0) {
+            out_order[n_sel] = last;
+            out_mmr[n_sel] = wm;
+        }
+        n_sel++;
+        n_rem--;
+    }
+    if (lane == 0)
+        *out_n = n_sel;
+}
+
 uint32_t ew_blocks(size_t total)
 {
     size_t b = (total + 255) / 256;
@@ -643,8 +759,26 @@ hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P,
                              uint32_t *out_order, float *out_mmr, uint32_t *out_n, hipStream_t s)
 {
     const size_t lds = static_cast<size_t>(P ? P : 1) * 12;
-    hipLaunchKernelGGL(mmr_greedy_kernel, dim3(1), dim3(64), lds, s, gram, scores, P, k, lambda, out_order, out_mmr,
-                       out_n);
+#define RLR_MMR_REG(JV)                                                                                         \
+    hipLaunchKernelGGL(mmr_greedy_reg_kernel<JV>, dim3(1), dim3(256), 0, s, gram, scores, P, k, lambda, out_order, \
+                       out_mmr, out_n)
+    if (P == 0)
+        hipLaunchKernelGGL(mmr_greedy_kernel, dim3(1), dim3(64), lds, s, gram, scores, P, k, lambda, out_order, out_mmr,
+                           out_n);
+    else if (P <= 64)
+        RLR_MMR_REG(1);
+    else if (P <= 128)
+        RLR_MMR_REG(2);
+    else if (P <= 320)
+        RLR_MMR_REG(5);
+    else if (P <= 512)
+        RLR_MMR_REG(8);
+    else if (P <= 1024)
+        RLR_MMR_REG(16);
+    else
+        hipLaunchKernelGGL(mmr_greedy_kernel, dim3(1), dim3(64), lds, s, gram, scores, P, k, lambda, out_order, out_mmr,
+                           out_n);
+#undef RLR_MMR_REG
     return hipGetLastError();
 }
 
