@@ -150,6 +150,15 @@ int32_t rlr_mmr_select(rlr_index *idx, const uint64_t *pool_rows, const float *p
  *                 null stream); the library makes its work visible to that stream. */
 int32_t rlr_search_topk_device(rlr_index *idx, const float *queries, uint32_t n_queries,
                                uint32_t k, float guard_eps, void *d_packed_out, void *stream);
+/* The exchange step's merge: `d_gathered` is the all-gathered buffer, world x n_queries x k packed
+ * u64 (rank-major), on device `device_id`; bases[r] = first global row of rank r's shard
+ * (ascending).  Emits per query the global top-k as (global row, score) to host buffers, ordered
+ * (score desc, global row asc); n_out[q] = number of valid results (<= k; unused slots get row
+ * ~0 and NaN).  world <= 16, world * k <= 8192.  Runs on `stream` (hipStream_t or NULL) and
+ * returns after it has finished. */
+int32_t rlr_merge_topk(int32_t device_id, const void *d_gathered, uint32_t world, uint32_t n_queries,
+                       uint32_t k, const uint64_t *bases, uint64_t *rows_out, float *cos_out,
+                       uint32_t *n_out, void *stream);
 /* helpers for the packed format (host side) */
 uint64_t rlr_pack_result(float score, uint32_t row);
 void rlr_unpack_result(uint64_t packed, float *score, uint32_t *row);

@@ -402,6 +402,71 @@ __global__ __launch_bounds__(1024) void sort_emit_kernel(uint64_t *__restrict__ 
         out[i] = i < n_raw ? s[i] : 0ull;
 }
 
+// Exchange-step merge: one workgroup per query orders the world x k packed partial
+// results the all-gather delivered and emits the global top-k.  Shards are ascending row ranges,
+// so (score desc, global row asc) is the same tie rule every shard already applied.
+struct MergeBases {
+    uint64_t base[16];
+};
+
+__global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restrict__ gathered, uint32_t world,
+                                                         uint32_t n_queries, uint32_t k, MergeBases bases,
+                                                         uint64_t *__restrict__ rows_out, float *__restrict__ cos_out,
+                                                         uint32_t *__restrict__ n_out)
+{
+    __shared__ uint64_t s[8192];
+    __shared__ uint32_t s_valid;
+    const uint32_t q = blockIdx.x;
+    const uint32_t n = world * k;
+    uint32_t n_pad = 1;
+    while (n_pad < n)
+        n_pad <<= 1;
+    if (threadIdx.x == 0)
+        s_valid = 0;
+    __syncthreads();
+    uint32_t valid = 0;
+    for (uint32_t i = threadIdx.x; i < n_pad; i += 256) {
+        uint64_t v = 0;
+        if (i < n) {
+            const uint32_t r = i / k, j = i - r * k;
+            const uint64_t p = gathered[(static_cast<size_t>(r) * n_queries + q) * k + j];
+            if (p != 0) {
+                const uint64_t local = 0xFFFFFFFFull - (p & 0xFFFFFFFFull);
+                const uint64_t glob = bases.base[r] + local;
+                v = (p & 0xFFFFFFFF00000000ull) | (0xFFFFFFFFull - glob);
+                valid++;
+            }
+        }
+        s[i] = v;
+    }
+    atomicAdd(&s_valid, valid);
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= n_pad; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n_pad; i += 256) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = s[i], b = s[ixj];
+                    const bool desc = (i & kk) == 0;
+                    if (desc ? (a < b) : (a > b)) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t m = min(s_valid, k);
+    for (uint32_t i = threadIdx.x; i < k; i += 256) {
+        const uint64_t v = i < m ? s[i] : 0ull;
+        rows_out[static_cast<size_t>(q) * k + i] = i < m ? 0xFFFFFFFFull - (v & 0xFFFFFFFFull) : ~0ull;
+        cos_out[static_cast<size_t>(q) * k + i] = key_score(static_cast<uint32_t>(v >> 32));
+    }
+    if (threadIdx.x == 0)
+        n_out[q] = m;
+}
+
 __global__ void emit_kernel(const uint64_t *__restrict__ packed, uint32_t n, uint64_t *__restrict__ out, uint32_t k)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1064,6 +1129,48 @@ int32_t rlr_search_topk_device(rlr_index *ix, const float *queries, uint32_t n_q
     // run_search has synchronised the context stream, so the results are complete; a later
     // enqueue on `user` is ordered after them.
     (void)user;
+    return RLR_OK;
+}
+
+int32_t rlr_merge_topk(int32_t device_id, const void *d_gathered, uint32_t world, uint32_t n_queries, uint32_t k,
+                       const uint64_t *bases, uint64_t *rows_out, float *cos_out, uint32_t *n_out, void *stream)
+{
+    if (n_queries == 0 || k == 0)
+        return RLR_OK;
+    if (!d_gathered || !bases || !rows_out || !cos_out || !n_out)
+        return fail(RLR_E_INVALID, "null argument");
+    if (world == 0 || world > 16)
+        return fail(RLR_E_INVALID, "world size %u not in [1, 16]", world);
+    if (static_cast<uint64_t>(world) * k > 8192)
+        return fail(RLR_E_INVALID, "world * k = %llu exceeds the 8192-entry merge", static_cast<unsigned long long>(world) * k);
+    RLR_HIP(hipSetDevice(device_id));
+    // results are written straight into pinned, device-mapped host memory: no D2H copy
+    thread_local void *h_buf = nullptr;
+    thread_local size_t h_cap = 0;
+    const size_t nk = static_cast<size_t>(n_queries) * k;
+    const size_t need = nk * (sizeof(uint64_t) + sizeof(float)) + n_queries * sizeof(uint32_t) + 64;
+    if (h_cap < need) {
+        if (h_buf)
+            (void)hipHostFree(h_buf);
+        h_buf = nullptr;
+        h_cap = 0;
+        RLR_HIP(hipHostMalloc(&h_buf, std::max<size_t>(need, 1 << 16), hipHostMallocDefault));
+        h_cap = std::max<size_t>(need, 1 << 16);
+    }
+    uint64_t *h_rows = static_cast<uint64_t *>(h_buf);
+    float *h_cos = reinterpret_cast<float *>(h_rows + nk);
+    uint32_t *h_n = reinterpret_cast<uint32_t *>(h_cos + nk);
+    rlr::MergeBases mb;
+    for (uint32_t r = 0; r < 16; ++r)
+        mb.base[r] = r < world ? bases[r] : 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rlr::merge_topk_kernel, dim3(n_queries), dim3(256), 0, s, static_cast<const uint64_t *>(d_gathered),
+                       world, n_queries, k, mb, h_rows, h_cos, h_n);
+    RLR_HIP(hipGetLastError());
+    RLR_HIP(hipStreamSynchronize(s));
+    std::memcpy(rows_out, h_rows, nk * sizeof(uint64_t));
+    std::memcpy(cos_out, h_cos, nk * sizeof(float));
+    std::memcpy(n_out, h_n, n_queries * sizeof(uint32_t));
     return RLR_OK;
 }
 

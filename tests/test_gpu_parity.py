@@ -382,3 +382,43 @@ def test_batched_mfma_falls_back_on_duplicate_flood(rlr, oracle):
     prof = _check_batch(rlr, oracle, ix, rows, qs, 10)
     assert prof.n_batch_fallbacks >= 1          # query 0 overflows its band and is re-run alone
     ix.close()
+
+
+def test_merge_topk_kernel_matches_torch_merge_and_global_oracle(rlr, oracle):
+    """Four shards searched one after the other on the one GPU, their packed results laid out as an
+    all-gather would deliver them, merged by rlr_merge_topk: must equal the global oracle and the
+    torch merge used by the gloo test."""
+    import ctypes as C
+    import importlib
+    import torch
+    sharded = importlib.import_module("rust-local-rag_amd.sharded")
+    n_total, dim, k, world, nq = 9001, 768, 25, 4, 3
+    rows = oracle.synth_rows(n_total, dim, seed=321)
+    lo1 = sharded.shard_range(n_total, 1, world)[0]
+    rows[lo1 + 7] = rows[11]  # exact cross-shard tie
+    qs = np.stack([oracle.normalize(rows[11])] + [oracle.normalize(oracle.synth_query(dim, seed=330 + i)) for i in range(nq - 1)])
+    gathered = torch.zeros((world, nq, k), dtype=torch.int64, device="cuda")
+    bases = []
+    for r in range(world):
+        lo, hi = sharded.shard_range(n_total, r, world)
+        bases.append(lo)
+        ix = make_index(rlr, rows[lo:hi])
+        ix.search_topk_device(qs, k, gathered[r].data_ptr())
+        ix.close()
+    torch.cuda.synchronize()
+    bases_h = np.array(bases, dtype=np.uint64)
+    out_rows = np.zeros((nq, k), np.uint64)
+    out_cos = np.zeros((nq, k), np.float32)
+    out_n = np.zeros(nq, np.uint32)
+    L = rlr.lib()
+    st = L.rlr_merge_topk(0, C.c_void_p(gathered.data_ptr()), world, nq, k, bases_h.ctypes.data_as(C.POINTER(C.c_uint64)),
+                          out_rows.ctypes.data_as(C.POINTER(C.c_uint64)), out_cos.ctypes.data_as(C.POINTER(C.c_float)),
+                          out_n.ctypes.data_as(C.POINTER(C.c_uint32)), None)
+    assert st == 0 and (out_n == k).all()
+    t_rows, t_key = sharded.merge_packed(gathered.cpu(), torch.tensor(bases, dtype=torch.int64), k)
+    assert np.array_equal(out_rows.astype(np.int64), t_rows.numpy())
+    assert np.array_equal(bits(out_cos), bits(sharded.key_to_score(t_key.numpy())))
+    for i in range(nq):
+        wr, wc = oracle_topk(oracle, rows, qs[i], k)
+        assert np.array_equal(out_rows[i], wr) and np.array_equal(bits(out_cos[i]), bits(wc))
+    assert list(out_rows[0][:2]) == [11, lo1 + 7]  # the tie: lower global row first
