@@ -161,8 +161,10 @@ def main():
     ix = sh.index
     n_local = len(ix)
 
+    force_sharded = os.environ.get("RLR_BENCH_FORCE_SHARDED") == "1"  # rehearse the N>1 code path on one GPU
+
     def step(i):
-        if world == 1:
+        if world == 1 and not force_sharded:
             return ix.search_topk(qs[i], args.k)
         return sh.search_topk(qs[i], args.k)
 

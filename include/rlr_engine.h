@@ -83,6 +83,16 @@ int32_t rlr_engine_search_with_diversity(rlr_index *idx, const float *query_raw,
                                          const float *lex_scores, uint32_t n_lex,
                                          rlr_search_hit *out, uint32_t cap, uint32_t *n_out);
 
+/* Additive batched entry point (the reference has no batched API; its oracle is "loop
+ * search_with_diversity over the batch"): n_queries raw query embeddings,
+ * no lexical candidates.  Hits of query q start at out[q * cap]; n_out[q] = their count.
+ * The scan runs through the batched (matrix-core) path of rlr_search_topk and the MMR through
+ * rlr_mmr_select_batch; results are identical to n_queries single calls. */
+int32_t rlr_engine_search_with_diversity_batch(rlr_index *idx, const float *queries_raw, uint32_t dq,
+                                               uint32_t n_queries, uint32_t top_k, float diversity_factor,
+                                               const rlr_query_weights *weights, rlr_search_hit *out,
+                                               uint32_t cap, uint32_t *n_out);
+
 /* RagEngine::get_embedding_candidates (:415-461), `None` arm: top `count` by cosine. */
 int32_t rlr_engine_embedding_candidates(rlr_index *idx, const float *query_raw, uint32_t dq,
                                         uint32_t count, uint64_t *rows_out, float *scores_out,

@@ -140,6 +140,14 @@ int32_t rlr_mmr_select(rlr_index *idx, const uint64_t *pool_rows, const float *p
                        uint32_t P, uint32_t k, float lambda, uint32_t *order_out, float *mmr_out,
                        uint32_t *n_out);
 
+/* The same selection for a batch of queries in one set of launches: pools are P-strided
+ * (pool_rows / pool_scores / order_out / mmr_out are n_queries x P), pool_sizes[q] <= P <= 1024
+ * candidates are valid for query q.  One wavefront per query runs the greedy loop, all queries
+ * concurrently.  Per-query results are identical to rlr_mmr_select. */
+int32_t rlr_mmr_select_batch(rlr_index *idx, const uint64_t *pool_rows, const float *pool_scores,
+                             const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k,
+                             float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out);
+
 /* ---- device-resident variant (multi-GPU sharding) ------- */
 /* Same search, but the per-query result stays in device memory so the caller can hand it
  * to an RCCL all-gather without a host round trip.

@@ -82,6 +82,8 @@ PROTOTYPES = [
     ("rlr_score_rows", C.c_int32, [_H, f32p, u64p, C.c_uint32, f32p]),
     ("rlr_fetch_rows", C.c_int32, [_H, u64p, C.c_uint32, f32p]),
     ("rlr_mmr_select", C.c_int32, [_H, u64p, f32p, C.c_uint32, C.c_uint32, C.c_float, u32p, f32p, u32p]),
+    ("rlr_mmr_select_batch", C.c_int32, [_H, u64p, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, u32p, f32p,
+                                         u32p]),
     ("rlr_profile_enable", C.c_int32, [_H, C.c_int32]),
     ("rlr_profile_read", C.c_int32, [_H, C.POINTER(ProfileC), C.c_int32]),
     # rlr_engine.h
@@ -93,6 +95,9 @@ PROTOTYPES = [
     ("rlr_engine_search_with_diversity", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float,
                                                      C.POINTER(QueryWeightsC), u64p, f32p, C.c_uint32,
                                                      C.POINTER(SearchHitC), C.c_uint32, u32p]),
+    ("rlr_engine_search_with_diversity_batch", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
+                                                           C.POINTER(QueryWeightsC), C.POINTER(SearchHitC), C.c_uint32,
+                                                           u32p]),
     ("rlr_engine_embedding_candidates", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, u64p, f32p, u32p]),
 ]
 

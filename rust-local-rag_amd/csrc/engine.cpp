@@ -314,6 +314,112 @@ int32_t rlr_engine_search_with_diversity(rlr_index *idx, const float *query_raw,
     return RLR_OK;
 }
 
+int32_t rlr_engine_search_with_diversity_batch(rlr_index *idx, const float *queries_raw, uint32_t dq, uint32_t n_queries,
+                                               uint32_t top_k, float diversity_factor, const rlr_query_weights *weights,
+                                               rlr_search_hit *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!idx || !n_out || (n_queries && !queries_raw && dq) || (n_queries && cap && !out))
+        return RLR_E_INVALID;
+    for (uint32_t q = 0; q < n_queries; ++q)
+        n_out[q] = 0;
+    if (n_queries == 0)
+        return RLR_OK;
+    uint64_t N = 0;
+    uint32_t dim = 0;
+    int32_t st = rlr_index_info(idx, &N, &dim, nullptr, nullptr);
+    if (st != RLR_OK)
+        return st;
+    if (N == 0)
+        return RLR_OK;
+    if (diversity_factor < 0.0f) diversity_factor = 0.0f;
+    if (diversity_factor > 1.0f) diversity_factor = 1.0f;
+    rlr_resolved_weights w;
+    rlr_resolve_weights(weights, &w);
+    const bool plain = diversity_factor == 0.0f;
+    const uint32_t k_eff = std::max<uint32_t>(plain ? top_k : static_cast<uint32_t>(std::min<uint64_t>(
+                                                                  std::max<uint64_t>(static_cast<uint64_t>(top_k) * 3, static_cast<uint64_t>(top_k) + 10),
+                                                                  0xFFFFFFFFull)),
+                                              1u); // search() treats 0 as 1 (:490)
+    const uint64_t need = std::min<uint64_t>(N, k_eff);
+
+    auto single = [&](uint32_t q) -> int32_t { // reference path for one query of the batch
+        return rlr_engine_search_with_diversity(idx, queries_raw + static_cast<size_t>(q) * dq, dq, top_k, diversity_factor,
+                                                weights, nullptr, nullptr, 0, out + static_cast<size_t>(q) * cap, cap,
+                                                &n_out[q]);
+    };
+    if (w.embedding == 0.0f || need > 1024) { // degenerate weight / pool beyond the batched MMR: loop
+        for (uint32_t q = 0; q < n_queries; ++q)
+            if ((st = single(q)) != RLR_OK)
+                return st;
+        return RLR_OK;
+    }
+
+    std::vector<float> qn(static_cast<size_t>(n_queries) * dim);
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        const std::vector<float> v = prepare_query(queries_raw + static_cast<size_t>(q) * dq, dq, dim);
+        std::memcpy(qn.data() + static_cast<size_t>(q) * dim, v.data(), dim * sizeof(float));
+    }
+    const uint32_t fetch = static_cast<uint32_t>(std::min<uint64_t>(N, need + 8));
+    std::vector<uint64_t> rows(static_cast<size_t>(n_queries) * fetch);
+    std::vector<float> cosv(static_cast<size_t>(n_queries) * fetch);
+    std::vector<uint32_t> got(n_queries);
+    st = rlr_search_topk(idx, qn.data(), n_queries, fetch, -1.0f, rows.data(), cosv.data(), got.data());
+    if (st != RLR_OK)
+        return st;
+
+    const uint32_t P = static_cast<uint32_t>(need);
+    std::vector<std::vector<Cand>> pools(n_queries);
+    std::vector<uint32_t> redo;
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        std::vector<Cand> &c = pools[q];
+        c.reserve(got[q]);
+        for (uint32_t i = 0; i < got[q]; ++i) {
+            const float e = cosv[static_cast<size_t>(q) * fetch + i];
+            c.push_back({rows[static_cast<size_t>(q) * fetch + i], combine(w, e, 0.0f), e, 0.0f});
+        }
+        std::sort(c.begin(), c.end(), cand_before);
+        // same boundary rule as search_impl: a rounding tie that reaches the last fetched row
+        // cannot be resolved from this fetch -> that query takes the single-query path
+        if (got[q] < N && got[q] > 0) {
+            const float c_tail = combine(w, cosv[static_cast<size_t>(q) * fetch + got[q] - 1], 0.0f);
+            if (!(c.size() >= need && (std::isnan(c_tail) || c[need - 1].c > c_tail)))
+                redo.push_back(q);
+        }
+        if (c.size() > need)
+            c.resize(need);
+    }
+    if (plain) {
+        for (uint32_t q = 0; q < n_queries; ++q)
+            emit(pools[q], out + static_cast<size_t>(q) * cap, cap, &n_out[q]);
+    } else {
+        std::vector<uint64_t> prow(static_cast<size_t>(n_queries) * P, 0);
+        std::vector<float> psc(static_cast<size_t>(n_queries) * P, 0.0f);
+        std::vector<uint32_t> psz(n_queries), order(static_cast<size_t>(n_queries) * P), nsel(n_queries);
+        for (uint32_t q = 0; q < n_queries; ++q) {
+            psz[q] = static_cast<uint32_t>(pools[q].size());
+            for (uint32_t i = 0; i < psz[q]; ++i) {
+                prow[static_cast<size_t>(q) * P + i] = pools[q][i].row;
+                psc[static_cast<size_t>(q) * P + i] = pools[q][i].c;
+            }
+        }
+        st = rlr_mmr_select_batch(idx, prow.data(), psc.data(), psz.data(), n_queries, P, top_k, diversity_factor,
+                                  order.data(), nullptr, nsel.data());
+        if (st != RLR_OK)
+            return st;
+        std::vector<Cand> picked;
+        for (uint32_t q = 0; q < n_queries; ++q) {
+            picked.clear();
+            for (uint32_t i = 0; i < nsel[q]; ++i)
+                picked.push_back(pools[q][order[static_cast<size_t>(q) * P + i]]);
+            emit(picked, out + static_cast<size_t>(q) * cap, cap, &n_out[q]);
+        }
+    }
+    for (uint32_t q : redo)
+        if ((st = single(q)) != RLR_OK)
+            return st;
+    return RLR_OK;
+}
+
 int32_t rlr_engine_embedding_candidates(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_t count,
                                         uint64_t *rows_out, float *scores_out, uint32_t *n_out)
 {

@@ -367,6 +367,9 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const float4 *__restr
 __global__ __launch_bounds__(64) void gram_kernel(const float *__restrict__ pool, uint32_t P, uint32_t dim,
                                                   float *__restrict__ gram)
 {
+    // blockIdx.z = query of a batch (pool and gram are P-strided per query)
+    pool += static_cast<size_t>(blockIdx.z) * P * dim;
+    gram += static_cast<size_t>(blockIdx.z) * P * P;
     const uint32_t i = blockIdx.y;
     const uint32_t j = blockIdx.x * 64 + threadIdx.x;
     if (j > i || i >= P)
@@ -508,15 +511,33 @@ template <int J>
 __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__restrict__ gram,
                                                              const float *__restrict__ scores, uint32_t P, uint32_t k,
                                                              float lambda, uint32_t *__restrict__ out_order,
-                                                             float *__restrict__ out_mmr, uint32_t *__restrict__ out_n)
+                                                             float *__restrict__ out_mmr, uint32_t *__restrict__ out_n,
+                                                             const uint32_t *__restrict__ sizes)
 {
+    // batch: blockIdx.x = query; arrays are strided by the launch-wide P, the pool size is sizes[q]
+    {
+        const uint32_t stride = P;
+        gram += static_cast<size_t>(blockIdx.x) * stride * stride;
+        scores += static_cast<size_t>(blockIdx.x) * stride;
+        out_order += static_cast<size_t>(blockIdx.x) * stride;
+        out_mmr += static_cast<size_t>(blockIdx.x) * stride;
+        out_n += blockIdx.x;
+    }
+    const uint32_t g_stride = P;
+    if (sizes)
+        P = sizes[blockIdx.x];
+    if (P == 0) {
+        if (threadIdx.x == 0)
+            *out_n = 0;
+        return;
+    }
     // The Gram matrix was just written by other CUs (possibly other XCDs): its first touch from
     // this CU is an Infinity-Cache/HBM miss (~0.4 us), and every pick reads a different row, so
     // the greedy chain would pay that miss 99 times.  All four waves first sweep the matrix
     // (P*P*4 bytes, 360 KB at P = 300) into this XCD's L2; the chain's loads then hit L2.
     {
         const float4 *g4 = reinterpret_cast<const float4 *>(gram);
-        const uint32_t n4 = (P * P) / 4;
+        const uint32_t n4 = (P * g_stride) / 4;
         float warm = 0.0f;
         for (uint32_t i = threadIdx.x * 8; i < n4; i += 256 * 8) // one 128-B line per thread and step
             warm += g4[i].x;
@@ -554,7 +575,7 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
     const float one_minus = 1.0f - lambda;
     const float neg_inf = -__builtin_inff();
     while (n_sel < k && n_rem > 0) {
-        const float *g_last = gram + static_cast<size_t>(last) * P;
+        const float *g_last = gram + static_cast<size_t>(last) * g_stride;
         float sim[J];
 #pragma unroll
         for (int j = 0; j < J; ++j)
@@ -747,24 +768,28 @@ hipError_t launch_compact_rows(const void *src, void *dst, uint32_t pitch16, con
     return hipGetLastError();
 }
 
-hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram, hipStream_t s)
+hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram, uint32_t n_queries, hipStream_t s)
 {
-    if (P == 0)
+    if (P == 0 || n_queries == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(gram_kernel, dim3((P + 63) / 64, P), dim3(64), 0, s, pool, P, dim, gram);
+    hipLaunchKernelGGL(gram_kernel, dim3((P + 63) / 64, P, n_queries), dim3(64), 0, s, pool, P, dim, gram);
     return hipGetLastError();
 }
 
+// n_queries > 1 (or sizes != null): per-query arrays strided by P, pool sizes in sizes[q] (<= P <= 1024)
 hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P, uint32_t k, float lambda,
-                             uint32_t *out_order, float *out_mmr, uint32_t *out_n, hipStream_t s)
+                             uint32_t *out_order, float *out_mmr, uint32_t *out_n, const uint32_t *sizes,
+                             uint32_t n_queries, hipStream_t s)
 {
     const size_t lds = static_cast<size_t>(P ? P : 1) * 12;
-#define RLR_MMR_REG(JV)                                                                                         \
-    hipLaunchKernelGGL(mmr_greedy_reg_kernel<JV>, dim3(1), dim3(256), 0, s, gram, scores, P, k, lambda, out_order, \
-                       out_mmr, out_n)
-    if (P == 0)
+#define RLR_MMR_REG(JV)                                                                                          \
+    hipLaunchKernelGGL(mmr_greedy_reg_kernel<JV>, dim3(n_queries), dim3(256), 0, s, gram, scores, P, k, lambda,   \
+                       out_order, out_mmr, out_n, sizes)
+    if (P == 0 || (P > 1024 && n_queries == 1 && !sizes))
         hipLaunchKernelGGL(mmr_greedy_kernel, dim3(1), dim3(64), lds, s, gram, scores, P, k, lambda, out_order, out_mmr,
                            out_n);
+    else if (P > 1024)
+        return hipErrorInvalidValue;
     else if (P <= 64)
         RLR_MMR_REG(1);
     else if (P <= 128)
@@ -773,11 +798,8 @@ hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P,
         RLR_MMR_REG(5);
     else if (P <= 512)
         RLR_MMR_REG(8);
-    else if (P <= 1024)
-        RLR_MMR_REG(16);
     else
-        hipLaunchKernelGGL(mmr_greedy_kernel, dim3(1), dim3(64), lds, s, gram, scores, P, k, lambda, out_order, out_mmr,
-                           out_n);
+        RLR_MMR_REG(16);
 #undef RLR_MMR_REG
     return hipGetLastError();
 }

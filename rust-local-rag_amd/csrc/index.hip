@@ -1263,8 +1263,8 @@ int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *po
     uint32_t *d_n = reinterpret_cast<uint32_t *>(d_sc + 3ull * P);
     RLR_HIP(hipMemcpyAsync(d_sc, pool_scores, static_cast<size_t>(P) * sizeof(float), hipMemcpyHostToDevice, s));
     RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_pool, s));
-    RLR_HIP(launch_gram(d_pool, P, ix->dim, d_gram, s));
-    RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, s));
+    RLR_HIP(launch_gram(d_pool, P, ix->dim, d_gram, 1, s));
+    RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, nullptr, 1, s));
     // one D2H: order | mmr | n are contiguous
     RLR_TRY(pin_reserve(c, (2ull * P + 4) * 4));
     RLR_HIP(hipMemcpyAsync(c->h_pin, d_order, (2ull * P + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -1278,6 +1278,85 @@ int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *po
             mmr_out[i] = h_mmr[i];
     }
     *n_out = n_sel;
+    return RLR_OK;
+}
+
+int32_t rlr_mmr_select_batch(rlr_index *ix, const uint64_t *pool_rows, const float *pool_scores,
+                             const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k, float lambda,
+                             uint32_t *order_out, float *mmr_out, uint32_t *n_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (n_queries == 0)
+        return RLR_OK;
+    if (!pool_rows || !pool_scores || !pool_sizes || !order_out || !n_out)
+        return fail(RLR_E_INVALID, "null argument");
+    if (P == 0) {
+        for (uint32_t q = 0; q < n_queries; ++q)
+            n_out[q] = 0;
+        return RLR_OK;
+    }
+    if (P > 1024)
+        return fail(RLR_E_INVALID, "batched MMR supports pools of at most 1024 candidates (got %u)", P);
+    RLR_TRY(use_device(ix));
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    hipStream_t s = c->stream;
+    const uint32_t QC = 64; // queries per pass: pool 64 x P x dim f32 + gram 64 x P x P
+    std::vector<uint64_t> rows_chunk;
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += QC) {
+        const uint32_t m = std::min(QC, n_queries - q0);
+        const uint32_t n_list = m * P;
+        // unused slots (j >= pool_sizes[q]) gather row 0: never read by the greedy kernel
+        rows_chunk.assign(n_list, 0);
+        for (uint32_t q = 0; q < m; ++q) {
+            const uint32_t pq = pool_sizes[q0 + q];
+            if (pq > P)
+                return fail(RLR_E_INVALID, "pool_sizes[%u] = %u exceeds P = %u", q0 + q, pq, P);
+            std::memcpy(rows_chunk.data() + static_cast<size_t>(q) * P, pool_rows + static_cast<size_t>(q0 + q) * P,
+                        pq * sizeof(uint64_t));
+        }
+        // pinned staging layout: [row list (upload_list)] [scores] [sizes] [results]; reserve it all
+        // BEFORE upload_list enqueues its copy so the buffer is never reallocated under a transfer
+        const size_t list_bytes = static_cast<size_t>(n_list) * 8 + 64;
+        const size_t in_bytes = static_cast<size_t>(n_list) * 4 + static_cast<size_t>(m + 4) * 4;
+        const size_t out_bytes = (2ull * n_list + m) * 4;
+        RLR_TRY(pin_reserve(c, list_bytes + in_bytes + out_bytes + 64));
+        RLR_TRY(upload_list(ix, c, rows_chunk.data(), n_list));
+        const uint64_t floats = static_cast<uint64_t>(n_list) * ix->dim + static_cast<uint64_t>(m) * P * P + 3ull * n_list +
+                                2ull * m + 8;
+        RLR_TRY(grow(&c->d_pool, &c->pool_cap, floats));
+        float *d_pool = c->d_pool;
+        float *d_gram = d_pool + static_cast<uint64_t>(n_list) * ix->dim;
+        float *d_sc = d_gram + static_cast<uint64_t>(m) * P * P;
+        uint32_t *d_order = reinterpret_cast<uint32_t *>(d_sc + n_list);
+        float *d_mmr = d_sc + 2ull * n_list;
+        uint32_t *d_n = reinterpret_cast<uint32_t *>(d_sc + 3ull * n_list);
+        uint32_t *d_sizes = d_n + m;
+        char *h_base = static_cast<char *>(c->h_pin) + list_bytes;
+        float *h_sc = reinterpret_cast<float *>(h_base);
+        uint32_t *h_sizes = reinterpret_cast<uint32_t *>(h_sc + n_list);
+        std::memcpy(h_sc, pool_scores + static_cast<size_t>(q0) * P, static_cast<size_t>(n_list) * sizeof(float));
+        std::memcpy(h_sizes, pool_sizes + q0, m * sizeof(uint32_t));
+        RLR_HIP(hipMemcpyAsync(d_sc, h_sc, static_cast<size_t>(n_list) * sizeof(float), hipMemcpyHostToDevice, s));
+        RLR_HIP(hipMemcpyAsync(d_sizes, h_sizes, m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, n_list, d_pool, s));
+        RLR_HIP(launch_gram(d_pool, P, ix->dim, d_gram, m, s));
+        RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, d_sizes, m, s));
+        // results: order | mmr | n are contiguous
+        uint32_t *h_res = reinterpret_cast<uint32_t *>(h_sizes + m + 4);
+        RLR_HIP(hipMemcpyAsync(h_res, d_order, (2ull * n_list + m) * 4, hipMemcpyDeviceToHost, s));
+        RLR_HIP(hipStreamSynchronize(s));
+        const float *h_mmr = reinterpret_cast<const float *>(h_res + n_list);
+        const uint32_t *h_n = h_res + 2ull * n_list;
+        for (uint32_t q = 0; q < m; ++q) {
+            const uint32_t ns = h_n[q];
+            n_out[q0 + q] = ns;
+            std::memcpy(order_out + static_cast<size_t>(q0 + q) * P, h_res + static_cast<size_t>(q) * P, ns * sizeof(uint32_t));
+            if (mmr_out)
+                std::memcpy(mmr_out + static_cast<size_t>(q0 + q) * P, h_mmr + static_cast<size_t>(q) * P, ns * sizeof(float));
+        }
+    }
     return RLR_OK;
 }
 

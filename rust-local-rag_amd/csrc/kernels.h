@@ -102,10 +102,10 @@ hipError_t launch_gather_f32(const void *rows, uint32_t pitch16, uint32_t dim, i
 hipError_t launch_compact_rows(const void *src, void *dst, uint32_t pitch16, const uint32_t *keep,
                                uint32_t n_keep, hipStream_t s);
 // gram[i*P + j] = dot_ref(pool[i], pool[j]) over a dense f32 P x dim pool.
-hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram, hipStream_t s);
+hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram, uint32_t n_queries, hipStream_t s);
 // greedy MMR over the gram matrix; out_order/out_mmr/out_n on the device.
 hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P, uint32_t k,
                              float lambda, uint32_t *out_order, float *out_mmr, uint32_t *out_n,
-                             hipStream_t s);
+                             const uint32_t *sizes, uint32_t n_queries, hipStream_t s);
 
 } // namespace rlr

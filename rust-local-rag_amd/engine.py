@@ -206,6 +206,26 @@ class RagEngine:
             hits, cap, C.byref(n)))
         return self._results(hits, n.value)
 
+    # -- additive batched entry point (oracle: loop search_with_diversity over the batch) -------
+    def search_with_diversity_batch(self, query_embeddings, top_k: int, diversity_factor: float,
+                                    weights: Optional[QueryWeights] = None) -> List[List[SearchResult]]:
+        q = _f32(query_embeddings)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        nq, dq = q.shape
+        cap = max(3 * max(top_k, 1), top_k + 10)
+        hits = (N.SearchHitC * (cap * max(nq, 1)))()
+        n_out = np.zeros(max(nq, 1), dtype=np.uint32)
+        wc = weights.to_c() if weights is not None else None
+        N.check(N.lib().rlr_engine_search_with_diversity_batch(
+            self.index.handle, q.ctypes.data_as(N.f32p), dq, nq, top_k, float(diversity_factor),
+            C.byref(wc) if wc is not None else None, hits, cap, n_out.ctypes.data_as(N.u32p)))
+        out = []
+        for i in range(nq):
+            view = (N.SearchHitC * cap).from_buffer(hits, i * cap * C.sizeof(N.SearchHitC))
+            out.append(self._results(view, int(n_out[i])))
+        return out
+
     # -- RagEngine::get_embedding_candidates (rag_engine.rs:415-461) -----------------------
     def get_embedding_candidates(self, query_embedding, count: int) -> List[Tuple[str, float]]:
         q = _f32(query_embedding).ravel()

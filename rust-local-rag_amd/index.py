@@ -150,6 +150,19 @@ class GpuIndex:
                                        order.ctypes.data_as(N.u32p), _fp(mmr), C.byref(n)))
         return order[: n.value], mmr[: n.value]
 
+    def mmr_select_batch(self, pool_rows, pool_scores, pool_sizes, k: int, lam: float):
+        """pool_rows/pool_scores: [Q, P]; pool_sizes: [Q] -> (order u32 [Q, P], mmr f32 [Q, P], n u32 [Q])"""
+        pool_rows = _u64(pool_rows)
+        pool_scores = _f32(pool_scores)
+        nq, P = pool_rows.shape
+        sizes = np.ascontiguousarray(pool_sizes, dtype=np.uint32)
+        order = np.zeros((nq, max(P, 1)), dtype=np.uint32)
+        mmr = np.zeros((nq, max(P, 1)), dtype=np.float32)
+        n = np.zeros(max(nq, 1), dtype=np.uint32)
+        N.check(self._L.rlr_mmr_select_batch(self._h, _up(pool_rows), _fp(pool_scores), sizes.ctypes.data_as(N.u32p), nq, P,
+                                             k, lam, order.ctypes.data_as(N.u32p), _fp(mmr), n.ctypes.data_as(N.u32p)))
+        return order, mmr, n[:nq]
+
     # -- measurement ---------------------------------------------------------
     def profile_enable(self, on: bool = True) -> None:
         N.check(self._L.rlr_profile_enable(self._h, int(on)))

@@ -422,3 +422,45 @@ def test_merge_topk_kernel_matches_torch_merge_and_global_oracle(rlr, oracle):
         wr, wc = oracle_topk(oracle, rows, qs[i], k)
         assert np.array_equal(out_rows[i], wr) and np.array_equal(bits(out_cos[i]), bits(wc))
     assert list(out_rows[0][:2]) == [11, lo1 + 7]  # the tie: lower global row first
+
+
+# ---------------------------------------------------------------- batched MMR / batched engine
+def test_mmr_select_batch_equals_single_calls(rlr, oracle):
+    rows = oracle.synth_rows(6000, 768, seed=411, n_clusters=20)
+    ix = make_index(rlr, rows)
+    nq, P, k, lam = 70, 300, 100, 0.3   # 70 queries -> two passes of the 64-query chunking
+    qs = np.stack([oracle.normalize(oracle.synth_query(768, seed=1000 + i)) for i in range(nq)])
+    pr, pc = ix.search_topk(qs, P)
+    sc = (np.float32(0.7) * pc).astype(np.float32)
+    sizes = np.full(nq, P, np.uint32)
+    sizes[3] = 17           # ragged pools
+    sizes[5] = 1
+    sizes[9] = 0
+    order, mmr, n = ix.mmr_select_batch(pr, sc, sizes, k, lam)
+    for q in range(nq):
+        o1, m1 = ix.mmr_select(pr[q][:sizes[q]], sc[q][:sizes[q]], k, lam)
+        assert n[q] == len(o1), q
+        assert np.array_equal(order[q][:n[q]], o1), q
+        assert np.array_equal(bits(mmr[q][1:n[q]]), bits(m1[1:]))
+    # and one of them against the oracle
+    wo, _ = oracle.mmr(rows[pr[0].astype(np.int64)], sc[0], k, lam)
+    assert np.array_equal(order[0][:n[0]], wo)
+    ix.close()
+
+
+@pytest.mark.parametrize("nq,k,lam", [(20, 10, 0.5), (18, 100, 0.7), (5, 5, 0.0)])
+def test_engine_search_with_diversity_batch_matches_oracle(rlr, oracle, nq, k, lam):
+    n, dim = 12000, 768
+    eng = rlr.RagEngine(dim)
+    eng.index.fill_synthetic(n, seed=421, n_clusters=30)
+    eng._chunks = [rlr.DocumentChunk(str(i), "synthetic", "", i) for i in range(n)]
+    rows = oracle.synth_rows(n, dim, seed=421, n_clusters=30)
+    qs = np.stack([oracle.synth_query(dim, seed=1100 + i) for i in range(nq)])
+    got = eng.search_with_diversity_batch(qs, k, lam)
+    assert len(got) == nq
+    for q in range(nq):
+        wr, wc, we, _ = oracle.search_with_diversity(rows, qs[q], k, lam)
+        assert [g.row for g in got[q]] == list(wr), q
+        assert np.array_equal(bits([g.score for g in got[q]]), bits(wc))
+        assert np.array_equal(bits([g.embedding_score for g in got[q]]), bits(we))
+    eng.close()
