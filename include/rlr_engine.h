@@ -93,6 +93,22 @@ int32_t rlr_engine_search_with_diversity_batch(rlr_index *idx, const float *quer
                                                const rlr_query_weights *weights, rlr_search_hit *out,
                                                uint32_t cap, uint32_t *n_out);
 
+/* The tail of RagEngine::search once a reranker has answered (:599-700), SURVEY 8(f) row f2:
+ * blended = w_reranker * relevance/max_relevance + w_initial * initial/max_initial over the
+ * stage-1 candidates the reranker scored (in the reranker's order, unknown/repeated rows
+ * skipped), stable sort desc, truncate to top_k, then fill from the remaining candidates by
+ * initial score.  Pure host arithmetic on <= 3*top_k items.
+ *   candidates / n_candidates   output of rlr_engine_search(stage = 1)
+ *   rer_rows / rer_relevance    the reranker's (row, relevance) list; n_reranked == 0 = reranker
+ *                               absent or failed -> pure fallback ordering
+ *   out / has_reranker_out / reranker_score_out   final results (score = blended or initial),
+ *                               per-result flag and raw relevance (SearchResult.reranker_score) */
+int32_t rlr_engine_blend_reranked(const rlr_search_hit *candidates, uint32_t n_candidates,
+                                  const uint64_t *rer_rows, const float *rer_relevance, uint32_t n_reranked,
+                                  uint32_t top_k, const rlr_query_weights *weights, rlr_search_hit *out,
+                                  float *reranker_score_out, int32_t *has_reranker_out, uint32_t cap,
+                                  uint32_t *n_out);
+
 /* RagEngine::get_embedding_candidates (:415-461), `None` arm: top `count` by cosine. */
 int32_t rlr_engine_embedding_candidates(rlr_index *idx, const float *query_raw, uint32_t dq,
                                         uint32_t count, uint64_t *rows_out, float *scores_out,

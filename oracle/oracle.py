@@ -56,6 +56,9 @@ def lib() -> C.CDLL:
         L.rlr_o_embedding_candidates.restype = C.c_size_t
         L.rlr_o_mmr.argtypes = [_f32p, _f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, _u32p, _f32p]
         L.rlr_o_mmr.restype = C.c_size_t
+        L.rlr_o_blend.argtypes = [_u64p, _f32p, C.c_size_t, _u64p, _f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
+                                  _u32p, _f32p, _f32p, C.POINTER(C.c_int32)]
+        L.rlr_o_blend.restype = C.c_size_t
         L.rlr_o_search_with_diversity.argtypes = [
             _f32p, C.c_size_t, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_float,
             C.c_float, _u64p, _f32p, C.c_size_t, C.c_int, _u64p, _f32p, _f32p, _f32p, C.c_size_t]
@@ -159,6 +162,21 @@ def mmr(emb, scores, top_k, lam):
     mm = np.zeros(max(P, 1), dtype=np.float32)
     k = lib().rlr_o_mmr(_p(emb), _p(scores), P, d, top_k, lam, order.ctypes.data_as(_u32p), _p(mm))
     return order[:k], mm[:k]
+
+
+def blend(cand_rows, cand_initial, rer_rows, rer_relevance, top_k, w_reranker=0.7, w_initial=0.3):
+    """-> (candidate index u32[k], score f32[k], reranker score f32[k], has_reranker bool[k])"""
+    cr = np.ascontiguousarray(cand_rows, dtype=np.uint64)
+    ci = _f32(cand_initial)
+    rr = np.ascontiguousarray(rer_rows if len(rer_rows) else [0], dtype=np.uint64)
+    rl = _f32(rer_relevance if len(rer_relevance) else [0])
+    cap = len(cr) + 1
+    oc = np.zeros(cap, np.uint32); os_ = np.zeros(cap, np.float32); orr = np.zeros(cap, np.float32)
+    oh = np.zeros(cap, np.int32)
+    k = lib().rlr_o_blend(cr.ctypes.data_as(_u64p), _p(ci), len(cr), rr.ctypes.data_as(_u64p), _p(rl),
+                          len(rer_rows), top_k, w_reranker, w_initial, oc.ctypes.data_as(_u32p), _p(os_), _p(orr),
+                          oh.ctypes.data_as(C.POINTER(C.c_int32)))
+    return oc[:k], os_[:k], orr[:k], oh[:k].astype(bool)
 
 
 def search_with_diversity(rows, q_raw, top_k, diversity, w_e=0.7, w_l=0.3, lex=None,

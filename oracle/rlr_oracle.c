@@ -313,6 +313,99 @@ RLR_O_API size_t rlr_o_embedding_candidates(const float *rows, size_t n, size_t 
 }
 
 /* ------------------------------------------------------------------------ */
+/* f2  reranker blend + result assembly   src/rag_engine.rs:599-700           */
+/* cand_*: the initial_k stage-1 candidates in the order `search` produced    */
+/*         them (row, initial_score).  rer_*: the reranker's output in its    */
+/*         order (row, relevance); rows not among the candidates or repeated  */
+/*         are skipped (:617-618).  Output: final order, score, and whether a */
+/*         reranker score is attached (0 for fallback-filled results).        */
+/* Tie rule for the fallback sort over `candidate_map.values()` (HashMap      */
+/* order in the reference): candidate order.                                  */
+/* ------------------------------------------------------------------------ */
+struct blended {
+    float score;
+    size_t cand;  /* index into the candidate list */
+    float rer;
+    int has_rer;
+};
+
+static void stable_sort_blended(struct blended *v, struct blended *tmp, size_t n)
+{
+    if (n < 2)
+        return;
+    size_t h = n / 2;
+    stable_sort_blended(v, tmp, h);
+    stable_sort_blended(v + h, tmp, n - h);
+    size_t i = 0, j = h, k = 0;
+    while (i < h && j < n) {
+        /* b.score.partial_cmp(&a.score).unwrap_or(Equal): NaN ties with everything */
+        int right_first = (v[j].score > v[i].score) && !isnan(v[j].score) && !isnan(v[i].score);
+        if (right_first)
+            tmp[k++] = v[j++];
+        else
+            tmp[k++] = v[i++];
+    }
+    while (i < h) tmp[k++] = v[i++];
+    while (j < n) tmp[k++] = v[j++];
+    memcpy(v, tmp, n * sizeof(*v));
+}
+
+RLR_O_API size_t rlr_o_blend(const uint64_t *cand_rows, const float *cand_initial, size_t n_cand,
+                             const uint64_t *rer_rows, const float *rer_relevance, size_t n_rer,
+                             size_t top_k, float w_reranker, float w_initial, uint32_t *out_cand,
+                             float *out_score, float *out_rer, int32_t *out_has_rer)
+{
+    struct blended *res = (struct blended *)malloc(sizeof(struct blended) * (n_cand + n_rer + 1));
+    struct blended *tmp = (struct blended *)malloc(sizeof(struct blended) * (n_cand + n_rer + 1));
+    unsigned char *seen = (unsigned char *)calloc(n_cand + 1, 1);
+    size_t n_res = 0;
+    if (n_rer > 0) { /* :602 */
+        float max_rer = 0.0f, max_init = 0.0f;
+        for (size_t i = 0; i < n_rer; ++i) max_rer = fmaxf(max_rer, rer_relevance[i]);
+        if (!(max_rer >= 1.1920929e-07f)) max_rer = 1.1920929e-07f;
+        for (size_t i = 0; i < n_cand; ++i) max_init = fmaxf(max_init, cand_initial[i]);
+        if (!(max_init >= 1.1920929e-07f)) max_init = 1.1920929e-07f;
+        for (size_t i = 0; i < n_rer; ++i) { /* :616-654 */
+            size_t c = n_cand;
+            for (size_t j = 0; j < n_cand; ++j)
+                if (cand_rows[j] == rer_rows[i]) { c = j; break; }
+            if (c == n_cand || seen[c])
+                continue;
+            seen[c] = 1;
+            float rn = rer_relevance[i] / max_rer;
+            float in = cand_initial[c] / max_init;
+            float t0 = w_reranker * rn;
+            float t1 = w_initial * in;
+            res[n_res++] = (struct blended){t0 + t1, c, rer_relevance[i], 1};
+        }
+        stable_sort_blended(res, tmp, n_res); /* :657-661 */
+        if (n_res > top_k) n_res = top_k;     /* :664 */
+    }
+    if (n_res < top_k) { /* :667-698 fallback fill by initial score */
+        struct blended *fb = (struct blended *)malloc(sizeof(struct blended) * (n_cand + 1));
+        for (size_t j = 0; j < n_cand; ++j)
+            fb[j] = (struct blended){cand_initial[j], j, 0.0f, 0};
+        stable_sort_blended(fb, tmp, n_cand);
+        for (size_t j = 0; j < n_cand && n_res < top_k; ++j)
+            if (!seen[fb[j].cand]) {
+                seen[fb[j].cand] = 1;
+                res[n_res++] = fb[j];
+            }
+        free(fb);
+    }
+    for (size_t i = 0; i < n_res; ++i) {
+        out_cand[i] = (uint32_t)res[i].cand;
+        out_score[i] = res[i].score;
+        out_rer[i] = res[i].rer;
+        out_has_rer[i] = res[i].has_rer;
+    }
+    free(res);
+    free(tmp);
+    free(seen);
+    return n_res;
+}
+
+/* ------------------------------------------------------------------------ */
 /* a8  mmr_diversify        src/rag_engine.rs:767-839 (test twin :2824-2875)  */
 /* emb: P x d row-major candidate embeddings in candidate order;              */
 /* score: P relevance scores (the combined score of each result).             */

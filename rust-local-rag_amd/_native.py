@@ -98,6 +98,9 @@ PROTOTYPES = [
     ("rlr_engine_search_with_diversity_batch", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
                                                            C.POINTER(QueryWeightsC), C.POINTER(SearchHitC), C.c_uint32,
                                                            u32p]),
+    ("rlr_engine_blend_reranked", C.c_int32, [C.POINTER(SearchHitC), C.c_uint32, u64p, f32p, C.c_uint32, C.c_uint32,
+                                              C.POINTER(QueryWeightsC), C.POINTER(SearchHitC), f32p, i32p, C.c_uint32,
+                                              u32p]),
     ("rlr_engine_embedding_candidates", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, u64p, f32p, u32p]),
 ]
 

@@ -420,6 +420,78 @@ int32_t rlr_engine_search_with_diversity_batch(rlr_index *idx, const float *quer
     return RLR_OK;
 }
 
+int32_t rlr_engine_blend_reranked(const rlr_search_hit *candidates, uint32_t n_candidates, const uint64_t *rer_rows,
+                                  const float *rer_relevance, uint32_t n_reranked, uint32_t top_k,
+                                  const rlr_query_weights *weights, rlr_search_hit *out, float *reranker_score_out,
+                                  int32_t *has_reranker_out, uint32_t cap, uint32_t *n_out)
+{
+    if (!n_out || (n_candidates && !candidates) || (n_reranked && (!rer_rows || !rer_relevance)))
+        return RLR_E_INVALID;
+    *n_out = 0;
+    rlr_resolved_weights w;
+    rlr_resolve_weights(weights, &w);
+    struct Item {
+        float score;
+        uint32_t cand;
+        float rer;
+        int32_t has;
+    };
+    // `b.score.partial_cmp(&a.score).unwrap_or(Equal)` under a stable sort: NaN ties with everything
+    auto before = [](const Item &a, const Item &b) { return a.score > b.score; };
+    std::vector<Item> res;
+    std::vector<char> seen(n_candidates, 0);
+    if (n_reranked > 0) { // :602
+        float max_rer = 0.0f, max_init = 0.0f;
+        for (uint32_t i = 0; i < n_reranked; ++i) max_rer = std::fmax(max_rer, rer_relevance[i]);
+        if (!(max_rer >= 1.1920929e-07f)) max_rer = 1.1920929e-07f;
+        for (uint32_t i = 0; i < n_candidates; ++i) max_init = std::fmax(max_init, candidates[i].initial_score);
+        if (!(max_init >= 1.1920929e-07f)) max_init = 1.1920929e-07f;
+        std::unordered_map<uint64_t, uint32_t> where;
+        for (uint32_t i = n_candidates; i-- > 0;)
+            where[candidates[i].row] = i; // first occurrence wins
+        for (uint32_t i = 0; i < n_reranked; ++i) { // :616-654
+            auto it = where.find(rer_rows[i]);
+            if (it == where.end() || seen[it->second])
+                continue;
+            seen[it->second] = 1;
+            const float rn = rer_relevance[i] / max_rer;
+            const float in = candidates[it->second].initial_score / max_init;
+            const float t0 = w.reranker * rn;
+            const float t1 = w.initial * in;
+            res.push_back({t0 + t1, it->second, rer_relevance[i], 1});
+        }
+        std::stable_sort(res.begin(), res.end(), before); // :657-661
+        if (res.size() > top_k)
+            res.resize(top_k); // :664
+    }
+    if (res.size() < top_k) { // :667-698
+        std::vector<Item> fb;
+        fb.reserve(n_candidates);
+        for (uint32_t i = 0; i < n_candidates; ++i)
+            fb.push_back({candidates[i].initial_score, i, 0.0f, 0});
+        std::stable_sort(fb.begin(), fb.end(), before);
+        for (const Item &f : fb) {
+            if (res.size() >= top_k)
+                break;
+            if (!seen[f.cand]) {
+                seen[f.cand] = 1;
+                res.push_back(f);
+            }
+        }
+    }
+    const uint32_t n = static_cast<uint32_t>(std::min<size_t>(res.size(), cap));
+    if (n && (!out || !reranker_score_out || !has_reranker_out))
+        return RLR_E_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        out[i] = candidates[res[i].cand];
+        out[i].score = res[i].score;
+        reranker_score_out[i] = res[i].rer;
+        has_reranker_out[i] = res[i].has;
+    }
+    *n_out = n;
+    return RLR_OK;
+}
+
 int32_t rlr_engine_embedding_candidates(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_t count,
                                         uint64_t *rows_out, float *scores_out, uint32_t *n_out)
 {

@@ -206,6 +206,34 @@ class RagEngine:
             hits, cap, C.byref(n)))
         return self._results(hits, n.value)
 
+    # -- tail of RagEngine::search when a reranker answered (rag_engine.rs:599-700) --------------
+    def finish_with_reranker(self, candidates: Sequence[SearchResult], reranked: Sequence[Tuple[str, float]],
+                             top_k: int, weights: Optional[QueryWeights] = None) -> List[SearchResult]:
+        """candidates: `search(..., stage=1)`; reranked: the reranker's (chunk_id, relevance) list in its
+        order (empty = reranker absent/failed -> fallback ordering by initial score)."""
+        n = len(candidates)
+        cand = (N.SearchHitC * max(n, 1))()
+        for i, r in enumerate(candidates):
+            cand[i].row, cand[i].score, cand[i].embedding_score = r.row, r.score, r.embedding_score or 0.0
+            cand[i].lexical_score, cand[i].initial_score = r.lexical_score or 0.0, r.initial_score or 0.0
+        known = [(self._row_of[c], s) for c, s in reranked if c in self._row_of]
+        rr = np.ascontiguousarray([r for r, _ in known] or [0], dtype=np.uint64)
+        rs = np.ascontiguousarray([s for _, s in known] or [0], dtype=np.float32)
+        top_k = max(top_k, 1)
+        out = (N.SearchHitC * max(n, 1))()
+        rer = np.zeros(max(n, 1), np.float32)
+        has = np.zeros(max(n, 1), np.int32)
+        n_out = C.c_uint32()
+        wc = weights.to_c() if weights is not None else None
+        N.check(N.lib().rlr_engine_blend_reranked(cand, n, rr.ctypes.data_as(N.u64p), rs.ctypes.data_as(N.f32p), len(known),
+                                                  top_k, C.byref(wc) if wc is not None else None, out,
+                                                  rer.ctypes.data_as(N.f32p), has.ctypes.data_as(N.i32p), max(n, 1),
+                                                  C.byref(n_out)))
+        res = self._results(out, n_out.value)
+        for i, r in enumerate(res):
+            r.reranker_score = float(rer[i]) if has[i] else None
+        return res
+
     # -- additive batched entry point (oracle: loop search_with_diversity over the batch) -------
     def search_with_diversity_batch(self, query_embeddings, top_k: int, diversity_factor: float,
                                     weights: Optional[QueryWeights] = None) -> List[List[SearchResult]]:

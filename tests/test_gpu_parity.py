@@ -464,3 +464,24 @@ def test_engine_search_with_diversity_batch_matches_oracle(rlr, oracle, nq, k, l
         assert np.array_equal(bits([g.score for g in got[q]]), bits(wc))
         assert np.array_equal(bits([g.embedding_score for g in got[q]]), bits(we))
     eng.close()
+
+
+def test_search_stage1_then_reranker_blend(rlr, oracle):
+    """stage-1 candidates from the GPU + the host-side blend of rag_engine.rs:599-700 (row f2)."""
+    rows = oracle.synth_rows(4000, 768, seed=501)
+    eng, ids = build_engine(rlr, rows)
+    stored = eng.index.fetch_rows(np.arange(4000))
+    q = oracle.synth_query(768, seed=502)
+    cands = eng.search(q, 5, stage=1)                        # 15 candidates for the reranker
+    wr, wc, _, _ = oracle.search(stored, q, 5, stage=1)
+    assert [c.row for c in cands] == list(wr)
+    rng = np.random.default_rng(1)
+    pick = rng.permutation(15)[:9]
+    rel = rng.random(9).astype(np.float32)
+    reranked = [(cands[i].chunk_id, float(rel[j])) for j, i in enumerate(pick)]
+    got = eng.finish_with_reranker(cands, reranked, 5)
+    oc, os_, orr, oh = oracle.blend(wr, wc, [wr[i] for i in pick], rel, 5)
+    assert [g.row for g in got] == [int(wr[i]) for i in oc]
+    assert np.array_equal(bits([g.score for g in got]), bits(os_))
+    assert [g.reranker_score is not None for g in got] == list(oh)
+    eng.close()
