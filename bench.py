@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--check", type=int, default=1, help="queries verified against the oracle on the CPU sample")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not record HIP events in the timed region (roofline fields become null)")
+    ap.add_argument("--image", action="store_true",
+                    help="keep the binary16 nomination image for the batched path (rlr_index_enable_batch_image)")
     ap.add_argument("--batch", type=int, default=1,
                     help="queries per step; >= 16 takes the matrix-core (MFMA) batched path (BASELINE config 3 uses 256)")
     return ap.parse_args()
@@ -160,6 +162,8 @@ def main():
     fill_s = time.perf_counter() - t0
     ix = sh.index
     n_local = len(ix)
+    if args.image:
+        ix.enable_batch_image(True)
 
     force_sharded = os.environ.get("RLR_BENCH_FORCE_SHARDED") == "1"  # rehearse the N>1 code path on one GPU
 

@@ -92,6 +92,13 @@ int32_t rlr_index_delete_rows(rlr_index *idx, const uint64_t *rows, uint64_t n);
 int32_t rlr_index_fill_synthetic(rlr_index *idx, uint64_t n_rows, uint64_t row0, uint64_t seed,
                                  uint32_t n_clusters);
 
+/* Keep (enable != 0) or drop a binary16 "nomination image" of the rows laid out for the batched
+ * matrix-core path: [tile of 256 rows][K-chunk][wave][MFMA fragment], every fragment load lane-
+ * linear and a tile contiguous in HBM.  Costs dim * 2 bytes per row; kept in sync by upload /
+ * append / delete / fill.  Results are unchanged (the image only nominates; nominated rows are
+ * re-scored from the row-major master copy); batched throughput roughly doubles.  dim % 64 == 0. */
+int32_t rlr_index_enable_batch_image(rlr_index *idx, int32_t enable);
+
 /* ---- the hot path ------------------------------------------------------- */
 /* Brute-force cosine scan + top-k.
  * replaces: the exact-scan branch of RagEngine::search, rag_engine.rs:496-503 (ids = all

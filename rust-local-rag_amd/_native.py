@@ -73,6 +73,7 @@ PROTOTYPES = [
     ("rlr_index_append", C.c_int32, [_H, f32p, C.c_uint64, C.c_int32, u64p]),
     ("rlr_index_delete_rows", C.c_int32, [_H, u64p, C.c_uint64]),
     ("rlr_index_fill_synthetic", C.c_int32, [_H, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
+    ("rlr_index_enable_batch_image", C.c_int32, [_H, C.c_int32]),
     ("rlr_search_topk", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, u64p, f32p, u32p]),
     ("rlr_search_topk_device", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]),
     ("rlr_merge_topk", C.c_int32, [C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p, f32p, u32p,

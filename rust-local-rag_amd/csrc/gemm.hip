@@ -104,6 +104,64 @@ struct GemmArgs {
     size_t score_stride;
 };
 
+// ---- epilogue shared by the GEMM kernels: D layout is col = lane & 15 (query), row = 4*(lane >> 4) + reg
+template <bool MATERIALISE>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x4 (&acc)[kRG][kNB], uint32_t row0, uint32_t last_row,
+                                              uint32_t qb, int lane)
+{
+    const uint32_t qcol = qb * kQB + (lane & 15);
+    if constexpr (MATERIALISE) {
+#pragma unroll
+        for (int rg = 0; rg < kRG; ++rg) {
+            const uint32_t r = row0 + rg * 16 + 4 * (lane >> 4);
+            const uint32_t rel = r - a.row_begin;
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) {
+                const uint32_t q = qcol + nb * 16;
+                if (q >= a.n_queries)
+                    continue;
+                float *dst = a.scores + static_cast<size_t>(q) * a.score_stride + rel;
+                const f32x4 v = acc[rg][nb];
+                if (r + 3 <= last_row) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (r + i <= last_row)
+                            dst[i] = v[i];
+                }
+            }
+        }
+    } else {
+        float tau_l[kNB];
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb) {
+            const uint32_t q = qcol + nb * 16;
+            tau_l[nb] = q < a.n_queries ? a.tau[q] : __builtin_inff();
+        }
+#pragma unroll
+        for (int rg = 0; rg < kRG; ++rg) {
+            const uint32_t r = row0 + rg * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) {
+                const f32x4 v = acc[rg][nb];
+                const float t = tau_l[nb];
+                if (v[0] >= t || v[1] >= t || v[2] >= t || v[3] >= t) {
+                    const uint32_t q = qcol + nb * 16;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (v[i] >= t && r + i <= last_row) {
+                            const uint32_t slot = atomicAdd(&a.st[q].n_cand, 1u);
+                            if (slot < a.st[q].cap)
+                                a.cand[static_cast<size_t>(q) * a.cand_stride + slot] = pack_result(v[i], r + i);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool F16ROWS, bool MATERIALISE>
 __global__ __launch_bounds__(512) void gemm_nominate_kernel(const GemmArgs a)
 {
@@ -212,58 +270,149 @@ __global__ __launch_bounds__(512) void gemm_nominate_kernel(const GemmArgs a)
         __syncthreads();
     }
 
-    // ---- epilogue: D layout is col = lane & 15 (query), row = 4*(lane >> 4) + reg ----------
-    const uint32_t qcol = qb * kQB + (lane & 15);
-    if constexpr (MATERIALISE) {
+    gemm_epilogue<MATERIALISE>(a, acc, row0, last_row, qb, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Nomination image: an optional binary16 copy of the corpus laid out for this GEMM,
+//   [tile of 256 rows][K-chunk of 64][wave 8][row group 2][k-step 2][lane 64][8 halfs]
+// i.e. every MFMA A fragment of every wave is one lane-linear 1 KiB block, a tile's K-chunk is
+// 32 KB contiguous and a whole tile is dim/64 * 32 KB contiguous.  The row-major matrix makes
+// this GEMM read 256-byte pieces at a 3 KB stride (12 visits per DRAM page, every lane its own
+// request); the image turns the same bytes into a sequential stream of perfectly coalesced loads
+// and halves them for f32 corpora.  Costs dim*2 bytes per row of HBM; the row-major matrix stays
+// the master copy (exact re-score, single-query scan).
+// ---------------------------------------------------------------------------------------------
+template <bool F16ROWS>
+__global__ __launch_bounds__(256) void build_image_kernel(const unsigned char *__restrict__ rows, uint32_t pitch_bytes,
+                                                          uint32_t n_rows, uint32_t n_chunks, uint32_t tile_begin,
+                                                          uint32_t tile_end, half8 *__restrict__ image)
+{
+    const size_t per_tile = static_cast<size_t>(n_chunks) * 8 * 4 * 64; // half8 entries per tile
+    const size_t first = static_cast<size_t>(tile_begin) * per_tile;
+    const size_t total = static_cast<size_t>(tile_end - tile_begin) * per_tile;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+        const size_t e = first + i;
+        const uint32_t lane = e & 63;
+        const uint32_t ks = (e >> 6) & 1;
+        const uint32_t rg = (e >> 7) & 1;
+        const uint32_t w = (e >> 8) & 7;
+        const size_t tc = e >> 11; // tile * n_chunks + chunk
+        const uint32_t c = static_cast<uint32_t>(tc % n_chunks);
+        const uint32_t t = static_cast<uint32_t>(tc / n_chunks);
+        const uint32_t row = t * 256 + w * 32 + rg * 16 + (lane & 15);
+        const uint32_t k = c * 64 + ks * 32 + (lane >> 4) * 8;
+        half8 v;
 #pragma unroll
-        for (int rg = 0; rg < kRG; ++rg) {
-            const uint32_t r = row0 + rg * 16 + 4 * (lane >> 4);
-            const uint32_t rel = r - a.row_begin;
-#pragma unroll
-            for (int nb = 0; nb < kNB; ++nb) {
-                const uint32_t q = qcol + nb * 16;
-                if (q >= a.n_queries)
-                    continue;
-                float *dst = a.scores + static_cast<size_t>(q) * a.score_stride + rel;
-                const f32x4 v = acc[rg][nb];
-                if (r + 3 <= last_row) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (r + i <= last_row)
-                            dst[i] = v[i];
-                }
+        for (int j = 0; j < 8; ++j)
+            v[j] = static_cast<_Float16>(0.0f);
+        if (row < n_rows) {
+            const unsigned char *src = rows + static_cast<size_t>(row) * pitch_bytes;
+            if constexpr (F16ROWS) {
+                v = *reinterpret_cast<const half8 *>(src + k * 2);
+            } else {
+                const float4 lo = *reinterpret_cast<const float4 *>(src + k * 4);
+                const float4 hi = *reinterpret_cast<const float4 *>(src + k * 4 + 16);
+                v = cvt8(lo, hi);
             }
         }
-    } else {
-        float tau_l[kNB];
-#pragma unroll
-        for (int nb = 0; nb < kNB; ++nb) {
-            const uint32_t q = qcol + nb * 16;
-            tau_l[nb] = q < a.n_queries ? a.tau[q] : __builtin_inff();
-        }
-#pragma unroll
-        for (int rg = 0; rg < kRG; ++rg) {
-            const uint32_t r = row0 + rg * 16 + 4 * (lane >> 4);
-#pragma unroll
-            for (int nb = 0; nb < kNB; ++nb) {
-                const f32x4 v = acc[rg][nb];
-                const float t = tau_l[nb];
-                if (v[0] >= t || v[1] >= t || v[2] >= t || v[3] >= t) {
-                    const uint32_t q = qcol + nb * 16;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (v[i] >= t && r + i <= last_row) {
-                            const uint32_t slot = atomicAdd(&a.st[q].n_cand, 1u);
-                            if (slot < a.st[q].cap)
-                                a.cand[static_cast<size_t>(q) * a.cand_stride + slot] = pack_result(v[i], r + i);
-                        }
-                    }
-                }
-            }
-        }
+        image[e] = v;
     }
+}
+
+// GEMM over the image: a four-slot register ring of A fragments per wave (16 VGPRs per chunk),
+// every chunk requested three MFMA phases before use, all loads lane-linear; branch-free loop
+// (past the end the last chunk is fetched again, never used).
+template <bool MATERIALISE>
+__global__ __launch_bounds__(512) void gemm_image_kernel(const GemmArgs a, const half8 *__restrict__ image)
+{
+    __shared__ half8 s_b[2][kChunkFrags];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t bid = blockIdx.x;
+    const uint32_t rt = (bid / (8 * a.n_qblocks)) * 8 + (bid & 7); // tile index relative to row_begin
+    const uint32_t qb = (bid >> 3) % a.n_qblocks;
+    const uint32_t n_rows = a.row_end - a.row_begin;
+    if (rt * kBM >= n_rows)
+        return;
+    const uint32_t row0 = a.row_begin + rt * kBM + wave * (kRG * 16);
+    const uint32_t last_row = a.row_end - 1;
+    const uint32_t n_chunks = a.n_ksteps / kKsChunk; // multiple of 4
+    const uint32_t tile = a.row_begin / kBM + rt;     // row_begin is a multiple of 256
+    // this wave's fragments of chunk c: image[((tile*n_chunks + c)*8 + wave)*4 + rg*2 + ks][lane]
+    const half8 *ap = image + (static_cast<size_t>(tile) * n_chunks * 8 + wave) * 4 * 64 + lane;
+    const half8 *bsrc = a.qfrag + static_cast<size_t>(qb) * a.n_ksteps * kNB * 64;
+
+    f32x4 acc[kRG][kNB];
+#pragma unroll
+    for (int rg = 0; rg < kRG; ++rg)
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb)
+            acc[rg][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    half8 breg[4];
+    half8 ring[4][kRG][kKsChunk];
+
+#define RLR_LOAD_B(CHUNK)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) breg[i] = bsrc[static_cast<size_t>(CHUNK) * kChunkFrags + tid + 512 * i]
+#define RLR_STORE_B(BUF) _Pragma("unroll") for (int i = 0; i < 4; ++i) s_b[BUF][tid + 512 * i] = breg[i]
+#define RLR_LOAD_A(CHUNK, SLOT)                                                                    \
+    _Pragma("unroll") for (int rg = 0; rg < kRG; ++rg) _Pragma("unroll") for (int ks = 0; ks < kKsChunk; ++ks) \
+        ring[SLOT][rg][ks] = ap[static_cast<size_t>(CHUNK) * (8 * 4 * 64) + (rg * 2 + ks) * 64]
+// B fragments are read two steps ahead into a rotating set of four registers: the LDS latency
+// of fragment f+2 overlaps the MFMAs of fragment f (hipcc otherwise re-uses two registers and
+// waits on every pair).  sched_group_barrier pins the 1 ds_read : 2 MFMA interleave.
+#define RLR_COMPUTE(BUF, SLOT)                                                                     \
+    do {                                                                                           \
+        const half8 *sb = s_b[BUF] + lane;                                                         \
+        half8 bq[4];                                                                               \
+        bq[0] = sb[0];                                                                             \
+        bq[1] = sb[64];                                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                         \
+        _Pragma("unroll") for (int f = 0; f < kKsChunk * kNB; ++f)                                  \
+        {                                                                                          \
+            if (f + 2 < kKsChunk * kNB) {                                                          \
+                bq[(f + 2) & 3] = sb[(f + 2) * 64];                                                \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+            }                                                                                      \
+            _Pragma("unroll") for (int rg = 0; rg < kRG; ++rg) acc[rg][f % kNB] =                   \
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[SLOT][rg][f / kNB], bq[f & 3], acc[rg][f % kNB], 0, 0, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x008, kRG, 0);                                   \
+        }                                                                                          \
+    } while (0)
+#define RLR_PHASE(U)                                                                               \
+    do {                                                                                           \
+        const uint32_t cc = c + (U);                                                               \
+        RLR_LOAD_A(min(cc + 3, last_c), ((U) + 3) & 3);                                            \
+        RLR_LOAD_B(min(cc + 1, last_c));                                                           \
+        __builtin_amdgcn_sched_barrier(0); /* do not sink the loads below the MFMAs */             \
+        RLR_COMPUTE((U) & 1, (U));                                                                 \
+        RLR_STORE_B(((U) + 1) & 1);                                                                \
+        __syncthreads();                                                                           \
+    } while (0)
+
+    const uint32_t last_c = n_chunks - 1;
+    RLR_LOAD_A(0, 0);
+    RLR_LOAD_A(1, 1);
+    RLR_LOAD_A(2, 2);
+    RLR_LOAD_B(0);
+    RLR_STORE_B(0);
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t c = 0; c < n_chunks; c += 4) {
+        RLR_PHASE(0);
+        RLR_PHASE(1);
+        RLR_PHASE(2);
+        RLR_PHASE(3);
+    }
+#undef RLR_PHASE
+#undef RLR_COMPUTE
+#undef RLR_LOAD_A
+#undef RLR_STORE_B
+#undef RLR_LOAD_B
+    gemm_epilogue<MATERIALISE>(a, acc, row0, last_row, qb, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -388,7 +537,7 @@ hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pi
 hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin,
                                 uint32_t row_end, const void *qfrag, uint32_t n_queries, const float *tau,
                                 uint64_t *cand, uint32_t cand_stride, SelectState *st, float *scores,
-                                size_t score_stride, hipStream_t s)
+                                size_t score_stride, const void *image, hipStream_t s)
 {
     if (row_end <= row_begin)
         return hipSuccess;
@@ -410,6 +559,13 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
     const uint32_t n_rt = (row_end - row_begin + kBM - 1) / kBM;
     const uint32_t grid = ((n_rt + 7) / 8) * 8 * a.n_qblocks;
     const bool mat = scores != nullptr;
+    if (image && row_begin % kBM == 0 && (a.n_ksteps / kKsChunk) % 4 == 0) {
+        if (mat)
+            hipLaunchKernelGGL((gemm_image_kernel<true>), dim3(grid), dim3(512), 0, s, a, static_cast<const half8 *>(image));
+        else
+            hipLaunchKernelGGL((gemm_image_kernel<false>), dim3(grid), dim3(512), 0, s, a, static_cast<const half8 *>(image));
+        return hipGetLastError();
+    }
     if (dtype == RLR_F16) {
         if (mat)
             hipLaunchKernelGGL((gemm_nominate_kernel<true, true>), dim3(grid), dim3(512), 0, s, a);
@@ -422,6 +578,30 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
             hipLaunchKernelGGL((gemm_nominate_kernel<false, false>), dim3(grid), dim3(512), 0, s, a);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_build_image(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t n_rows,
+                              uint32_t tile_begin, uint32_t tile_end, void *image, hipStream_t s)
+{
+    if (tile_end <= tile_begin)
+        return hipSuccess;
+    const uint32_t n_chunks = dim / 64;
+    const size_t total = static_cast<size_t>(tile_end - tile_begin) * n_chunks * 8 * 4 * 64;
+    const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((total + 255) / 256, 65536));
+    const unsigned char *r = static_cast<const unsigned char *>(rows);
+    if (dtype == RLR_F16)
+        hipLaunchKernelGGL(build_image_kernel<true>, dim3(blocks), dim3(256), 0, s, r, pitch16 * 16, n_rows, n_chunks,
+                           tile_begin, tile_end, static_cast<half8 *>(image));
+    else
+        hipLaunchKernelGGL(build_image_kernel<false>, dim3(blocks), dim3(256), 0, s, r, pitch16 * 16, n_rows, n_chunks,
+                           tile_begin, tile_end, static_cast<half8 *>(image));
+    return hipGetLastError();
+}
+
+size_t image_bytes(uint32_t dim, uint64_t n_rows)
+{
+    const uint64_t tiles = (n_rows + kBM - 1) / kBM;
+    return static_cast<size_t>(tiles) * kBM * dim * 2;
 }
 
 hipError_t launch_batch_finish(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *queries,

@@ -110,6 +110,9 @@ struct rlr_index {
     int n_cu = 256;
     int scan_variant = 0;
     uint32_t batch_min = 16;  // smallest batch that takes the matrix-core path (RLR_BATCH_MIN)
+    bool image_enabled = false; // keep a binary16 nomination image of the rows for the batched GEMM
+    void *d_image = nullptr;
+    size_t image_cap = 0;       // bytes
     std::mutex mu;
     std::vector<Ctx *> free_ctx;
     bool profiling = false;
@@ -275,6 +278,29 @@ int32_t ensure_rows(rlr_index *ix, uint64_t want_rows)
         (void)hipFree(ix->d_rows);
     ix->d_rows = n;
     ix->cap_rows = cap;
+    return RLR_OK;
+}
+
+// (Re)build the nomination image for every tile that holds a row >= first_row.
+int32_t sync_image(rlr_index *ix, uint64_t first_row)
+{
+    if (!ix->image_enabled)
+        return RLR_OK;
+    const size_t need = image_bytes(ix->dim, std::max<uint64_t>(ix->cap_rows, ix->n_rows));
+    if (ix->image_cap < need) {
+        if (ix->d_image)
+            (void)hipFree(ix->d_image);
+        ix->d_image = nullptr;
+        ix->image_cap = 0;
+        RLR_HIP(hipMalloc(&ix->d_image, std::max<size_t>(need, 256)));
+        ix->image_cap = std::max<size_t>(need, 256);
+        first_row = 0; // fresh buffer: every tile has to be written
+    }
+    const uint32_t t0 = static_cast<uint32_t>(first_row / 256);
+    const uint32_t t1 = static_cast<uint32_t>((ix->n_rows + 255) / 256);
+    RLR_HIP(launch_build_image(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, static_cast<uint32_t>(ix->n_rows), t0, t1,
+                               ix->d_image, nullptr));
+    RLR_HIP(hipStreamSynchronize(nullptr));
     return RLR_OK;
 }
 
@@ -648,10 +674,13 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     RLR_HIP(hipMemsetAsync(c->d_bhist, 0, static_cast<size_t>(nq) * 2 * kHistBins * sizeof(uint32_t), s));
     RLR_HIP(hipMemsetAsync(c->d_bstatus, 0xFF, static_cast<size_t>(nq) * sizeof(uint32_t), s));
     if (timed) RLR_HIP(hipEventRecord(c->bev[0], s));
-    RLR_HIP(launch_prep_queries(dq, nq, ix->q_pitch, ix->dim, ix->dtype, c->d_qfrag, s));
+    const bool use_image = ix->image_enabled && ix->d_image && (ix->dim / 64) % 4 == 0;
+    const void *image = use_image ? ix->d_image : nullptr;
+    // the image stores k in natural order (like binary16 rows); only the direct f32-row loads permute it
+    RLR_HIP(launch_prep_queries(dq, nq, ix->q_pitch, ix->dim, use_image ? static_cast<int>(RLR_F16) : ix->dtype, c->d_qfrag, s));
     // 1. nominated scores of the sample rows, materialised
     RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, 0, static_cast<uint32_t>(S), c->d_qfrag, nq,
-                                 nullptr, nullptr, 0, nullptr, c->d_sample, s_stride, s));
+                                 nullptr, nullptr, 0, nullptr, c->d_sample, s_stride, image, s));
     if (timed) RLR_HIP(hipEventRecord(c->bev[1], s));
     // 2. per-query k-th score of the sample -> threshold; the sample's own candidates
     RLR_HIP(launch_batch_select(c->d_sample, static_cast<uint32_t>(S), s_stride, nq, c->d_bhist, c->d_bstate, two_eps,
@@ -659,7 +688,7 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     if (timed) RLR_HIP(hipEventRecord(c->bev[2], s));
     // 3. the rest of the corpus, filtered in the GEMM epilogue
     RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, static_cast<uint32_t>(S), n, c->d_qfrag, nq,
-                                 c->d_tau, c->d_bcand, fin_cap, c->d_bstate, nullptr, 0, s));
+                                 c->d_tau, c->d_bcand, fin_cap, c->d_bstate, nullptr, 0, image, s));
     if (timed) RLR_HIP(hipEventRecord(c->bev[3], s));
     // 4. per-query finish: band, reference-order re-score, order, emit
     RLR_HIP(launch_batch_finish(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, ix->q_pitch, nq, c->d_bcand, fin_cap,
@@ -684,7 +713,7 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
             (void)hipEventElapsedTime(&fin, c->bev[3], c->ev[3]);
             ix->prof.batch_gemm_ms += prep + g2; // prep is ~us; both GEMM launches are in here
             ix->prof.batch_other_ms += sel + fin;
-            ix->prof.batch_gemm_bytes += static_cast<uint64_t>(n_qblocks) * n * ix->dim * (ix->dtype == RLR_F16 ? 2 : 4);
+            ix->prof.batch_gemm_bytes += static_cast<uint64_t>(n_qblocks) * n * ix->dim * ((ix->dtype == RLR_F16 || use_image) ? 2 : 4);
             ix->prof.batch_gemm_flops += 2.0 * nq * static_cast<double>(n) * ix->dim;
         }
     }
@@ -931,6 +960,8 @@ int32_t rlr_index_destroy(rlr_index *ix)
         ctx_free(c);
     if (ix->d_rows)
         (void)hipFree(ix->d_rows);
+    if (ix->d_image)
+        (void)hipFree(ix->d_image);
     delete ix;
     return RLR_OK;
 }
@@ -962,7 +993,7 @@ int32_t rlr_index_upload(rlr_index *ix, const float *rows, uint64_t n_rows, int3
     RLR_TRY(ensure_rows(ix, n_rows));
     RLR_TRY(ingest(ix, rows, n_rows, 0, normalize_on_device));
     ix->n_rows = n_rows;
-    return RLR_OK;
+    return sync_image(ix, 0);
 }
 
 int32_t rlr_index_append(rlr_index *ix, const float *rows, uint64_t n_rows, int32_t normalize_on_device,
@@ -978,7 +1009,7 @@ int32_t rlr_index_append(rlr_index *ix, const float *rows, uint64_t n_rows, int3
     ix->n_rows = first + n_rows;
     if (first_row_out)
         *first_row_out = first;
-    return RLR_OK;
+    return sync_image(ix, first);
 }
 
 int32_t rlr_index_delete_rows(rlr_index *ix, const uint64_t *rows, uint64_t n)
@@ -1033,9 +1064,29 @@ int32_t rlr_index_delete_rows(rlr_index *ix, const uint64_t *rows, uint64_t n)
     }
     (void)hipFree(d_bounce);
     (void)hipFree(d_keep);
-    if (st == RLR_OK)
+    if (st == RLR_OK) {
         ix->n_rows = first_dead + keep.size();
+        st = sync_image(ix, first_dead);
+    }
     return st;
+}
+
+int32_t rlr_index_enable_batch_image(rlr_index *ix, int32_t enable)
+{
+    RLR_TRY(check_handle(ix));
+    RLR_TRY(use_device(ix));
+    if (!enable) {
+        ix->image_enabled = false;
+        if (ix->d_image)
+            (void)hipFree(ix->d_image);
+        ix->d_image = nullptr;
+        ix->image_cap = 0;
+        return RLR_OK;
+    }
+    if (ix->dim % 64 != 0)
+        return fail(RLR_E_INVALID, "the nomination image needs dim %% 64 == 0 (dim = %u)", ix->dim);
+    ix->image_enabled = true;
+    return sync_image(ix, 0);
 }
 
 int32_t rlr_index_fill_synthetic(rlr_index *ix, uint64_t n_rows, uint64_t row0, uint64_t seed, uint32_t n_clusters)
@@ -1058,8 +1109,10 @@ int32_t rlr_index_fill_synthetic(rlr_index *ix, uint64_t n_rows, uint64_t row0, 
             st = fail(RLR_E_HIP, "synthetic fill failed: %s", hipGetErrorString(e));
     }
     (void)hipFree(d_norm);
-    if (st == RLR_OK)
+    if (st == RLR_OK) {
         ix->n_rows = n_rows;
+        st = sync_image(ix, 0);
+    }
     return st;
 }
 

@@ -68,7 +68,11 @@ hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pi
 hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin,
                                 uint32_t row_end, const void *qfrag, uint32_t n_queries, const float *tau,
                                 uint64_t *cand, uint32_t cand_stride, SelectState *st, float *scores,
-                                size_t score_stride, hipStream_t s);
+                                size_t score_stride, const void *image, hipStream_t s);
+// optional binary16 nomination image of the corpus in GEMM-fragment order (see gemm.hip)
+size_t image_bytes(uint32_t dim, uint64_t n_rows);
+hipError_t launch_build_image(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t n_rows,
+                              uint32_t tile_begin, uint32_t tile_end, void *image, hipStream_t s);
 hipError_t launch_batch_finish(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *queries,
                                uint32_t q_pitch, uint32_t n_queries, const uint64_t *cand, uint32_t cand_stride,
                                const SelectState *st, uint32_t k, float two_eps, uint64_t *out, uint32_t *status,

@@ -106,6 +106,10 @@ class GpuIndex:
     def fill_synthetic(self, n_rows: int, seed: int, row0: int = 0, n_clusters: int = 0) -> None:
         N.check(self._L.rlr_index_fill_synthetic(self._h, n_rows, row0, seed, n_clusters))
 
+    def enable_batch_image(self, on: bool = True) -> None:
+        """binary16 nomination image for the batched matrix-core path (dim * 2 bytes per row)"""
+        N.check(self._L.rlr_index_enable_batch_image(self._h, int(on)))
+
     # -- hot path ------------------------------------------------------------
     def search_topk(self, queries, k: int, guard_eps: float = -1.0):
         """queries: [Q, dim] (or [dim]) already normalised -> (rows u64 [Q,k'], cos f32 [Q,k'])"""

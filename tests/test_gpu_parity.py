@@ -485,3 +485,29 @@ def test_search_stage1_then_reranker_blend(rlr, oracle):
     assert np.array_equal(bits([g.score for g in got]), bits(os_))
     assert [g.reranker_score is not None for g in got] == list(oh)
     eng.close()
+
+
+# ---------------------------------------------------------------- nomination image (batched path)
+@pytest.mark.parametrize("dim,dtype", [(768, "f32"), (1024, "f16")])
+def test_batch_image_same_results_and_tracks_mutation(rlr, oracle, dim, dtype):
+    n = 9000
+    rows = oracle.synth_rows(n, dim, seed=611, f16=(dtype == "f16"))
+    qs = np.stack([oracle.normalize(oracle.synth_query(dim, seed=1300 + i)) for i in range(24)])
+    ix = rlr.GpuIndex(dim, dtype)
+    ix.upload(oracle.synth_rows(n, dim, seed=611))
+    ix.enable_batch_image(True)
+    prof = _check_batch(rlr, oracle, ix, rows, qs, 50)
+    assert prof.n_batches == 1 and prof.n_batch_fallbacks == 0
+    # append + delete: the image must follow the row-major master copy
+    extra = oracle.synth_rows(700, dim, seed=612, f16=(dtype == "f16"))
+    ix.append(oracle.synth_rows(700, dim, seed=612))
+    dead = np.array([3, 255, 256, 4000, 9100], dtype=np.uint64)
+    ix.delete_rows(dead)
+    all_rows = np.concatenate([rows, extra])
+    keep = np.setdiff1d(np.arange(n + 700), dead)
+    prof = _check_batch(rlr, oracle, ix, all_rows[keep], qs, 50)
+    assert prof.n_batches == 1 and prof.n_batch_fallbacks == 0
+    # dropping the image falls back to the row-major GEMM with identical results
+    ix.enable_batch_image(False)
+    _check_batch(rlr, oracle, ix, all_rows[keep], qs[:16], 50)
+    ix.close()
