@@ -178,6 +178,32 @@ int32_t rlr_merge_topk(int32_t device_id, const void *d_gathered, uint32_t world
 uint64_t rlr_pack_result(float score, uint32_t row);
 void rlr_unpack_result(uint64_t packed, float *score, uint32_t *row);
 
+/* ---- one process, several GPUs ------------------------------------------------------------ */
+/* The reference is a single-process server; this handle lets such a host drive all GPUs of a node
+ * without torch / one-process-per-GPU: rows are split into contiguous ranges (shard g holds rows
+ * [g*ceil(N/G), ...)), every search runs on all shards concurrently (one host thread per device)
+ * and the per-shard top-k lists (k x 8 bytes each) are merged on the host.  Results are identical
+ * to a single index over the same rows.  device_ids may repeat (several shards on one GPU).
+ * The benchmark contract's multi-GPU path is the one-process-per-GPU / RCCL variant
+ * (rlr_search_topk_device + rlr_merge_topk, rust-local-rag_amd/sharded.py). */
+typedef struct rlr_multi rlr_multi;
+int32_t rlr_multi_create(uint32_t dim, int32_t dtype, int32_t n_devices, const int32_t *device_ids,
+                         rlr_multi **out);
+int32_t rlr_multi_destroy(rlr_multi *m);
+int32_t rlr_multi_info(const rlr_multi *m, uint64_t *n_rows, uint32_t *n_shards);
+/* replace all rows (host memory, n_rows x dim f32), sharded by contiguous ranges */
+int32_t rlr_multi_upload(rlr_multi *m, const float *rows, uint64_t n_rows, int32_t normalize_on_device);
+int32_t rlr_multi_fill_synthetic(rlr_multi *m, uint64_t n_rows, uint64_t seed, uint32_t n_clusters);
+/* same contract as rlr_search_topk, row numbers are global */
+int32_t rlr_multi_search_topk(rlr_multi *m, const float *queries, uint32_t n_queries, uint32_t k,
+                              float guard_eps, uint64_t *rows_out, float *cos_out, uint32_t *n_out);
+int32_t rlr_multi_score_rows(rlr_multi *m, const float *query, const uint64_t *rows, uint32_t n, float *cos_out);
+int32_t rlr_multi_fetch_rows(rlr_multi *m, const uint64_t *rows, uint32_t n, float *out);
+/* MMR over a pool whose rows live on different shards: the pool rows are gathered to the first
+ * device (P x dim f32, < 1 MB for the reference's pool of 300) and selected there. */
+int32_t rlr_multi_mmr_select(rlr_multi *m, const uint64_t *pool_rows, const float *pool_scores, uint32_t P,
+                             uint32_t k, float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out);
+
 /* ---- measurement hooks --------------------------------------------------- */
 typedef struct rlr_profile {
     uint64_t n_searches;   /* rlr_search_topk* calls (queries, not batches) since reset */

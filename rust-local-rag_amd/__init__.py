@@ -12,7 +12,7 @@ CPU implementation of the search path.
 from ._native import (DEFAULT_DIVERSITY, DEFAULT_TOP_K, MAX_TOP_K, RLR_F16, RLR_F32, RlrError, SO_PATH, lib)
 from .engine import (DocumentChunk, QueryWeights, RagEngine, ResolvedWeights, SearchRequest, SearchResult,
                      format_search_results, normalize, resolve_weight)
-from .index import GpuIndex, Profile, default_guard_eps, device_count
+from .index import GpuIndex, MultiGpuIndex, Profile, default_guard_eps, device_count
 from .persistence import (LoadReport, get_index_path, get_legacy_path, load_from_disk, sanitize_model_name,
                           save_to_disk)
 
@@ -21,7 +21,7 @@ lib()  # fail loudly at import time when librlr_gpu.so is missing
 __all__ = [
     "DEFAULT_DIVERSITY", "DEFAULT_TOP_K", "MAX_TOP_K", "RLR_F16", "RLR_F32", "RlrError", "SO_PATH", "lib",
     "DocumentChunk", "QueryWeights", "RagEngine", "ResolvedWeights", "SearchRequest", "SearchResult",
-    "format_search_results", "normalize", "resolve_weight", "GpuIndex", "Profile", "default_guard_eps",
+    "format_search_results", "normalize", "resolve_weight", "GpuIndex", "MultiGpuIndex", "Profile", "default_guard_eps",
     "device_count", "LoadReport", "get_index_path", "get_legacy_path", "load_from_disk", "sanitize_model_name",
     "save_to_disk",
 ]

@@ -177,6 +177,78 @@ class GpuIndex:
         return Profile(*(getattr(p, f) for f, _ in N.ProfileC._fields_))
 
 
+class MultiGpuIndex:
+    """One process, several GPUs (rlr_multi_*): contiguous row shards, host-side merge."""
+
+    def __init__(self, dim: int, device_ids, dtype: str = "f32"):
+        self._L = N.lib()
+        self._h = C.c_void_p()
+        ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+        code = {"f32": N.RLR_F32, "f16": N.RLR_F16}[dtype]
+        N.check(self._L.rlr_multi_create(dim, code, ids.size, ids.ctypes.data_as(N.i32p), C.byref(self._h)))
+        self.dim = dim
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.rlr_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        n = C.c_uint64()
+        N.check(self._L.rlr_multi_info(self._h, C.byref(n), None))
+        return int(n.value)
+
+    def upload(self, rows, normalize: bool = False) -> None:
+        rows = _f32(rows).reshape(-1, self.dim)
+        N.check(self._L.rlr_multi_upload(self._h, _fp(rows), rows.shape[0], int(normalize)))
+
+    def fill_synthetic(self, n_rows: int, seed: int, n_clusters: int = 0) -> None:
+        N.check(self._L.rlr_multi_fill_synthetic(self._h, n_rows, seed, n_clusters))
+
+    def search_topk(self, queries, k: int, guard_eps: float = -1.0):
+        q = _f32(queries).reshape(-1, self.dim)
+        nq = q.shape[0]
+        rows = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        cos = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        n_out = np.zeros(max(nq, 1), dtype=np.uint32)
+        N.check(self._L.rlr_multi_search_topk(self._h, _fp(q), nq, k, guard_eps, _up(rows), _fp(cos),
+                                              n_out.ctypes.data_as(N.u32p)))
+        kk = int(n_out[0]) if nq else 0
+        return rows[:, :kk], cos[:, :kk]
+
+    def score_rows(self, query, rows) -> np.ndarray:
+        q = _f32(query).ravel()
+        rows = _u64(rows).ravel()
+        out = np.zeros(rows.size, dtype=np.float32)
+        if rows.size:
+            N.check(self._L.rlr_multi_score_rows(self._h, _fp(q), _up(rows), rows.size, _fp(out)))
+        return out
+
+    def fetch_rows(self, rows) -> np.ndarray:
+        rows = _u64(rows).ravel()
+        out = np.zeros((rows.size, self.dim), dtype=np.float32)
+        if rows.size:
+            N.check(self._L.rlr_multi_fetch_rows(self._h, _up(rows), rows.size, _fp(out)))
+        return out
+
+    def mmr_select(self, pool_rows, pool_scores, k: int, lam: float):
+        pool_rows = _u64(pool_rows).ravel()
+        pool_scores = _f32(pool_scores).ravel()
+        P = pool_rows.size
+        order = np.zeros(max(P, 1), dtype=np.uint32)
+        mmr = np.zeros(max(P, 1), dtype=np.float32)
+        n = C.c_uint32()
+        N.check(self._L.rlr_multi_mmr_select(self._h, _up(pool_rows), _fp(pool_scores), P, k, lam,
+                                             order.ctypes.data_as(N.u32p), _fp(mmr), C.byref(n)))
+        return order[: n.value], mmr[: n.value]
+
+
 def default_guard_eps(dim: int) -> float:
     return float(N.lib().rlr_default_guard_eps(dim))
 

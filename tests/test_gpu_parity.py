@@ -511,3 +511,38 @@ def test_batch_image_same_results_and_tracks_mutation(rlr, oracle, dim, dtype):
     ix.enable_batch_image(False)
     _check_batch(rlr, oracle, ix, all_rows[keep], qs[:16], 50)
     ix.close()
+
+
+# ---------------------------------------------------------------- one process, several shards
+def test_multi_index_three_shards_on_one_gpu(rlr, oracle):
+    """rlr_multi_* with three shards that all live on GPU 0: concurrent per-shard searches from
+    three host threads, host merge, cross-shard ties, score/fetch routing, MMR over a pool that
+    spans shards."""
+    n, dim = 10_001, 768
+    rows = oracle.synth_rows(n, dim, seed=711, n_clusters=15)
+    rows[7000] = rows[12]                     # exact tie across shards 0 and 2
+    mi = rlr.MultiGpuIndex(dim, [0, 0, 0])
+    mi.upload(rows)
+    assert len(mi) == n
+    qs = np.stack([oracle.normalize(rows[12])] + [oracle.normalize(oracle.synth_query(dim, seed=1400 + i)) for i in range(4)])
+    r, c = mi.search_topk(qs, 40)
+    for i in range(len(qs)):
+        wr, wc = oracle_topk(oracle, rows, qs[i], 40)
+        assert np.array_equal(r[i], wr) and np.array_equal(bits(c[i]), bits(wc)), i
+    assert list(r[0][:2]) == [12, 7000]
+    pick = np.array([0, 3333, 3334, 6667, 6668, 10000, 5], dtype=np.uint64)   # shard boundaries
+    assert np.array_equal(bits(mi.fetch_rows(pick)), bits(rows[pick.astype(np.int64)]))
+    want = np.array([oracle.dot(qs[1], rows[int(p)]) for p in pick], np.float32)
+    assert np.array_equal(bits(mi.score_rows(qs[1], pick)), bits(want))
+    pr, pc = mi.search_topk(qs[1], 300)
+    sc = (np.float32(0.7) * pc[0]).astype(np.float32)
+    order, _ = mi.mmr_select(pr[0], sc, 100, 0.3)
+    worder, _ = oracle.mmr(rows[pr[0].astype(np.int64)], sc, 100, 0.3)
+    assert np.array_equal(order, worder)
+    # batched queries go through the MFMA path on every shard
+    qb = np.stack([oracle.normalize(oracle.synth_query(dim, seed=1500 + i)) for i in range(20)])
+    rb, cb = mi.search_topk(qb, 10)
+    for i in (0, 7, 19):
+        wr, wc = oracle_topk(oracle, rows, qb[i], 10)
+        assert np.array_equal(rb[i], wr) and np.array_equal(bits(cb[i]), bits(wc))
+    mi.close()
