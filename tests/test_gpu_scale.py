@@ -1,0 +1,89 @@
+"""Size-independent properties at a corpus far beyond what the oracle can scan in seconds
+(3 M x 768 f32 = 9.2 GB, generated on the device): sortedness, self-consistency of the emitted
+scores with the reference-order re-score, top-k-ness against a random sample, idempotence,
+single == batched == sharded, and a delete round trip."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+N, DIM, K, SEED = 3_000_000, 768, 100, 0x5EED0003
+
+
+@pytest.fixture(scope="module")
+def big(rlr):
+    ix = rlr.GpuIndex(DIM)
+    ix.fill_synthetic(N, seed=SEED)
+    yield ix
+    ix.close()
+
+
+def _queries(rlr, n, seed=5):
+    rng = np.random.default_rng(seed)
+    return np.stack([rlr.normalize(rng.standard_normal(DIM).astype(np.float32)) for _ in range(n)])
+
+
+def test_sorted_exact_and_topk_against_sample(rlr, big):
+    qs = _queries(rlr, 3)
+    rng = np.random.default_rng(1)
+    for q in qs:
+        r, c = big.search_topk(q, K)
+        r, c = r[0], c[0]
+        assert len(r) == K and len(set(r.tolist())) == K
+        key = list(zip((-c).tolist(), r.tolist()))
+        assert key == sorted(key)                                       # (score desc, row asc)
+        assert np.array_equal(bits(c), bits(big.score_rows(q, r)))      # emitted == reference-order dot of that row
+        sample = rng.choice(N, size=200_000, replace=False).astype(np.uint64)
+        s = big.score_rows(q, sample)
+        outside = ~np.isin(sample, r)
+        assert s[outside].max() <= c[-1]                                # nothing in the sample beats the k-th result
+        inside = sample[~outside]
+        if inside.size:                                                  # and sampled members carry the same score
+            pos = {int(x): i for i, x in enumerate(r)}
+            assert all(bits([s[np.where(sample == x)[0][0]]])[0] == bits([c[pos[int(x)]]])[0] for x in inside)
+        r2, c2 = big.search_topk(q, K)                                   # idempotent
+        assert np.array_equal(r2[0], r) and np.array_equal(bits(c2[0]), bits(c))
+
+
+def test_batched_equals_single_at_scale(rlr, big):
+    qs = _queries(rlr, 32, seed=6)
+    big.profile_read(reset=True)
+    rb, cb = big.search_topk(qs, K)
+    prof = big.profile_read()
+    assert prof.n_batches == 1 and prof.n_batch_fallbacks == 0
+    for i in range(0, 32, 5):
+        r1, c1 = big.search_topk(qs[i], K)
+        assert np.array_equal(r1[0], rb[i]) and np.array_equal(bits(c1[0]), bits(cb[i]))
+    big.enable_batch_image(True)                                         # and through the nomination image
+    ri, ci = big.search_topk(qs, K)
+    big.enable_batch_image(False)
+    assert np.array_equal(ri, rb) and np.array_equal(bits(ci), bits(cb))
+
+
+def test_sharded_equals_single_at_scale(rlr, big):
+    qs = _queries(rlr, 2, seed=7)
+    mi = rlr.MultiGpuIndex(DIM, [0, 0, 0, 0])
+    mi.fill_synthetic(N, seed=SEED)
+    for q in qs:
+        r1, c1 = big.search_topk(q, K)
+        rm, cm = mi.search_topk(q, K)
+        assert np.array_equal(r1, rm) and np.array_equal(bits(c1), bits(cm))
+    mi.close()
+
+
+def test_delete_round_trip(rlr):
+    n = 1_000_000
+    ix = rlr.GpuIndex(DIM)
+    ix.fill_synthetic(n, seed=SEED + 9)
+    q = _queries(rlr, 1, seed=8)[0]
+    r, c = ix.search_topk(q, 20)
+    dead = np.array([r[0][0], r[0][3], r[0][7]], dtype=np.uint64)
+    ix.delete_rows(dead)
+    r2, c2 = ix.search_topk(q, 17)
+    keep = [i for i in range(20) if i not in (0, 3, 7)]
+    want_rows = np.array([int(r[0][i]) - int((dead < r[0][i]).sum()) for i in keep], dtype=np.uint64)
+    assert np.array_equal(r2[0], want_rows)
+    assert np.array_equal(bits(c2[0]), bits(c[0][keep]))
+    ix.close()
