@@ -94,6 +94,7 @@ struct Ctx {
     // pinned host
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
+    bool hist_dirty = false; // a pipeline was enqueued and did not complete: d_hist may hold counts
 };
 
 } // namespace
@@ -208,6 +209,11 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
         if (!ix->free_ctx.empty()) {
             *out = ix->free_ctx.back();
             ix->free_ctx.pop_back();
+            if ((*out)->hist_dirty) { // a previous call failed half way: restore the zero-histogram invariant
+                (void)hipStreamSynchronize((*out)->stream);
+                if (hipMemset((*out)->d_hist, 0, 2 * kHistBins * sizeof(uint32_t)) == hipSuccess)
+                    (*out)->hist_dirty = false;
+            }
             return RLR_OK;
         }
     }
@@ -756,6 +762,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
         std::memcpy(h_q + static_cast<size_t>(q) * ix->q_pitch, queries + static_cast<size_t>(q) * ix->dim,
                     ix->dim * sizeof(float));
     hipStream_t s = c->stream;
+    c->hist_dirty = true; // cleared when every enqueued pipeline has run to its histogram-clearing stage
     RLR_HIP(hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s));
 
     const bool timed = ix->profiling;
@@ -791,6 +798,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
         }
         RLR_TRY(fetch_results(0, n_res));
         RLR_HIP(hipStreamSynchronize(s));
+        c->hist_dirty = false;
         if (h_results)
             *h_results = h_res;
         std::lock_guard<std::mutex> lk(ix->mu);
@@ -836,6 +844,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     }
     if (refetch)
         RLR_HIP(hipStreamSynchronize(s));
+    c->hist_dirty = false;
     if (h_results)
         *h_results = h_res;
     {
