@@ -13,6 +13,7 @@
 #include "../../include/rlr_gpu.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace rlr {
 
@@ -406,6 +407,97 @@ __global__ __launch_bounds__(64) void gram_kernel(const float *__restrict__ pool
     gram[static_cast<size_t>(j) * P + i] = s;
 }
 
+// Tiled Gram: a workgroup owns a 32 x 32 block of pairs (lower triangle of blocks only), stages
+// 64-column chunks of the 32 + 32 rows in LDS with coalesced loads, and every thread carries four
+// pairs (rows {ty, ty+16} x {tx, tx+16}: conflict-free LDS rows at a 68-float pitch) through the
+// chunks in ascending k, so each sum is still the reference's strict left-to-right chain.  Reads
+// each pool row 2 x ceil(P/32) times from L2 instead of P times: 27 -> ~8 us per 300-row pool and
+// ~5x on the batched MMR.
+constexpr int kGT = 32;      // pairs per block side
+constexpr int kGK = 64;      // columns per staged chunk
+constexpr int kGPitch = 68;  // floats
+
+__global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict__ pool, uint32_t P, uint32_t dim,
+                                                         float *__restrict__ gram)
+{
+    __shared__ __attribute__((aligned(16))) float sa[kGT * kGPitch];
+    __shared__ __attribute__((aligned(16))) float sb[kGT * kGPitch];
+    pool += static_cast<size_t>(blockIdx.z) * P * dim;
+    gram += static_cast<size_t>(blockIdx.z) * P * P;
+    // linear block id -> (bi >= bj) in the lower triangle
+    uint32_t bi = 0, rem = blockIdx.x;
+    while (rem > bi) {
+        rem -= bi + 1;
+        ++bi;
+    }
+    const uint32_t bj = rem;
+    const uint32_t i0 = bi * kGT, j0 = bj * kGT;
+    const uint32_t t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    float acc00 = 0.0f, acc01 = 0.0f, acc10 = 0.0f, acc11 = 0.0f;
+    const bool vec = (dim & 3u) == 0;
+    for (uint32_t k0 = 0; k0 < dim; k0 += kGK) {
+        const uint32_t kc = min(static_cast<uint32_t>(kGK), dim - k0);
+        // stage: 64 rows x kc columns; 16 threads per row, float4 each when dim % 4 == 0
+        for (uint32_t idx = t; idx < 2 * kGT * (kGK / 4); idx += 256) {
+            const uint32_t r = idx / (kGK / 4), c4 = idx % (kGK / 4);
+            const bool is_b = r >= kGT;
+            const uint32_t row = (is_b ? j0 + (r - kGT) : i0 + r);
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (row < P && c4 * 4 < kc) {
+                const float *src = pool + static_cast<size_t>(row) * dim + k0 + c4 * 4;
+                if (vec) {
+                    v = *reinterpret_cast<const float4 *>(src);
+                } else {
+                    v.x = src[0];
+                    if (c4 * 4 + 1 < kc) v.y = src[1];
+                    if (c4 * 4 + 2 < kc) v.z = src[2];
+                    if (c4 * 4 + 3 < kc) v.w = src[3];
+                }
+            }
+            float *dst = (is_b ? sb + (r - kGT) * kGPitch : sa + r * kGPitch) + c4 * 4;
+            *reinterpret_cast<float4 *>(dst) = v;
+        }
+        __syncthreads();
+        const float4 *a0 = reinterpret_cast<const float4 *>(sa + ty * kGPitch);
+        const float4 *a1 = reinterpret_cast<const float4 *>(sa + (ty + 16) * kGPitch);
+        const float4 *b0 = reinterpret_cast<const float4 *>(sb + tx * kGPitch);
+        const float4 *b1 = reinterpret_cast<const float4 *>(sb + (tx + 16) * kGPitch);
+        const uint32_t n4 = kc / 4;
+        for (uint32_t c = 0; c < n4; ++c) {
+            const float4 xa = a0[c], xb = a1[c], ya = b0[c], yb = b1[c];
+            float p;
+            p = xa.x * ya.x; acc00 = acc00 + p;  p = xa.y * ya.y; acc00 = acc00 + p;
+            p = xa.z * ya.z; acc00 = acc00 + p;  p = xa.w * ya.w; acc00 = acc00 + p;
+            p = xa.x * yb.x; acc01 = acc01 + p;  p = xa.y * yb.y; acc01 = acc01 + p;
+            p = xa.z * yb.z; acc01 = acc01 + p;  p = xa.w * yb.w; acc01 = acc01 + p;
+            p = xb.x * ya.x; acc10 = acc10 + p;  p = xb.y * ya.y; acc10 = acc10 + p;
+            p = xb.z * ya.z; acc10 = acc10 + p;  p = xb.w * ya.w; acc10 = acc10 + p;
+            p = xb.x * yb.x; acc11 = acc11 + p;  p = xb.y * yb.y; acc11 = acc11 + p;
+            p = xb.z * yb.z; acc11 = acc11 + p;  p = xb.w * yb.w; acc11 = acc11 + p;
+        }
+        for (uint32_t e = n4 * 4; e < kc; ++e) { // dim % 4 tail
+            const float xa = sa[ty * kGPitch + e], xb = sa[(ty + 16) * kGPitch + e];
+            const float ya = sb[tx * kGPitch + e], yb = sb[(tx + 16) * kGPitch + e];
+            float p;
+            p = xa * ya; acc00 = acc00 + p;
+            p = xa * yb; acc01 = acc01 + p;
+            p = xb * ya; acc10 = acc10 + p;
+            p = xb * yb; acc11 = acc11 + p;
+        }
+        __syncthreads();
+    }
+    const uint32_t ri[2] = {i0 + ty, i0 + ty + 16}, cj[2] = {j0 + tx, j0 + tx + 16};
+    const float v[2][2] = {{acc00, acc01}, {acc10, acc11}};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if (ri[a] < P && cj[b] < P) {
+                gram[static_cast<size_t>(ri[a]) * P + cj[b]] = v[a][b];
+                gram[static_cast<size_t>(cj[b]) * P + ri[a]] = v[a][b]; // dot(i,j) == dot(j,i) bitwise
+            }
+}
+
 __device__ inline bool finite_f(float x)
 {
     return (__builtin_bit_cast(uint32_t, x) & 0x7F800000u) != 0x7F800000u;
@@ -772,7 +864,13 @@ hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram,
 {
     if (P == 0 || n_queries == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(gram_kernel, dim3((P + 63) / 64, P, n_queries), dim3(64), 0, s, pool, P, dim, gram);
+    static const bool naive = getenv("RLR_GRAM_NAIVE") != nullptr;
+    if (naive) {
+        hipLaunchKernelGGL(gram_kernel, dim3((P + 63) / 64, P, n_queries), dim3(64), 0, s, pool, P, dim, gram);
+        return hipGetLastError();
+    }
+    const uint32_t nb = (P + kGT - 1) / kGT;
+    hipLaunchKernelGGL(gram_tiled_kernel, dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim, gram);
     return hipGetLastError();
 }
 
