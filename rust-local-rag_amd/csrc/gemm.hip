@@ -28,6 +28,8 @@
 #include "kernels.h"
 #include "../../include/rlr_gpu.h"
 
+#include <cstdlib>
+
 namespace rlr {
 
 namespace {
@@ -320,9 +322,80 @@ __global__ __launch_bounds__(256) void build_image_kernel(const unsigned char *_
     }
 }
 
-// GEMM over the image: a four-slot register ring of A fragments per wave (16 VGPRs per chunk),
-// every chunk requested three MFMA phases before use, all loads lane-linear; branch-free loop
-// (past the end the last chunk is fetched again, never used).
+// GEMM over the image.  Wave tile = 64 rows x 128 queries (wave w: rows 64*(w/2).., queries
+// 128*(w%2)..): the same 32 accumulator tiles as a 32 x 256 wave tile, but a K-step needs 8 B
+// fragments from LDS instead of 16 (LDS fragment latency, not bandwidth, paces this kernel: MFMA
+// pipe 31 % busy with 16), and 4 A fragments which come straight from the image (lane-linear 1 KiB
+// loads; the two waves that share rows hit L1/L2 on the second read).  A fragments rotate through
+// two register slots (the slot a phase has just consumed is refilled with the chunk after next),
+// B fragments are read two steps ahead; every workgroup walks the K-chunks in its own rotation so
+// the 256 CUs do not all read the same lines of the shared query image at once (-3 %).
+// Timing ablations of this kernel (256 queries x 10M x 768, 5.7 ms): without the per-phase B
+// (query chunk) global->LDS staging and barrier 3.4 ms, without the barrier alone 5.3 ms, without
+// the A (row) loads 5.1 ms; staging B with global_load_lds instead of registers: 5.7 ms.  The query
+// chunk re-read per 256-row tile (32 KB per phase, as many bytes as the rows themselves) is the
+// cost to attack next (larger row tile per staged chunk).
+// the loop is branch-free (past the end the last chunk is fetched again, never used).
+constexpr int kRGI = 4;          // row groups per wave in the image kernel
+constexpr int kNBI = kNB / 2;    // query column blocks per wave
+
+template <bool MATERIALISE>
+__device__ __forceinline__ void gemm_image_epilogue(const GemmArgs &a, f32x4 (&acc)[kRGI][kNBI], uint32_t row0,
+                                                    uint32_t last_row, uint32_t q0, int lane)
+{
+    const uint32_t qcol = q0 + (lane & 15);
+    if constexpr (MATERIALISE) {
+#pragma unroll
+        for (int rg = 0; rg < kRGI; ++rg) {
+            const uint32_t r = row0 + rg * 16 + 4 * (lane >> 4);
+            const uint32_t rel = r - a.row_begin;
+#pragma unroll
+            for (int nb = 0; nb < kNBI; ++nb) {
+                const uint32_t q = qcol + nb * 16;
+                if (q >= a.n_queries)
+                    continue;
+                float *dst = a.scores + static_cast<size_t>(q) * a.score_stride + rel;
+                const f32x4 v = acc[rg][nb];
+                if (r + 3 <= last_row) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (r + i <= last_row)
+                            dst[i] = v[i];
+                }
+            }
+        }
+    } else {
+        float tau_l[kNBI];
+#pragma unroll
+        for (int nb = 0; nb < kNBI; ++nb) {
+            const uint32_t q = qcol + nb * 16;
+            tau_l[nb] = q < a.n_queries ? a.tau[q] : __builtin_inff();
+        }
+#pragma unroll
+        for (int rg = 0; rg < kRGI; ++rg) {
+            const uint32_t r = row0 + rg * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int nb = 0; nb < kNBI; ++nb) {
+                const f32x4 v = acc[rg][nb];
+                const float t = tau_l[nb];
+                if (v[0] >= t || v[1] >= t || v[2] >= t || v[3] >= t) {
+                    const uint32_t q = qcol + nb * 16;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (v[i] >= t && r + i <= last_row) {
+                            const uint32_t slot = atomicAdd(&a.st[q].n_cand, 1u);
+                            if (slot < a.st[q].cap)
+                                a.cand[static_cast<size_t>(q) * a.cand_stride + slot] = pack_result(v[i], r + i);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool MATERIALISE>
 __global__ __launch_bounds__(512) void gemm_image_kernel(const GemmArgs a, const half8 *__restrict__ image)
 {
@@ -331,88 +404,94 @@ __global__ __launch_bounds__(512) void gemm_image_kernel(const GemmArgs a, const
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wq = wave & 1;
     const uint32_t bid = blockIdx.x;
     const uint32_t rt = (bid / (8 * a.n_qblocks)) * 8 + (bid & 7); // tile index relative to row_begin
     const uint32_t qb = (bid >> 3) % a.n_qblocks;
     const uint32_t n_rows = a.row_end - a.row_begin;
     if (rt * kBM >= n_rows)
         return;
-    const uint32_t row0 = a.row_begin + rt * kBM + wave * (kRG * 16);
+    const uint32_t row0 = a.row_begin + rt * kBM + wr * (kRGI * 16);
     const uint32_t last_row = a.row_end - 1;
-    const uint32_t n_chunks = a.n_ksteps / kKsChunk; // multiple of 4
+    const uint32_t n_chunks = a.n_ksteps / kKsChunk;
     const uint32_t tile = a.row_begin / kBM + rt;     // row_begin is a multiple of 256
-    // this wave's fragments of chunk c: image[((tile*n_chunks + c)*8 + wave)*4 + rg*2 + ks][lane]
-    const half8 *ap = image + (static_cast<size_t>(tile) * n_chunks * 8 + wave) * 4 * 64 + lane;
+    // rows 64*wr + 16*rg + r of the tile are image wave (2*wr + rg/2), row group rg % 2:
+    //   image[(((tile*n_chunks + c)*8 + 2*wr + rg/2)*2 + rg%2)*2 + ks][lane]  ==  base + c*2048 + (rg*2 + ks)*64
+    const half8 *ap = image + (static_cast<size_t>(tile) * n_chunks * 8 + 2 * wr) * 4 * 64 + lane;
     const half8 *bsrc = a.qfrag + static_cast<size_t>(qb) * a.n_ksteps * kNB * 64;
 
-    f32x4 acc[kRG][kNB];
+    f32x4 acc[kRGI][kNBI];
 #pragma unroll
-    for (int rg = 0; rg < kRG; ++rg)
+    for (int rg = 0; rg < kRGI; ++rg)
 #pragma unroll
-        for (int nb = 0; nb < kNB; ++nb)
+        for (int nb = 0; nb < kNBI; ++nb)
             acc[rg][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     half8 breg[4];
-    half8 ring[4][kRG][kKsChunk];
+    half8 ring[2][kRGI][kKsChunk];
 
 #define RLR_LOAD_B(CHUNK)                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) breg[i] = bsrc[static_cast<size_t>(CHUNK) * kChunkFrags + tid + 512 * i]
 #define RLR_STORE_B(BUF) _Pragma("unroll") for (int i = 0; i < 4; ++i) s_b[BUF][tid + 512 * i] = breg[i]
 #define RLR_LOAD_A(CHUNK, SLOT)                                                                    \
-    _Pragma("unroll") for (int rg = 0; rg < kRG; ++rg) _Pragma("unroll") for (int ks = 0; ks < kKsChunk; ++ks) \
+    _Pragma("unroll") for (int rg = 0; rg < kRGI; ++rg) _Pragma("unroll") for (int ks = 0; ks < kKsChunk; ++ks) \
         ring[SLOT][rg][ks] = ap[static_cast<size_t>(CHUNK) * (8 * 4 * 64) + (rg * 2 + ks) * 64]
-// B fragments are read two steps ahead into a rotating set of four registers: the LDS latency
-// of fragment f+2 overlaps the MFMAs of fragment f (hipcc otherwise re-uses two registers and
-// waits on every pair).  sched_group_barrier pins the 1 ds_read : 2 MFMA interleave.
+// B fragments two steps ahead in a rotating set of four registers; 1 ds_read : 4 MFMA interleave
 #define RLR_COMPUTE(BUF, SLOT)                                                                     \
     do {                                                                                           \
-        const half8 *sb = s_b[BUF] + lane;                                                         \
+        const half8 *sb = s_b[BUF] + wq * (kNBI * 64) + lane;                                      \
         half8 bq[4];                                                                               \
         bq[0] = sb[0];                                                                             \
         bq[1] = sb[64];                                                                            \
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                         \
-        _Pragma("unroll") for (int f = 0; f < kKsChunk * kNB; ++f)                                  \
+        _Pragma("unroll") for (int f = 0; f < kKsChunk * kNBI; ++f)                                 \
         {                                                                                          \
-            if (f + 2 < kKsChunk * kNB) {                                                          \
-                bq[(f + 2) & 3] = sb[(f + 2) * 64];                                                \
+            if (f + 2 < kKsChunk * kNBI) {                                                         \
+                bq[(f + 2) & 3] = sb[((f + 2) / kNBI) * (kNB * 64) + ((f + 2) % kNBI) * 64];        \
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
             }                                                                                      \
-            _Pragma("unroll") for (int rg = 0; rg < kRG; ++rg) acc[rg][f % kNB] =                   \
-                __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[SLOT][rg][f / kNB], bq[f & 3], acc[rg][f % kNB], 0, 0, 0); \
-            __builtin_amdgcn_sched_group_barrier(0x008, kRG, 0);                                   \
+            _Pragma("unroll") for (int rg = 0; rg < kRGI; ++rg) acc[rg][f % kNBI] =                 \
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[SLOT][rg][f / kNBI], bq[f & 3], acc[rg][f % kNBI], 0, 0, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x008, kRGI, 0);                                  \
         }                                                                                          \
     } while (0)
-#define RLR_PHASE(U)                                                                               \
+// OFF = phase offset inside the two-phase iteration (c is even, so the A slot and the B buffer of
+// chunk c + OFF are both OFF & 1 -- compile-time constants)
+#define RLR_ROT(X) (((X) + c_rot) % n_chunks)
+#define RLR_PHASE(OFF)                                                                             \
     do {                                                                                           \
-        const uint32_t cc = c + (U);                                                               \
-        RLR_LOAD_A(min(cc + 3, last_c), ((U) + 3) & 3);                                            \
-        RLR_LOAD_B(min(cc + 1, last_c));                                                           \
+        const uint32_t cc = c + (OFF);                                                             \
+        RLR_LOAD_B(RLR_ROT(min(cc + 1, last_c)));                                                  \
         __builtin_amdgcn_sched_barrier(0); /* do not sink the loads below the MFMAs */             \
-        RLR_COMPUTE((U) & 1, (U));                                                                 \
-        RLR_STORE_B(((U) + 1) & 1);                                                                \
+        RLR_COMPUTE((OFF) & 1, (OFF) & 1);                                                         \
+        /* the slot just consumed takes chunk cc + 2: one full phase of lookahead for it */        \
+        RLR_LOAD_A(RLR_ROT(min(cc + 2, last_c)), (OFF) & 1);                                       \
+        RLR_STORE_B(((OFF) & 1) ^ 1);                                                              \
         __syncthreads();                                                                           \
     } while (0)
 
     const uint32_t last_c = n_chunks - 1;
-    RLR_LOAD_A(0, 0);
-    RLR_LOAD_A(1, 1);
-    RLR_LOAD_A(2, 2);
-    RLR_LOAD_B(0);
+    // every workgroup walks the K-chunks in a rotated order, so that at any moment the 256 CUs read
+    // different chunks of the (shared, L2-resident) query image instead of all hitting the same lines
+    const uint32_t c_rot = (bid * 5u) % n_chunks;
+    RLR_LOAD_A(RLR_ROT(0), 0);
+    RLR_LOAD_A(RLR_ROT(1), 1);
+    RLR_LOAD_B(RLR_ROT(0));
     RLR_STORE_B(0);
     __syncthreads();
+    // loads past the last chunk are clamped re-fetches of it (never used); n_chunks is even
 #pragma unroll 1
-    for (uint32_t c = 0; c < n_chunks; c += 4) {
+    for (uint32_t c = 0; c < n_chunks; c += 2) {
         RLR_PHASE(0);
         RLR_PHASE(1);
-        RLR_PHASE(2);
-        RLR_PHASE(3);
     }
 #undef RLR_PHASE
+#undef RLR_ROT
 #undef RLR_COMPUTE
 #undef RLR_LOAD_A
 #undef RLR_STORE_B
 #undef RLR_LOAD_B
-    gemm_epilogue<MATERIALISE>(a, acc, row0, last_row, qb, lane);
+    gemm_image_epilogue<MATERIALISE>(a, acc, row0, last_row, qb * kQB + wq * (kNBI * 16), lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -560,10 +639,11 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
     const uint32_t grid = ((n_rt + 7) / 8) * 8 * a.n_qblocks;
     const bool mat = scores != nullptr;
     if (image && row_begin % kBM == 0 && (a.n_ksteps / kKsChunk) % 4 == 0) {
+        const half8 *img = static_cast<const half8 *>(image);
         if (mat)
-            hipLaunchKernelGGL((gemm_image_kernel<true>), dim3(grid), dim3(512), 0, s, a, static_cast<const half8 *>(image));
+            hipLaunchKernelGGL((gemm_image_kernel<true>), dim3(grid), dim3(512), 0, s, a, img);
         else
-            hipLaunchKernelGGL((gemm_image_kernel<false>), dim3(grid), dim3(512), 0, s, a, static_cast<const half8 *>(image));
+            hipLaunchKernelGGL((gemm_image_kernel<false>), dim3(grid), dim3(512), 0, s, a, img);
         return hipGetLastError();
     }
     if (dtype == RLR_F16) {
