@@ -137,9 +137,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: librlr_gpu.so has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("RLR_BENCH_FORCE_DIST") == "1"  # rehearse RCCL init + all-gather with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     sharded = importlib.import_module("rust-local-rag_amd.sharded")
 
@@ -165,7 +171,7 @@ def main():
     if args.image:
         ix.enable_batch_image(True)
 
-    force_sharded = os.environ.get("RLR_BENCH_FORCE_SHARDED") == "1"  # rehearse the N>1 code path on one GPU
+    force_sharded = os.environ.get("RLR_BENCH_FORCE_SHARDED") == "1" or force_dist  # rehearse the N>1 code path on one GPU
 
     def step(i):
         if world == 1 and not force_sharded:

@@ -19,6 +19,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 import ctypes as C
+import os
 
 from . import _native as N
 from .index import GpuIndex, _f32
@@ -122,7 +123,7 @@ class ShardedIndex:
             self._gath = torch.zeros((self.world, nq, k), dtype=torch.int64, device=self.dev)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         self.index.search_topk_device(q, k, self._local.data_ptr(), stream)
-        if self.world > 1:
+        if self.world > 1 or (self.dist is not None and os.environ.get("RLR_BENCH_FORCE_DIST") == "1"):
             # the exchange step: world x k x 8 B per query over xGMI (RCCL all-gather)
             self.dist.all_gather_into_tensor(self._gath.view(self.world * nq, k), self._local, group=self.group)
             gathered = self._gath
