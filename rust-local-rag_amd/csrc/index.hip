@@ -149,15 +149,6 @@ int32_t grow(T **p, uint64_t *cap, uint64_t want, bool keep = false)
     return RLR_OK;
 }
 
-template <typename T>
-int32_t grow32(T **p, uint32_t *cap, uint32_t want)
-{
-    uint64_t c = *cap;
-    int32_t s = grow(p, &c, want);
-    *cap = static_cast<uint32_t>(c);
-    return s;
-}
-
 int32_t pin_reserve(Ctx *c, size_t bytes)
 {
     if (c->h_pin_bytes >= bytes)

@@ -7,10 +7,6 @@
 
 namespace rlr {
 
-struct DeviceInfo {
-    int n_cu = 256;
-};
-
 // ---- scan.hip : wavefront-order candidate scan (HBM-bound) ----------------
 struct ScanArgs {
     const void *rows;     // n_rows x pitch16 x 16 B, row-major
@@ -25,7 +21,6 @@ struct ScanArgs {
     int variant;          // tuning knob, 0 = default
 };
 hipError_t launch_scan(const ScanArgs &a, hipStream_t stream);
-const char *scan_kernel_name(const ScanArgs &a);
 
 // ---- select.hip : radix select / collect / sort -------------------------
 // Selection state kept on the device between the stages of one query.
@@ -39,11 +34,6 @@ struct SelectState {
     uint32_t cap;        // in : candidate buffer capacity
     uint32_t pad;
 };
-hipError_t launch_hist1(const float *scores, uint32_t n, uint32_t *hist1, int n_cu, hipStream_t s);
-hipError_t launch_find1(const uint32_t *hist1, SelectState *st, hipStream_t s);
-hipError_t launch_hist2(const float *scores, uint32_t n, const SelectState *st, uint32_t *hist2,
-                        int n_cu, hipStream_t s);
-hipError_t launch_find2(const uint32_t *hist2, SelectState *st, float two_eps, hipStream_t s);
 hipError_t launch_collect(const float *scores, uint32_t n, SelectState *st, uint32_t *cand,
                           int n_cu, hipStream_t s);
 // single-query pipeline: bin searches folded into the kernels that need them

@@ -317,12 +317,6 @@ bool fixed_shape(const ScanArgs &a, int *ch)
 
 } // namespace
 
-const char *scan_kernel_name(const ScanArgs &a)
-{
-    int ch;
-    return fixed_shape(a, &ch) ? "scan_fixed_kernel" : "scan_generic_kernel";
-}
-
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
 {
     if (a.n_rows == 0)

@@ -371,13 +371,6 @@ uint32_t sel_blocks(uint32_t n, int n_cu)
 
 } // namespace
 
-hipError_t launch_hist1(const float *scores, uint32_t n, uint32_t *hist1, int n_cu, hipStream_t s)
-{
-    hipLaunchKernelGGL(hist1_kernel, dim3(sel_blocks(n, n_cu)), dim3(kSelThreads), 0, s, scores, n,
-                       hist1, size_t(0), 0u);
-    return hipGetLastError();
-}
-
 // Batched two-pass select over q_count score rows of length n (stride score_stride):
 // leaves key_lo / tau per query and the sample's candidates in cand[q][...].
 hipError_t launch_batch_select(const float *scores, uint32_t n, size_t score_stride, uint32_t q_count,
@@ -396,27 +389,6 @@ hipError_t launch_batch_select(const float *scores, uint32_t n, size_t score_str
     hipLaunchKernelGGL(find2_kernel, dim3(q_count), dim3(kSelThreads), 0, s, hist + kHistBins, st, two_eps, hs, tau_out);
     hipLaunchKernelGGL(collect_packed_kernel, dim3(bx, q_count), dim3(kSelThreads), 0, s, scores, n, st, cand,
                        score_stride, cand_stride);
-    return hipGetLastError();
-}
-
-hipError_t launch_find1(const uint32_t *hist1, SelectState *st, hipStream_t s)
-{
-    hipLaunchKernelGGL(find1_kernel, dim3(1), dim3(kSelThreads), 0, s, hist1, st, 0u);
-    return hipGetLastError();
-}
-
-hipError_t launch_hist2(const float *scores, uint32_t n, const SelectState *st, uint32_t *hist2,
-                        int n_cu, hipStream_t s)
-{
-    hipLaunchKernelGGL(hist2_kernel, dim3(sel_blocks(n, n_cu)), dim3(kSelThreads), 0, s, scores, n,
-                       st, hist2, size_t(0), 0u);
-    return hipGetLastError();
-}
-
-hipError_t launch_find2(const uint32_t *hist2, SelectState *st, float two_eps, hipStream_t s)
-{
-    hipLaunchKernelGGL(find2_kernel, dim3(1), dim3(kSelThreads), 0, s, hist2, st, two_eps, 0u,
-                       static_cast<float *>(nullptr));
     return hipGetLastError();
 }
 
