@@ -1,0 +1,47 @@
+"""The C ABI from plain C: examples/search_demo.c is compiled with gcc against include/*.h and
+librlr_gpu.so (CPU: it must compile and link; GPU: it must print the Python binding's results)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _build(tmp_path):
+    exe = os.path.join(str(tmp_path), "search_demo")
+    lib_dir = os.path.join(ROOT, "rust-local-rag_amd")
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "search_demo.c"), "-L", lib_dir, "-lrlr_gpu", "-lm",
+           f"-Wl,-rpath,{lib_dir}", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_demo_compiles_and_links_against_the_headers(rlr, tmp_path, gpu_available):
+    exe = _build(tmp_path)
+    if not gpu_available:
+        r = subprocess.run([exe, "1000"], capture_output=True, text=True)
+        assert r.returncode == 2 and "no CPU path" in r.stderr   # fails loudly without a GPU
+
+
+@pytest.mark.gpu
+def test_demo_output_matches_python_binding(rlr, tmp_path):
+    exe = _build(tmp_path)
+    n, dim, k = 50_000, 768, 7
+    out = subprocess.run([exe, str(n), str(dim), str(k)], capture_output=True, text=True, check=True).stdout
+    s_rows = [(int(l.split()[1]), np.float32(l.split()[2])) for l in out.splitlines() if l.startswith("S ")]
+    d_rows = [(int(l.split()[1]), np.float32(l.split()[2])) for l in out.splitlines() if l.startswith("D ")]
+    eng = rlr.RagEngine(dim)
+    eng.index.fill_synthetic(n, seed=0x5EED0003, n_clusters=32)
+    eng._chunks = [rlr.DocumentChunk(str(i), "synthetic", "", i) for i in range(n)]
+    i = np.arange(dim, dtype=np.float32)
+    q = (np.sin(np.float32(0.37) * i) + np.float32(0.25) * np.cos(np.float32(0.11) * i)).astype(np.float32)
+    # sinf/cosf of libm vs numpy may differ in the last bit of the *query*; compare rows, scores loosely
+    got_s = eng.search(q, k)
+    got_d = eng.search_with_diversity(q, k, 0.3)
+    assert [r for r, _ in s_rows] == [g.row for g in got_s]
+    assert [r for r, _ in d_rows] == [g.row for g in got_d]
+    assert np.allclose([s for _, s in s_rows], [g.score for g in got_s], atol=1e-6)
+    eng.close()
