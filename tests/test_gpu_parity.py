@@ -546,3 +546,45 @@ def test_multi_index_three_shards_on_one_gpu(rlr, oracle):
         wr, wc = oracle_topk(oracle, rows, qb[i], 10)
         assert np.array_equal(rb[i], wr) and np.array_equal(bits(cb[i]), bits(wc))
     mi.close()
+
+
+# ---------------------------------------------------------------- rarely taken paths
+def test_multi_query_band_overflow_rescans(rlr, oracle):
+    """fewer than 16 queries (looped single-query pipeline) where one query's band overflows:
+    the large-candidate path has to re-scan because the score buffer holds a later query."""
+    base = oracle.synth_rows(3000, 768, seed=801)
+    q0 = oracle.synth_query(768, seed=802)
+    dup = oracle.normalize(q0 + np.float32(0.01) * base[0])
+    rows = np.concatenate([base, np.repeat(dup[None, :], 5000, axis=0)])
+    qs = np.stack([oracle.normalize(q0)] + [oracle.normalize(oracle.synth_query(768, seed=810 + i)) for i in range(4)])
+    ix = make_index(rlr, rows)
+    r, c = ix.search_topk(qs, 12)
+    for i in range(5):
+        wr, wc = oracle_topk(oracle, rows, qs[i], 12)
+        assert np.array_equal(r[i], wr) and np.array_equal(bits(c[i]), bits(wc)), i
+    assert ix.profile_read().n_retries >= 1
+    ix.close()
+
+
+def test_k_larger_than_the_lds_sort(rlr, oracle):
+    rows = oracle.synth_rows(12000, 256, seed=803)
+    qn = oracle.normalize(oracle.synth_query(256, seed=804))
+    ix = make_index(rlr, rows)
+    r, c = ix.search_topk(qn, 5000)          # > 4096: global-memory bitonic path
+    wr, wc = oracle_topk(oracle, rows, qn, 5000)
+    assert np.array_equal(r[0], wr) and np.array_equal(bits(c[0]), bits(wc))
+    ix.close()
+
+
+@pytest.mark.parametrize("dim", [200, 72, 1536])
+def test_fp16_rows_generic_dims(rlr, oracle, dim):
+    rows = oracle.synth_rows(2500, dim, seed=805 + dim, f16=True)
+    qn = oracle.normalize(oracle.synth_query(dim, seed=806))
+    ix = rlr.GpuIndex(dim, "f16")
+    ix.reserve(5000)
+    ix.upload(oracle.synth_rows(2500, dim, seed=805 + dim))
+    r, c = ix.search_topk(qn, 33)
+    wr, wc = oracle_topk(oracle, rows, qn, 33)
+    assert np.array_equal(r[0], wr) and np.array_equal(bits(c[0]), bits(wc))
+    assert np.array_equal(bits(ix.fetch_rows(wr[:5])), bits(rows[wr[:5].astype(np.int64)]))
+    ix.close()
