@@ -21,9 +21,10 @@ _u32p = C.POINTER(C.c_uint32)
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "rlr_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE])
+    """Build the checker if it is missing (a shipped .so is used as is: file times do not survive a
+    snapshot copy, and several processes must never race each other through `make`)."""
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-s", "-B" if force else "-s", "-C", _HERE])
     return _SO
 
 
