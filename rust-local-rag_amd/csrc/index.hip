@@ -464,6 +464,23 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
     }
     atomicAdd(&s_valid, valid);
     __syncthreads();
+    if (n_pad <= 1024) {
+        // rank sort: the keys are unique (global row in the low word); padding zeros keep their place
+        __shared__ uint64_t s_sorted[1024];
+        for (uint32_t i = threadIdx.x; i < n_pad; i += 256) {
+            const uint64_t mine = s[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n_pad; ++j) {
+                const uint64_t o = s[j];
+                rank += (o > mine) || (o == mine && j < i);
+            }
+            s_sorted[rank] = mine;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_pad; i += 256)
+            s[i] = s_sorted[i];
+        __syncthreads();
+    } else
     for (uint32_t kk = 2; kk <= n_pad; kk <<= 1) {
         for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
             for (uint32_t i = threadIdx.x; i < n_pad; i += 256) {
@@ -798,9 +815,10 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
         return RLR_OK;
     }
 
-    if (!timed) {
+    if (!timed || nq == 1) {
+        // (with profiling on, a single query's four events are read after the one final sync)
         for (uint32_t q = 0; q < nq; ++q)
-            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, d_meta + q, false));
+            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, d_meta + q, timed));
     } else {
         // one query at a time so the four events can be read back per query
         for (uint32_t q = 0; q < nq; ++q) {
@@ -821,6 +839,16 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     else
         RLR_HIP(hipMemcpyAsync(h_meta, d_meta, nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     RLR_HIP(hipStreamSynchronize(s));
+    if (timed && nq == 1) {
+        float a = 0, b = 0, d = 0;
+        RLR_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+        RLR_HIP(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+        RLR_HIP(hipEventElapsedTime(&d, c->ev[2], c->ev[3]));
+        scan_ms += a;
+        select_ms += b;
+        rescore_ms += d;
+        total_ms += a + b + d;
+    }
     // band overflow -> large-candidate path (rare: massive exact ties, or k > 4096)
     bool refetch = false;
     for (uint32_t q = 0; q < nq; ++q) {

@@ -121,6 +121,9 @@ class ShardedIndex:
         if self._local is None or self._local.shape != (nq, k):
             self._local = torch.zeros((nq, k), dtype=torch.int64, device=self.dev)
             self._gath = torch.zeros((self.world, nq, k), dtype=torch.int64, device=self.dev)
+            self._rows_h = np.zeros((nq, k), dtype=np.uint64)
+            self._cos_h = np.zeros((nq, k), dtype=np.float32)
+            self._n_h = np.zeros(nq, dtype=np.uint32)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         self.index.search_topk_device(q, k, self._local.data_ptr(), stream)
         if self.world > 1 or (self.dist is not None and os.environ.get("RLR_BENCH_FORCE_DIST") == "1"):
@@ -130,11 +133,9 @@ class ShardedIndex:
         else:
             gathered = self._local
         # merge on the GPU in one launch (rlr_merge_topk), results land in pinned host memory
-        rows_h = np.zeros((nq, k), dtype=np.uint64)
-        cos_h = np.zeros((nq, k), dtype=np.float32)
-        n_h = np.zeros(nq, dtype=np.uint32)
+        rows_h, cos_h, n_h = self._rows_h, self._cos_h, self._n_h
         N.check(N.lib().rlr_merge_topk(self.dev.index, C.c_void_p(gathered.data_ptr()), self.world, nq, k,
                                        self._bases_h.ctypes.data_as(N.u64p), rows_h.ctypes.data_as(N.u64p),
                                        cos_h.ctypes.data_as(N.f32p), n_h.ctypes.data_as(N.u32p), C.c_void_p(stream)))
         n_valid = int(n_h[0]) if nq else 0
-        return rows_h[:, :n_valid].astype(np.int64), cos_h[:, :n_valid]
+        return rows_h[:, :n_valid].astype(np.int64), cos_h[:, :n_valid].copy()
