@@ -47,6 +47,8 @@ def parse():
                     help="do not record HIP events in the timed region (roofline fields become null)")
     ap.add_argument("--image", action="store_true",
                     help="keep the binary16 nomination image for the batched path (rlr_index_enable_batch_image)")
+    ap.add_argument("--settle-ms", type=float, default=500.0,
+                    help="untimed clock/power settle phase before the warmup steps (0 disables)")
     ap.add_argument("--batch", type=int, default=1,
                     help="queries per step; >= 16 takes the matrix-core (MFMA) batched path (BASELINE config 3 uses 256)")
     return ap.parse_args()
@@ -174,6 +176,15 @@ def main():
             return ix.search_topk(qs[i], args.k)
         return sh.search_topk(qs[i], args.k)
 
+    # Untimed settle phase before the W warmup steps.  Two things are kept out of the timed region:
+    # (1) a cold GPU needs some hundred ms of work before clocks / HBM power state are at their sustained
+    # level; (2) the HIP runtime grows its per-queue launch resources once, about 200 searches (~1000
+    # kernel launches) into a process, which stalls that one call for 30-40 ms (measured with
+    # scratch/step_jitter.py: call 206 at every corpus size, never again afterwards).
+    t_settle, n_settle = time.perf_counter(), 0
+    while args.settle_ms > 0 and ((time.perf_counter() - t_settle) * 1e3 < args.settle_ms or n_settle < 256):
+        step(0)
+        n_settle += 1
     for i in range(args.warmup):
         step(i)
 
