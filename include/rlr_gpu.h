@@ -165,6 +165,18 @@ int32_t rlr_mmr_select_batch(rlr_index *idx, const uint64_t *pool_rows, const fl
  *                 null stream); the library makes its work visible to that stream. */
 int32_t rlr_search_topk_device(rlr_index *idx, const float *queries, uint32_t n_queries,
                                uint32_t k, float guard_eps, void *d_packed_out, void *stream);
+/* The winner-row exchange of sharded MMR: rows of this shard as f32 values in
+ * DEVICE memory (`d_out`, n x dim floats, dense), ready to be handed to an RCCL all-to-all.
+ * Returns after the gather has finished.  replaces: the embedding re-lookup rag_engine.rs:742-753
+ * for rows that live on this GPU. */
+int32_t rlr_fetch_rows_device(rlr_index *idx, const uint64_t *rows, uint32_t n, void *d_out);
+/* rlr_mmr_select_batch for pools whose row VALUES are already in device memory (after the
+ * exchange): d_values is n_queries x P x dim f32 on idx's device, complete before the call
+ * (synchronise the stream that produced it).  `idx` supplies the device, dim and workspace; its
+ * rows are not read.  Everything else as rlr_mmr_select_batch. */
+int32_t rlr_mmr_select_values(rlr_index *idx, const void *d_values, const float *pool_scores,
+                              const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k,
+                              float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out);
 /* The exchange step's merge: `d_gathered` is the all-gathered buffer, world x n_queries x k packed
  * u64 (rank-major), on device `device_id`; bases[r] = first global row of rank r's shard
  * (ascending).  Emits per query the global top-k as (global row, score) to host buffers, ordered

@@ -82,6 +82,9 @@ PROTOTYPES = [
     ("rlr_unpack_result", None, [C.c_uint64, f32p, u32p]),
     ("rlr_score_rows", C.c_int32, [_H, f32p, u64p, C.c_uint32, f32p]),
     ("rlr_fetch_rows", C.c_int32, [_H, u64p, C.c_uint32, f32p]),
+    ("rlr_fetch_rows_device", C.c_int32, [_H, u64p, C.c_uint32, C.c_void_p]),
+    ("rlr_mmr_select_values", C.c_int32, [_H, C.c_void_p, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, u32p,
+                                          f32p, u32p]),
     ("rlr_mmr_select", C.c_int32, [_H, u64p, f32p, C.c_uint32, C.c_uint32, C.c_float, u32p, f32p, u32p]),
     ("rlr_mmr_select_batch", C.c_int32, [_H, u64p, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, u32p, f32p,
                                          u32p]),

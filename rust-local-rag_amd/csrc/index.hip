@@ -1362,14 +1362,17 @@ int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *po
     return RLR_OK;
 }
 
-int32_t rlr_mmr_select_batch(rlr_index *ix, const uint64_t *pool_rows, const float *pool_scores,
-                             const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k, float lambda,
-                             uint32_t *order_out, float *mmr_out, uint32_t *n_out)
+// Batched MMR over P-strided pools.  The pool rows either live in the index (pool_rows != null:
+// gathered to f32 here) or are already in device memory as n_queries x P x dim f32 values
+// (d_values != null: the sharded path, after the winner-row exchange).
+static int32_t mmr_batch_impl(rlr_index *ix, const uint64_t *pool_rows, const float *d_values, const float *pool_scores,
+                              const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k, float lambda,
+                              uint32_t *order_out, float *mmr_out, uint32_t *n_out)
 {
     RLR_TRY(check_handle(ix));
     if (n_queries == 0)
         return RLR_OK;
-    if (!pool_rows || !pool_scores || !pool_sizes || !order_out || !n_out)
+    if ((!pool_rows && !d_values) || !pool_scores || !pool_sizes || !order_out || !n_out)
         return fail(RLR_E_INVALID, "null argument");
     if (P == 0) {
         for (uint32_t q = 0; q < n_queries; ++q)
@@ -1388,27 +1391,28 @@ int32_t rlr_mmr_select_batch(rlr_index *ix, const uint64_t *pool_rows, const flo
     for (uint32_t q0 = 0; q0 < n_queries; q0 += QC) {
         const uint32_t m = std::min(QC, n_queries - q0);
         const uint32_t n_list = m * P;
-        // unused slots (j >= pool_sizes[q]) gather row 0: never read by the greedy kernel
-        rows_chunk.assign(n_list, 0);
-        for (uint32_t q = 0; q < m; ++q) {
-            const uint32_t pq = pool_sizes[q0 + q];
-            if (pq > P)
-                return fail(RLR_E_INVALID, "pool_sizes[%u] = %u exceeds P = %u", q0 + q, pq, P);
-            std::memcpy(rows_chunk.data() + static_cast<size_t>(q) * P, pool_rows + static_cast<size_t>(q0 + q) * P,
-                        pq * sizeof(uint64_t));
-        }
+        for (uint32_t q = 0; q < m; ++q)
+            if (pool_sizes[q0 + q] > P)
+                return fail(RLR_E_INVALID, "pool_sizes[%u] = %u exceeds P = %u", q0 + q, pool_sizes[q0 + q], P);
         // pinned staging layout: [row list (upload_list)] [scores] [sizes] [results]; reserve it all
         // BEFORE upload_list enqueues its copy so the buffer is never reallocated under a transfer
         const size_t list_bytes = static_cast<size_t>(n_list) * 8 + 64;
         const size_t in_bytes = static_cast<size_t>(n_list) * 4 + static_cast<size_t>(m + 4) * 4;
         const size_t out_bytes = (2ull * n_list + m) * 4;
         RLR_TRY(pin_reserve(c, list_bytes + in_bytes + out_bytes + 64));
-        RLR_TRY(upload_list(ix, c, rows_chunk.data(), n_list));
-        const uint64_t floats = static_cast<uint64_t>(n_list) * ix->dim + static_cast<uint64_t>(m) * P * P + 3ull * n_list +
-                                2ull * m + 8;
+        if (pool_rows) {
+            // unused slots (j >= pool_sizes[q]) gather row 0: never read by the greedy kernel
+            rows_chunk.assign(n_list, 0);
+            for (uint32_t q = 0; q < m; ++q)
+                std::memcpy(rows_chunk.data() + static_cast<size_t>(q) * P, pool_rows + static_cast<size_t>(q0 + q) * P,
+                            pool_sizes[q0 + q] * sizeof(uint64_t));
+            RLR_TRY(upload_list(ix, c, rows_chunk.data(), n_list));
+        }
+        const uint64_t pool_floats = pool_rows ? static_cast<uint64_t>(n_list) * ix->dim : 0;
+        const uint64_t floats = pool_floats + static_cast<uint64_t>(m) * P * P + 3ull * n_list + 2ull * m + 8;
         RLR_TRY(grow(&c->d_pool, &c->pool_cap, floats));
         float *d_pool = c->d_pool;
-        float *d_gram = d_pool + static_cast<uint64_t>(n_list) * ix->dim;
+        float *d_gram = d_pool + pool_floats;
         float *d_sc = d_gram + static_cast<uint64_t>(m) * P * P;
         uint32_t *d_order = reinterpret_cast<uint32_t *>(d_sc + n_list);
         float *d_mmr = d_sc + 2ull * n_list;
@@ -1421,8 +1425,12 @@ int32_t rlr_mmr_select_batch(rlr_index *ix, const uint64_t *pool_rows, const flo
         std::memcpy(h_sizes, pool_sizes + q0, m * sizeof(uint32_t));
         RLR_HIP(hipMemcpyAsync(d_sc, h_sc, static_cast<size_t>(n_list) * sizeof(float), hipMemcpyHostToDevice, s));
         RLR_HIP(hipMemcpyAsync(d_sizes, h_sizes, m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, n_list, d_pool, s));
-        RLR_HIP(launch_gram(d_pool, P, ix->dim, d_gram, m, s));
+        const float *d_rows_f32 = d_pool;
+        if (pool_rows)
+            RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, n_list, d_pool, s));
+        else
+            d_rows_f32 = d_values + static_cast<size_t>(q0) * P * ix->dim;
+        RLR_HIP(launch_gram(d_rows_f32, P, ix->dim, d_gram, m, s));
         RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, d_sizes, m, s));
         // results: order | mmr | n are contiguous
         uint32_t *h_res = reinterpret_cast<uint32_t *>(h_sizes + m + 4);
@@ -1438,6 +1446,42 @@ int32_t rlr_mmr_select_batch(rlr_index *ix, const uint64_t *pool_rows, const flo
                 std::memcpy(mmr_out + static_cast<size_t>(q0 + q) * P, h_mmr + static_cast<size_t>(q) * P, ns * sizeof(float));
         }
     }
+    return RLR_OK;
+}
+
+int32_t rlr_mmr_select_batch(rlr_index *ix, const uint64_t *pool_rows, const float *pool_scores,
+                             const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k, float lambda,
+                             uint32_t *order_out, float *mmr_out, uint32_t *n_out)
+{
+    if (n_queries && !pool_rows)
+        return fail(RLR_E_INVALID, "null argument");
+    return mmr_batch_impl(ix, pool_rows, nullptr, pool_scores, pool_sizes, n_queries, P, k, lambda, order_out, mmr_out, n_out);
+}
+
+int32_t rlr_mmr_select_values(rlr_index *ix, const void *d_values, const float *pool_scores, const uint32_t *pool_sizes,
+                              uint32_t n_queries, uint32_t P, uint32_t k, float lambda, uint32_t *order_out,
+                              float *mmr_out, uint32_t *n_out)
+{
+    if (n_queries && !d_values)
+        return fail(RLR_E_INVALID, "null argument");
+    return mmr_batch_impl(ix, nullptr, static_cast<const float *>(d_values), pool_scores, pool_sizes, n_queries, P, k, lambda,
+                          order_out, mmr_out, n_out);
+}
+
+int32_t rlr_fetch_rows_device(rlr_index *ix, const uint64_t *rows, uint32_t n, void *d_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (n == 0)
+        return RLR_OK;
+    if (!rows || !d_out)
+        return fail(RLR_E_INVALID, "null argument");
+    RLR_TRY(use_device(ix));
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    RLR_TRY(upload_list(ix, c, rows, n));
+    RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, n, static_cast<float *>(d_out), c->stream));
+    RLR_HIP(hipStreamSynchronize(c->stream));
     return RLR_OK;
 }
 

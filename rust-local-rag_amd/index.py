@@ -167,6 +167,25 @@ class GpuIndex:
                                              k, lam, order.ctypes.data_as(N.u32p), _fp(mmr), n.ctypes.data_as(N.u32p)))
         return order, mmr, n[:nq]
 
+    def fetch_rows_device(self, rows, d_out_ptr: int) -> None:
+        """rows of this index as dense f32 values into device memory at `d_out_ptr` (len(rows) x dim floats)"""
+        rows = _u64(rows).ravel()
+        if rows.size:
+            N.check(self._L.rlr_fetch_rows_device(self._h, _up(rows), rows.size, C.c_void_p(d_out_ptr)))
+
+    def mmr_select_values(self, d_values_ptr: int, pool_scores, pool_sizes, k: int, lam: float):
+        """mmr_select_batch for pools whose row values are in device memory: [Q, P, dim] f32 at `d_values_ptr`"""
+        pool_scores = _f32(pool_scores)
+        nq, P = pool_scores.shape
+        sizes = np.ascontiguousarray(pool_sizes, dtype=np.uint32)
+        order = np.zeros((nq, max(P, 1)), dtype=np.uint32)
+        mmr = np.zeros((nq, max(P, 1)), dtype=np.float32)
+        n = np.zeros(max(nq, 1), dtype=np.uint32)
+        N.check(self._L.rlr_mmr_select_values(self._h, C.c_void_p(d_values_ptr), _fp(pool_scores),
+                                              sizes.ctypes.data_as(N.u32p), nq, P, k, lam,
+                                              order.ctypes.data_as(N.u32p), _fp(mmr), n.ctypes.data_as(N.u32p)))
+        return order, mmr, n[:nq]
+
     # -- measurement ---------------------------------------------------------
     def profile_enable(self, on: bool = True) -> None:
         N.check(self._L.rlr_profile_enable(self._h, int(on)))

@@ -139,3 +139,130 @@ class ShardedIndex:
                                        cos_h.ctypes.data_as(N.f32p), n_h.ctypes.data_as(N.u32p), C.c_void_p(stream)))
         n_valid = int(n_h[0]) if nq else 0
         return rows_h[:, :n_valid].astype(np.int64), cos_h[:, :n_valid].copy()
+
+    # -- MMR on sharded data --------------------------------------------
+    def mmr_select_batch(self, pool_rows, pool_scores, pool_sizes, k: int, lam: float):
+        """Batched `mmr_diversify` over pools of GLOBAL rows (identical on every rank, as search_topk
+        returns them).  -> (order u32 [Q, P], mmr f32 [Q, P], n u32 [Q]) on every rank."""
+        torch = self.torch
+
+        def fetch(local_rows: np.ndarray):
+            out = torch.empty((max(local_rows.size, 1), self.dim), dtype=torch.float32, device=self.dev)
+            self.index.fetch_rows_device(local_rows, out.data_ptr())
+            return out[: local_rows.size]
+
+        def mmr(values, scores, sizes, kk, ll):
+            torch.cuda.current_stream(self.dev).synchronize()  # the exchange ran on torch's stream
+            return self.index.mmr_select_values(values.data_ptr(), scores, sizes, kk, ll)
+
+        return sharded_mmr(pool_rows, pool_scores, pool_sizes, k, lam, rank=self.rank, world=self.world,
+                           bases=self._bases_h, dim=self.dim, fetch=fetch, mmr=mmr, torch=torch,
+                           dist=self.dist if self.world > 1 else None, group=self.group, device=self.dev)
+
+    def search_with_diversity_batch(self, queries, k: int, diversity: float, w_e: float = 0.7):
+        """`search_with_diversity` (rag_engine.rs:717-759) for a batch of normalised queries over the
+        sharded corpus, no lexical term: -> list of (global rows in pick order, relevance scores, cosines)."""
+        lam = min(max(float(diversity), 0.0), 1.0)                 # :725
+        w = np.float32(w_e)
+        if lam == 0.0:                                             # :728-730
+            rows, cos = self.search_topk(queries, k)
+            return [(rows[q], (w * cos[q]).astype(np.float32), cos[q]) for q in range(rows.shape[0])]
+        pool = max(3 * k, k + 10)                                  # :734
+        rows, cos = self.search_topk(queries, pool)                # :735
+        nq, P = rows.shape
+        scores = (w * cos).astype(np.float32)                      # combined score, lexical part absent (:531-532)
+        sizes = np.full(nq, P, dtype=np.uint32)
+        order, _, n = self.mmr_select_batch(rows, scores, sizes, k, lam)  # :756
+        out = []
+        for q in range(nq):
+            o = order[q, : n[q]].astype(np.int64)
+            out.append((rows[q][o], scores[q][o], cos[q][o]))
+        return out
+
+
+def plan_winner_exchange(pool_rows, pool_sizes, bases, rank: int, world: int):
+    """Who sends which pool rows where.  Query q is diversified on rank q % world; the owner of a
+    pool row is the shard whose range holds it.  Every rank computes the same plan from the
+    (replicated) merged pools, so no size exchange is needed.
+      -> send_local   local rows this rank gathers, grouped by destination in (dst, query, position) order
+         send_counts  [world] rows per destination
+         recv_counts  [world] rows arriving per source
+         perm         [m * P] slot (j-th own query, position p) -> index into the receive buffer
+                      (sources concatenated in rank order); unused slots point at 0
+         my_queries   the queries this rank diversifies"""
+    rows = np.asarray(pool_rows, dtype=np.int64)
+    nq, P = rows.shape
+    sizes = np.asarray(pool_sizes, dtype=np.int64)
+    bases = np.asarray(bases, dtype=np.int64)
+    valid = np.arange(P)[None, :] < sizes[:, None]
+    owner = np.searchsorted(bases, rows, side="right") - 1
+    owner = np.where(valid, owner, -1)
+    dst = np.broadcast_to((np.arange(nq) % world)[:, None], (nq, P))
+    # send side: my rows, stable-sorted by destination (row-major flattening is (query, position) order)
+    mine = (owner == rank).ravel()
+    d_m = dst.ravel()[mine]
+    order = np.argsort(d_m, kind="stable")
+    send_local = (rows.ravel()[mine] - bases[rank])[order].astype(np.uint64)
+    send_counts = np.bincount(d_m, minlength=world).astype(np.int64)
+    # receive side: slots of my queries, arrival order = (source, query, position)
+    my_queries = np.arange(rank, nq, world)
+    own = owner[my_queries].ravel()
+    ok = own >= 0
+    arrival = np.argsort(own[ok], kind="stable")
+    recv_counts = np.bincount(own[ok], minlength=world).astype(np.int64)
+    perm = np.zeros(own.size, dtype=np.int64)
+    slots = np.flatnonzero(ok)
+    perm[slots[arrival]] = np.arange(arrival.size)
+    return send_local, send_counts, recv_counts, perm, my_queries
+
+
+def sharded_mmr(pool_rows, pool_scores, pool_sizes, k: int, lam: float, *, rank: int, world: int, bases, dim: int,
+                fetch, mmr, torch, dist=None, group=None, device=None):
+    """MMR over pools whose rows live on different ranks: winner-row exchange (one all-to-all of
+    exactly the needed rows), local batched MMR for the queries q % world == rank, one all-gather of
+    the pick lists.  `fetch(local_rows) -> tensor [n, dim] f32` and `mmr(values, scores, sizes, k, lam)
+    -> (order, mmr, n)` are the shard's row gather and batched MMR (GPU entry points in ShardedIndex,
+    CPU stand-ins in the gloo test)."""
+    rows = np.asarray(pool_rows, dtype=np.int64)
+    nq, P = rows.shape
+    scores = np.ascontiguousarray(pool_scores, dtype=np.float32)
+    sizes = np.ascontiguousarray(pool_sizes, dtype=np.uint32)
+    send_local, send_counts, recv_counts, perm, my_q = plan_winner_exchange(rows, sizes, bases, rank, world)
+    send = fetch(send_local)
+    if dist is not None and world > 1:
+        recv = torch.empty((max(int(recv_counts.sum()), 1), dim), dtype=torch.float32, device=send.device)
+        n_recv = int(recv_counts.sum())
+        dist.all_to_all_single(recv[:n_recv], send.contiguous(), output_split_sizes=[int(c) for c in recv_counts],
+                               input_split_sizes=[int(c) for c in send_counts], group=group)
+    else:
+        recv = send
+    m = my_q.size
+    per = (nq + world - 1) // world  # padded own-query count, equal on all ranks
+    res = np.zeros((per, 2 * P + 1), dtype=np.int32)
+    if m and P:
+        if recv.shape[0] == 0:
+            recv = torch.zeros((1, dim), dtype=torch.float32, device=send.device)
+        values = recv.index_select(0, torch.from_numpy(perm).to(recv.device)).contiguous()
+        order, mm, n = mmr(values, scores[my_q], sizes[my_q], k, lam)
+        res[:m, :P] = order.view(np.int32)
+        res[:m, P:2 * P] = mm.view(np.int32)
+        res[:m, 2 * P] = n.astype(np.int32)
+    if dist is not None and world > 1:
+        mine = torch.from_numpy(res).to(send.device)
+        allr = torch.empty((world * per, 2 * P + 1), dtype=torch.int32, device=send.device)
+        dist.all_gather_into_tensor(allr, mine, group=group)
+        allr = allr.cpu().numpy().reshape(world, per, 2 * P + 1)
+    else:
+        allr = res.reshape(1, per, 2 * P + 1)
+    order_out = np.zeros((nq, max(P, 1)), dtype=np.uint32)
+    mmr_out = np.zeros((nq, max(P, 1)), dtype=np.float32)
+    n_out = np.zeros(nq, dtype=np.uint32)
+    for r in range(world):
+        qs = np.arange(r, nq, world)
+        if qs.size == 0 or P == 0:
+            continue
+        blk = allr[r, : qs.size]
+        order_out[qs, :P] = blk[:, :P].view(np.uint32)
+        mmr_out[qs, :P] = np.ascontiguousarray(blk[:, P:2 * P]).view(np.float32)
+        n_out[qs] = blk[:, 2 * P].astype(np.uint32)
+    return order_out, mmr_out, n_out

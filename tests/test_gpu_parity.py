@@ -318,6 +318,50 @@ def test_sharded_index_world1_device_results(rlr, oracle):
     assert np.array_equal(r2[0].astype(np.uint64), wr) and np.array_equal(bits(c2[0]), bits(wc))
 
 
+def test_sharded_diversity_world1_winner_exchange_path(rlr, oracle):
+    """search_with_diversity over a ShardedIndex: plan -> rlr_fetch_rows_device -> permutation ->
+    rlr_mmr_select_values (the all-to-all / all-gather between them is covered by the gloo test)."""
+    import importlib
+    import torch  # noqa: F401
+    sharded = importlib.import_module("rust-local-rag_amd.sharded")
+    n, dim, k = 5000, 1024, 100
+    for dtype in ("f32", "f16"):
+        sh = sharded.ShardedIndex(dim, n, dtype, device=0, rank=0, world=1)
+        sh.fill_synthetic(seed=515, n_clusters=25)
+        rows = oracle.synth_rows(n, dim, seed=515, n_clusters=25, f16=(dtype == "f16"))
+        qs_raw = [oracle.synth_query(dim, seed=620 + i) for i in range(5)]
+        qs = np.stack([oracle.normalize(q) for q in qs_raw])
+        for lam in (0.7, 0.0):
+            got = sh.search_with_diversity_batch(qs, k, lam)
+            for i in range(len(qs)):
+                wr, wc, we, wl = oracle.search_with_diversity(rows, qs_raw[i], k, lam)
+                assert np.array_equal(got[i][0].astype(np.uint64), wr), (dtype, lam, i)
+                assert np.array_equal(bits(got[i][1]), bits(wc)), (dtype, lam, i)
+        sh.index.close()
+
+
+def test_mmr_select_values_entry_equals_index_pools(rlr, oracle):
+    import torch
+    rows = oracle.synth_rows(3000, 768, seed=93, n_clusters=9)
+    ix = make_index(rlr, rows)
+    qs = np.stack([oracle.normalize(oracle.synth_query(768, seed=94 + i)) for i in range(70)])  # > one 64-query pass
+    pr, pc = ix.search_topk(qs, 40)
+    scores = (np.float32(0.7) * pc).astype(np.float32)
+    sizes = np.full(len(qs), 40, np.uint32)
+    sizes[3] = 17
+    want = ix.mmr_select_batch(pr, scores, sizes, 10, 0.6)
+    vals = torch.empty((len(qs) * 40, 768), dtype=torch.float32, device="cuda")
+    ix.fetch_rows_device(pr.ravel(), vals.data_ptr())
+    assert np.array_equal(vals.cpu().numpy(), rows[pr.ravel().astype(np.int64)])
+    got = ix.mmr_select_values(vals.data_ptr(), scores, sizes, 10, 0.6)
+    assert np.array_equal(got[2], want[2])
+    for q in range(len(qs)):
+        nsel = got[2][q]
+        assert np.array_equal(got[0][q, :nsel], want[0][q, :nsel])
+        assert np.array_equal(bits(got[1][q, 1:nsel]), bits(want[1][q, 1:nsel]))
+    ix.close()
+
+
 # ---------------------------------------------------------------- batched (matrix-core) path
 def _check_batch(rlr, oracle, ix, rows, qs, k):
     ix.profile_read(reset=True)

@@ -111,3 +111,98 @@ def test_merge_handles_short_shards_and_padding():
     assert sharded.key_to_score(key.numpy())[0].tolist() == [np.float32(0.9), 0.5, 0.5, np.float32(0.1)]
     rows6, _ = sharded.merge_packed(torch.from_numpy(g.view(np.int64)), bases, 8)
     assert rows6[0].tolist() == [4, 1, 2, 5, 0, 3, -1, -1]
+
+
+# ---- MMR on sharded data: winner-row exchange (all-to-all) + pick-list all-gather ---------------
+def _mmr_worker(rank, world, port, n_total, dim, nq, P, k, lam, seed, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sharded = importlib.import_module("rust-local-rag_amd.sharded")
+        from oracle import oracle as O
+
+        lo, hi = sharded.shard_range(n_total, rank, world)
+        shard = O.synth_rows(hi - lo, dim, seed, row0=lo, n_clusters=5)
+        bases = np.array([sharded.shard_range(n_total, r, world)[0] for r in range(world)], dtype=np.uint64)
+        pools, scores, sizes = _pools(n_total, nq, P, seed)
+
+        def fetch(local_rows):  # stands in for rlr_fetch_rows_device
+            return torch.from_numpy(shard[local_rows.astype(np.int64)].reshape(-1, dim).copy())
+
+        def mmr(values, sc, sz, kk, ll):  # stands in for rlr_mmr_select_values: the oracle, query by query
+            v = values.numpy().reshape(len(sz), P, dim)
+            order = np.zeros((len(sz), P), np.uint32); mm = np.zeros((len(sz), P), np.float32); n = np.zeros(len(sz), np.uint32)
+            for j in range(len(sz)):
+                o, m_ = O.mmr(v[j, : sz[j]], sc[j, : sz[j]], kk, ll)
+                order[j, : len(o)] = o; mm[j, : len(o)] = m_; n[j] = len(o)
+            return order, mm, n
+
+        out = sharded.sharded_mmr(pools, scores, sizes, k, lam, rank=rank, world=world, bases=bases, dim=dim,
+                                  fetch=fetch, mmr=mmr, torch=torch, dist=dist)
+        ret[rank] = tuple(a.copy() for a in out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _pools(n_total, nq, P, seed):
+    rng = np.random.default_rng(seed)
+    pools = np.stack([rng.choice(n_total, size=P, replace=False) for _ in range(nq)]).astype(np.int64)
+    scores = np.sort(rng.random((nq, P)).astype(np.float32), axis=1)[:, ::-1].copy()
+    sizes = np.full(nq, P, dtype=np.uint32)
+    sizes[1] = P - 3          # a ragged pool
+    sizes[nq - 1] = 1         # a single-candidate pool
+    return pools, scores, sizes
+
+
+def test_world2_gloo_sharded_mmr_matches_global_oracle(oracle):
+    import torch.multiprocessing as mp
+
+    n_total, dim, nq, P, k, lam, seed, world = 301, 32, 5, 12, 6, 0.7, 91, 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_mmr_worker, args=(r, world, port, n_total, dim, nq, P, k, lam, seed, ret))
+             for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+    rows = oracle.synth_rows(n_total, dim, seed, n_clusters=5)
+    pools, scores, sizes = _pools(n_total, nq, P, seed)
+    for rank in range(world):
+        order, mm, n = ret[rank]
+        for q in range(nq):
+            o, m_ = oracle.mmr(rows[pools[q, : sizes[q]]], scores[q, : sizes[q]], k, lam)
+            assert n[q] == len(o), (rank, q)
+            assert np.array_equal(order[q, : n[q]], o), (rank, q)
+            assert np.array_equal(mm[q, 1: n[q]].view(np.uint32), m_[1:].view(np.uint32)), (rank, q)
+
+
+def test_winner_exchange_plan_is_consistent_across_ranks():
+    """every (src -> dst) count agrees on both sides and the permutation rebuilds the pool order"""
+    sharded = importlib.import_module("rust-local-rag_amd.sharded")
+    n_total, nq, P, world = 1000, 7, 9, 3
+    pools, _, sizes = _pools(n_total, nq, P, 5)
+    bases = np.array([sharded.shard_range(n_total, r, world)[0] for r in range(world)])
+    plans = [sharded.plan_winner_exchange(pools, sizes, bases, r, world) for r in range(world)]
+    for s in range(world):
+        for d in range(world):
+            assert plans[s][1][d] == plans[d][2][s]
+    for d in range(world):
+        # what dst receives, source by source
+        recv = []
+        for s in range(world):
+            send_local, send_counts = plans[s][0], plans[s][1]
+            off = int(send_counts[:d].sum())
+            recv.extend((send_local[off: off + int(send_counts[d])].astype(np.int64) + bases[s]).tolist())
+        perm, my_q = plans[d][3], plans[d][4]
+        assert my_q.tolist() == list(range(d, nq, world))
+        rebuilt = np.array(recv)[perm].reshape(len(my_q), P)
+        for j, q in enumerate(my_q):
+            assert np.array_equal(rebuilt[j, : sizes[q]], pools[q, : sizes[q]])
