@@ -1,4 +1,4 @@
-"""ctypes view of librlr_gpu.so (include/rlr_gpu.h + include/rlr_engine.h).
+"""ctypes view of librlr_gpu.so (include/rlr_gpu.h + include/rlr_engine.h + include/rlr_lexical.h).
 
 The product path has no CPU implementation: if the HIP library is missing or cannot be
 loaded this module raises, and every compute call on a box without a GPU returns
@@ -115,6 +115,16 @@ PROTOTYPES = [
                                               C.POINTER(QueryWeightsC), C.POINTER(SearchHitC), f32p, i32p, C.c_uint32,
                                               u32p]),
     ("rlr_engine_embedding_candidates", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, u64p, f32p, u32p]),
+    # rlr_lexical.h
+    ("rlr_lexical_create", C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
+    ("rlr_lexical_destroy", None, [_H]),
+    ("rlr_lexical_add_chunk", C.c_int32, [_H, C.c_uint64, C.c_char_p, C.c_size_t]),
+    ("rlr_lexical_remove_rows", C.c_int32, [_H, u64p, C.c_uint32]),
+    ("rlr_lexical_clear", C.c_int32, [_H]),
+    ("rlr_lexical_contains", C.c_int32, [_H, C.c_uint64]),
+    ("rlr_lexical_info", C.c_int32, [_H, u64p, u64p, u64p, u64p]),
+    ("rlr_lexical_score", C.c_int32, [_H, C.c_char_p, C.c_size_t, C.c_uint32, u64p, f32p, u32p]),
+    ("rlr_tokenize_ascii", C.c_int32, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
 ]
 
 _lib = None

@@ -18,9 +18,9 @@ OBJ = os.path.join(HERE, "_obj")
 SO = os.path.join(HERE, "librlr_gpu.so")
 ROOT = os.path.dirname(HERE)
 
-SOURCES = ["scan.hip", "select.hip", "exact.hip", "gemm.hip", "index.hip", "engine.cpp", "multi.cpp"]
+SOURCES = ["scan.hip", "select.hip", "exact.hip", "gemm.hip", "index.hip", "engine.cpp", "multi.cpp", "lexical.hip"]
 HEADERS = ["common.h", "kernels.h", "exact_dot.h", os.path.join(ROOT, "include", "rlr_gpu.h"),
-           os.path.join(ROOT, "include", "rlr_engine.h")]
+           os.path.join(ROOT, "include", "rlr_engine.h"), os.path.join(ROOT, "include", "rlr_lexical.h")]
 
 # -ffp-contract=off: a*b+c in source is a rounded multiply then a rounded add (the
 # reference's arithmetic); FMAs appear only where the source spells fmaf().

@@ -31,6 +31,22 @@ int32_t fail(int32_t code, const char *fmt, ...)
     return code;
 }
 
+} // namespace
+
+namespace rlr {
+// the same thread-local message for the other translation units of the library (lexical.hip)
+int32_t set_error(int32_t code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+} // namespace rlr
+
+namespace {
+
 #define RLR_HIP(call)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (call);                                                                    \

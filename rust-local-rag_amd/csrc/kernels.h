@@ -7,6 +7,9 @@
 
 namespace rlr {
 
+// index.hip: sets the thread-local rlr_last_error() message, returns `code`
+int32_t set_error(int32_t code, const char *fmt, ...);
+
 // ---- scan.hip : wavefront-order candidate scan (HBM-bound) ----------------
 struct ScanArgs {
     const void *rows;     // n_rows x pitch16 x 16 B, row-major

@@ -1,0 +1,696 @@
+// lexical.hip -- the C ABI of include/rlr_lexical.h: BM25 term of the hybrid score with the
+// postings resident in HBM (reference LexicalIndex,
+// /root/reference/src/rag_engine.rs:2083-2237).
+//
+// Host side: term dictionary, per-row term counts, corpus statistics; CSR postings are rebuilt
+// and uploaded lazily by the first score call after a mutation.
+// Device side, per query (one stream, no host round trip until the results are read):
+//   bm25_term_kernel   one launch per unique query term, in query order: every posting adds its
+//                      BM25 contribution to a dense per-row accumulator (one writer per row per
+//                      launch, so the f32 sum order is the term order -- deterministic); rows
+//                      whose sum becomes positive are appended to a compact "touched" list
+//                      (wave-aggregated atomics);
+//   <= 8192 postings   lex_sort_touched_kernel: packed (score, row) keys sorted in LDS;
+//   more               lex_pack_kernel + 8 x lex_select_pass_kernel (MSD radix select, 8-bit
+//                      digits over the unique 64-bit keys -- exact under massive score ties,
+//                      which BM25 produces whenever tf and document length repeat) +
+//                      lex_collect_kernel + lex_sort_sel_kernel;
+//   lex_clear_kernel   restores the all-zero accumulator by visiting only the touched rows.
+// All of it is integer/f32 work bounded by HBM latency, not bandwidth: a query touches
+// sum(df) postings x 8 B.
+#include "../../include/rlr_lexical.h"
+#include "common.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace rlr;
+
+namespace {
+
+#define LEX_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return set_error(e_ == hipErrorOutOfMemory ? RLR_E_OOM : RLR_E_HIP, "%s failed: %s (%s:%d)", \
+                             #call, hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+#define LEX_TRY(call)          \
+    do {                       \
+        int32_t s_ = (call);   \
+        if (s_ != RLR_OK)      \
+            return s_;         \
+    } while (0)
+
+constexpr uint32_t kMaxLimit = RLR_LEXICAL_MAX_LIMIT; // LDS sort capacity (64 KB of u64 keys)
+constexpr int kPasses = 8;                            // 8-bit digits over 64-bit keys
+constexpr float kK1 = 1.5f, kB = 0.75f;               // rag_engine.rs:2191-2192
+
+// control block in device memory, all zero between queries
+struct LexControl {
+    uint32_t n_touched;
+    uint32_t n_sel;
+    uint32_t pad[2];
+    uint64_t prefix[kPasses + 1]; // prefix[p]: the top 8*p key bits of the k-th largest key
+    uint32_t k_rem[kPasses + 1];  // rank still wanted inside that prefix (1-based)
+    uint32_t pad2[3];
+    uint32_t hist[kPasses][256];
+};
+
+// ---------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------
+// wave-aggregated append: lanes with `flag` get consecutive slots of list[]
+__device__ inline uint32_t wave_append_slot(bool flag, uint32_t *counter)
+{
+    const uint64_t mask = __ballot(flag);
+    if (mask == 0)
+        return 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+    uint32_t base = 0;
+    if (lane == leader)
+        base = atomicAdd(counter, static_cast<uint32_t>(__popcll(mask)));
+    base = __shfl(base, leader);
+    return base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+}
+
+// LexicalIndex::score inner loop, rag_engine.rs:2200-2213, for the postings of one term
+__global__ __launch_bounds__(256) void bm25_term_kernel(const uint32_t *__restrict__ post_row,
+                                                        const uint32_t *__restrict__ post_tf, uint32_t cnt,
+                                                        const uint32_t *__restrict__ doc_len, float avg, float idf,
+                                                        float *__restrict__ scores, uint32_t *__restrict__ touched,
+                                                        LexControl *__restrict__ ctl)
+{
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i0 = blockIdx.x * 256; i0 < cnt; i0 += stride) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool first_touch = false;
+        uint32_t row = 0;
+        if (i < cnt) {
+            row = post_row[i];
+            const float dl = static_cast<float>(doc_len[row]);
+            const float tf = static_cast<float>(post_tf[i]);
+            const float denom = tf + kK1 * ((1.0f - kB) + kB * (dl / avg));
+            if (dl != 0.0f && denom != 0.0f) {
+                const float sc = idf * (tf * (kK1 + 1.0f)) / denom;
+                const float old = scores[row];
+                const float now = old + sc; // `*scores.entry(doc).or_insert(0.0) += score`
+                scores[row] = now;
+                first_touch = old == 0.0f && now > 0.0f;
+            }
+        }
+        const uint32_t slot = wave_append_slot(first_touch, &ctl->n_touched);
+        if (first_touch)
+            touched[slot] = row;
+    }
+}
+
+__global__ __launch_bounds__(256) void lex_pack_kernel(const float *__restrict__ scores,
+                                                       const uint32_t *__restrict__ touched,
+                                                       const LexControl *__restrict__ ctl, uint64_t *__restrict__ keys)
+{
+    const uint32_t n = ctl->n_touched;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t row = touched[i];
+        keys[i] = pack_result(scores[row], row);
+    }
+}
+
+// bitonic sort (descending) of n_pad keys in LDS, n_pad a power of two <= kMaxLimit
+__device__ inline void lds_sort_desc(uint64_t *s, uint32_t n_pad)
+{
+    for (uint32_t kk = 2; kk <= n_pad; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = s[i], b = s[ixj];
+                    const bool desc = (i & kk) == 0;
+                    if (desc ? (a < b) : (a > b)) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// `results.sort_by(score desc)` + `truncate(limit)` (:2218-2222) when everything fits one workgroup
+template <bool FROM_TOUCHED>
+__global__ __launch_bounds__(1024) void lex_sort_kernel(const float *__restrict__ scores,
+                                                        const uint32_t *__restrict__ touched,
+                                                        const uint64_t *__restrict__ sel,
+                                                        const LexControl *__restrict__ ctl, uint32_t limit,
+                                                        uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_n)
+{
+    __shared__ uint64_t s[kMaxLimit];
+    uint32_t n = FROM_TOUCHED ? ctl->n_touched : ctl->n_sel;
+    n = min(n, kMaxLimit);
+    uint32_t n_pad = 1;
+    while (n_pad < n)
+        n_pad <<= 1;
+    for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
+        uint64_t v = 0;
+        if (i < n) {
+            if constexpr (FROM_TOUCHED) {
+                const uint32_t row = touched[i];
+                v = pack_result(scores[row], row);
+            } else {
+                v = sel[i];
+            }
+        }
+        s[i] = v;
+    }
+    __syncthreads();
+    lds_sort_desc(s, n_pad);
+    const uint32_t m = min(n, limit);
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x)
+        out_keys[i] = s[i];
+    if (threadIdx.x == 0)
+        *out_n = m;
+}
+
+// The (prefix, rank) the radix select has reached before pass `pass`, derived from the previous
+// pass's histogram by every workgroup on its own (256 bins: one serial walk by thread 0).
+__device__ inline void lex_derive_state(const LexControl *ctl, uint32_t limit, int pass, uint64_t *prefix, uint32_t *k_rem)
+{
+    __shared__ uint64_t s_prefix;
+    __shared__ uint32_t s_k;
+    if (threadIdx.x == 0) {
+        if (pass == 0) {
+            s_prefix = 0;
+            s_k = min(limit, ctl->n_touched);
+        } else {
+            uint32_t k = ctl->k_rem[pass - 1];
+            const uint32_t *h = ctl->hist[pass - 1];
+            uint32_t d = 255, seen = 0;
+            for (int b = 255; b >= 0; --b) {
+                const uint32_t c = h[b];
+                if (seen + c >= k) {
+                    d = static_cast<uint32_t>(b);
+                    break;
+                }
+                seen += c;
+            }
+            s_prefix = (ctl->prefix[pass - 1] << 8) | d;
+            s_k = k - seen;
+        }
+    }
+    __syncthreads();
+    *prefix = s_prefix;
+    *k_rem = s_k;
+}
+
+__global__ __launch_bounds__(256) void lex_select_pass_kernel(const uint64_t *__restrict__ keys, LexControl *__restrict__ ctl,
+                                                              uint32_t limit, int pass)
+{
+    __shared__ uint32_t s_h[256];
+    uint64_t prefix;
+    uint32_t k_rem;
+    lex_derive_state(ctl, limit, pass, &prefix, &k_rem);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->prefix[pass] = prefix;
+        ctl->k_rem[pass] = k_rem;
+    }
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n = ctl->n_touched;
+    const int shift = 56 - 8 * pass;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint64_t key = keys[i];
+        const bool match = pass == 0 || (key >> (shift + 8)) == prefix;
+        if (match)
+            atomicAdd(&s_h[(key >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    const uint32_t c = s_h[threadIdx.x];
+    if (c)
+        atomicAdd(&ctl->hist[pass][threadIdx.x], c);
+}
+
+__global__ __launch_bounds__(256) void lex_collect_kernel(const uint64_t *__restrict__ keys, LexControl *__restrict__ ctl,
+                                                          uint32_t limit, uint64_t *__restrict__ sel)
+{
+    uint64_t kth;
+    uint32_t k_rem;
+    lex_derive_state(ctl, limit, kPasses, &kth, &k_rem); // all 64 bits fixed: the k-th largest key itself
+    const uint32_t n = ctl->n_touched;
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i0 = blockIdx.x * 256; i0 < n; i0 += stride) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint64_t key = i < n ? keys[i] : 0ull;
+        const bool take = i < n && key >= kth;
+        const uint32_t slot = wave_append_slot(take, &ctl->n_sel);
+        if (take && slot < kMaxLimit)
+            sel[slot] = key;
+    }
+}
+
+__global__ __launch_bounds__(256) void lex_clear_kernel(float *__restrict__ scores, const uint32_t *__restrict__ touched,
+                                                        const LexControl *__restrict__ ctl)
+{
+    const uint32_t n = ctl->n_touched;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        scores[touched[i]] = 0.0f;
+}
+
+template <typename T>
+int32_t dev_grow(T **p, uint64_t *cap, uint64_t need, bool zero = false)
+{
+    if (*cap >= need && *p)
+        return RLR_OK;
+    if (*p)
+        (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const uint64_t n = std::max<uint64_t>(need, 1024);
+    LEX_HIP(hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
+    if (zero)
+        LEX_HIP(hipMemset(*p, 0, n * sizeof(T)));
+    *cap = n;
+    return RLR_OK;
+}
+
+void split_tokens(const char *s, size_t len, std::vector<std::string> *out)
+{
+    size_t i = 0;
+    while (i < len) {
+        while (i < len && s[i] == ' ')
+            ++i;
+        size_t j = i;
+        while (j < len && s[j] != ' ')
+            ++j;
+        if (j > i)
+            out->emplace_back(s + i, j - i);
+        i = j;
+    }
+}
+
+} // namespace
+
+struct rlr_lexical {
+    int32_t device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    // ---- host state (LexicalIndex fields, rag_engine.rs:2084-2090, keyed by row instead of chunk id)
+    std::unordered_map<std::string, uint32_t> term_id;
+    std::vector<uint32_t> df;                                          // term -> documents holding it
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> doc_terms; // row -> (term, count); empty = absent
+    std::vector<uint32_t> doc_len;                                     // row -> token count
+    uint64_t total_docs = 0, total_length = 0, n_postings = 0, n_live_terms = 0;
+    bool dirty = true;
+    // ---- device CSR
+    std::vector<uint64_t> term_off;
+    uint32_t *d_post_row = nullptr, *d_post_tf = nullptr, *d_doc_len = nullptr;
+    uint64_t post_cap = 0, post_tf_cap = 0, doc_cap = 0;
+    float *d_scores = nullptr;
+    uint64_t scores_cap = 0;
+    // ---- per-query workspace
+    uint32_t *d_touched = nullptr;
+    uint64_t touched_cap = 0;
+    uint64_t *d_keys = nullptr;
+    uint64_t keys_cap = 0;
+    uint64_t *d_sel = nullptr;
+    LexControl *d_ctl = nullptr;
+    uint64_t *d_out = nullptr; // kMaxLimit keys + count
+    uint64_t *h_out = nullptr; // pinned mirror
+};
+
+namespace {
+
+void remove_row_stats(rlr_lexical *lx, uint64_t row)
+{
+    auto &terms = lx->doc_terms[row];
+    if (terms.empty())
+        return;
+    for (const auto &tc : terms) {
+        if (lx->df[tc.first] > 0 && --lx->df[tc.first] == 0)
+            lx->n_live_terms--;
+    }
+    lx->n_postings -= terms.size();
+    const uint32_t len = lx->doc_len[row];
+    lx->total_length = lx->total_length >= len ? lx->total_length - len : 0; // :2153-2157
+    if (lx->total_docs > 0)
+        lx->total_docs--;
+    if (lx->total_docs == 0)
+        lx->total_length = 0; // :2164-2166
+    terms.clear();
+    lx->doc_len[row] = 0;
+}
+
+int32_t commit(rlr_lexical *lx)
+{
+    const uint64_t n_rows = lx->doc_terms.size();
+    const size_t n_terms = lx->df.size();
+    lx->term_off.assign(n_terms + 1, 0);
+    for (size_t t = 0; t < n_terms; ++t)
+        lx->term_off[t + 1] = lx->term_off[t] + lx->df[t];
+    const uint64_t total = lx->term_off[n_terms];
+    std::vector<uint32_t> rows(std::max<uint64_t>(total, 1)), tfs(std::max<uint64_t>(total, 1));
+    std::vector<uint64_t> fill(lx->term_off.begin(), lx->term_off.end() - 1);
+    for (uint64_t r = 0; r < n_rows; ++r)
+        for (const auto &tc : lx->doc_terms[r]) { // rows ascending -> every posting list is sorted by row
+            const uint64_t at = fill[tc.first]++;
+            rows[at] = static_cast<uint32_t>(r);
+            tfs[at] = tc.second;
+        }
+    LEX_TRY(dev_grow(&lx->d_post_row, &lx->post_cap, total));
+    LEX_TRY(dev_grow(&lx->d_post_tf, &lx->post_tf_cap, total));
+    LEX_TRY(dev_grow(&lx->d_doc_len, &lx->doc_cap, n_rows));
+    if (lx->scores_cap < n_rows || !lx->d_scores) {
+        LEX_HIP(hipStreamSynchronize(lx->stream));
+        LEX_TRY(dev_grow(&lx->d_scores, &lx->scores_cap, n_rows + n_rows / 4, /*zero=*/true));
+    }
+    if (total) {
+        LEX_HIP(hipMemcpy(lx->d_post_row, rows.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+        LEX_HIP(hipMemcpy(lx->d_post_tf, tfs.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (n_rows)
+        LEX_HIP(hipMemcpy(lx->d_doc_len, lx->doc_len.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice));
+    lx->dirty = false;
+    return RLR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t rlr_lexical_create(int32_t device_id, rlr_lexical **out)
+{
+    if (!out)
+        return set_error(RLR_E_INVALID, "out is null");
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return set_error(RLR_E_NO_DEVICE, "no HIP device: the lexical index has no CPU path");
+    if (device_id < 0 || device_id >= n_dev)
+        return set_error(RLR_E_NO_DEVICE, "device %d out of range (%d devices)", device_id, n_dev);
+    rlr_lexical *lx = new (std::nothrow) rlr_lexical();
+    if (!lx)
+        return set_error(RLR_E_OOM, "host allocation failed");
+    lx->device = device_id;
+    hipDeviceProp_t prop;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess)
+        e = hipGetDeviceProperties(&prop, device_id);
+    if (e == hipSuccess) {
+        lx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        e = hipStreamCreateWithFlags(&lx->stream, hipStreamNonBlocking);
+    }
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void **>(&lx->d_ctl), sizeof(LexControl));
+    if (e == hipSuccess)
+        e = hipMemset(lx->d_ctl, 0, sizeof(LexControl));
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void **>(&lx->d_sel), kMaxLimit * sizeof(uint64_t));
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void **>(&lx->d_out), (kMaxLimit + 1) * sizeof(uint64_t));
+    if (e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void **>(&lx->h_out), (kMaxLimit + 1) * sizeof(uint64_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        rlr_lexical_destroy(lx);
+        return set_error(e == hipErrorOutOfMemory ? RLR_E_OOM : RLR_E_HIP, "lexical index setup failed: %s",
+                         hipGetErrorString(e));
+    }
+    *out = lx;
+    return RLR_OK;
+}
+
+void rlr_lexical_destroy(rlr_lexical *lx)
+{
+    if (!lx)
+        return;
+    (void)hipSetDevice(lx->device);
+    if (lx->stream) {
+        (void)hipStreamSynchronize(lx->stream);
+        (void)hipStreamDestroy(lx->stream);
+    }
+    void *dev[] = {lx->d_post_row, lx->d_post_tf, lx->d_doc_len, lx->d_scores, lx->d_touched,
+                   lx->d_keys,     lx->d_sel,     lx->d_ctl,     lx->d_out};
+    for (void *p : dev)
+        if (p)
+            (void)hipFree(p);
+    if (lx->h_out)
+        (void)hipHostFree(lx->h_out);
+    delete lx;
+}
+
+int32_t rlr_lexical_add_chunk(rlr_lexical *lx, uint64_t row, const char *tokens, size_t len)
+{
+    if (!lx)
+        return set_error(RLR_E_INVALID, "lexical handle is null");
+    if (len && !tokens)
+        return set_error(RLR_E_INVALID, "tokens is null");
+    if (row >= 0xFFFFFFFFull)
+        return set_error(RLR_E_RANGE, "row %llu does not fit the 32-bit postings", static_cast<unsigned long long>(row));
+    std::lock_guard<std::mutex> lk(lx->mu);
+    if (row >= lx->doc_terms.size()) {
+        lx->doc_terms.resize(row + 1);
+        lx->doc_len.resize(row + 1, 0);
+    }
+    remove_row_stats(lx, row); // `if self.doc_terms.contains_key(id) { self.remove_chunk(id) }`
+    lx->dirty = true;
+    std::vector<std::string> toks;
+    split_tokens(tokens, len, &toks);
+    if (toks.empty())
+        return RLR_OK; // :2112-2114
+    std::unordered_map<uint32_t, uint32_t> counts;
+    std::vector<uint32_t> order; // first-occurrence order keeps the per-row list reproducible
+    for (const auto &t : toks) {
+        auto it = lx->term_id.find(t);
+        uint32_t id;
+        if (it == lx->term_id.end()) {
+            id = static_cast<uint32_t>(lx->df.size());
+            lx->term_id.emplace(t, id);
+            lx->df.push_back(0);
+        } else {
+            id = it->second;
+        }
+        if (counts[id]++ == 0)
+            order.push_back(id);
+    }
+    auto &terms = lx->doc_terms[row];
+    terms.reserve(order.size());
+    uint32_t doc_length = 0;
+    for (uint32_t id : order) {
+        terms.emplace_back(id, counts[id]);
+        doc_length += counts[id];
+        if (lx->df[id]++ == 0)
+            lx->n_live_terms++;
+    }
+    lx->n_postings += terms.size();
+    lx->doc_len[row] = doc_length;
+    lx->total_docs += 1;
+    lx->total_length += doc_length;
+    return RLR_OK;
+}
+
+int32_t rlr_lexical_remove_rows(rlr_lexical *lx, const uint64_t *rows, uint32_t n)
+{
+    if (!lx)
+        return set_error(RLR_E_INVALID, "lexical handle is null");
+    if (n == 0)
+        return RLR_OK;
+    if (!rows)
+        return set_error(RLR_E_INVALID, "rows is null");
+    std::lock_guard<std::mutex> lk(lx->mu);
+    const uint64_t size = lx->doc_terms.size();
+    std::vector<char> dead(size, 0);
+    bool any = false;
+    for (uint32_t i = 0; i < n; ++i)
+        if (rows[i] < size && !dead[rows[i]]) {
+            dead[rows[i]] = 1;
+            remove_row_stats(lx, rows[i]);
+            any = true;
+        }
+    if (!any)
+        return RLR_OK;
+    uint64_t w = 0; // stable compaction, the same renumbering rlr_index_delete_rows applies
+    for (uint64_t r = 0; r < size; ++r)
+        if (!dead[r]) {
+            if (w != r) {
+                lx->doc_terms[w] = std::move(lx->doc_terms[r]);
+                lx->doc_len[w] = lx->doc_len[r];
+            }
+            ++w;
+        }
+    lx->doc_terms.resize(w);
+    lx->doc_len.resize(w);
+    lx->dirty = true;
+    return RLR_OK;
+}
+
+int32_t rlr_lexical_clear(rlr_lexical *lx)
+{
+    if (!lx)
+        return set_error(RLR_E_INVALID, "lexical handle is null");
+    std::lock_guard<std::mutex> lk(lx->mu);
+    lx->term_id.clear();
+    lx->df.clear();
+    lx->doc_terms.clear();
+    lx->doc_len.clear();
+    lx->total_docs = lx->total_length = lx->n_postings = lx->n_live_terms = 0;
+    lx->dirty = true;
+    return RLR_OK;
+}
+
+int32_t rlr_lexical_contains(rlr_lexical *lx, uint64_t row)
+{
+    if (!lx)
+        return set_error(RLR_E_INVALID, "lexical handle is null");
+    std::lock_guard<std::mutex> lk(lx->mu);
+    return row < lx->doc_terms.size() && !lx->doc_terms[row].empty() ? 1 : 0;
+}
+
+int32_t rlr_lexical_info(rlr_lexical *lx, uint64_t *total_docs, uint64_t *total_length, uint64_t *n_terms,
+                         uint64_t *n_postings)
+{
+    if (!lx)
+        return set_error(RLR_E_INVALID, "lexical handle is null");
+    std::lock_guard<std::mutex> lk(lx->mu);
+    if (total_docs) *total_docs = lx->total_docs;
+    if (total_length) *total_length = lx->total_length;
+    if (n_terms) *n_terms = lx->n_live_terms;
+    if (n_postings) *n_postings = lx->n_postings;
+    return RLR_OK;
+}
+
+int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, uint64_t *rows_out,
+                          float *scores_out, uint32_t *n_out)
+{
+    if (!lx)
+        return set_error(RLR_E_INVALID, "lexical handle is null");
+    if (!n_out)
+        return set_error(RLR_E_INVALID, "n_out is null");
+    *n_out = 0;
+    if (len && !query_tokens)
+        return set_error(RLR_E_INVALID, "query_tokens is null");
+    std::lock_guard<std::mutex> lk(lx->mu);
+    if (lx->total_docs == 0) // :2170-2172
+        return RLR_OK;
+    std::vector<std::string> toks;
+    split_tokens(query_tokens, len, &toks);
+    if (toks.empty()) // :2175-2177
+        return RLR_OK;
+    const uint32_t lim = limit == 0 ? kMaxLimit : std::min(limit, kMaxLimit);
+    if (!rows_out || !scores_out)
+        return set_error(RLR_E_INVALID, "rows_out / scores_out is null");
+    LEX_HIP(hipSetDevice(lx->device));
+    if (lx->dirty)
+        LEX_TRY(commit(lx));
+
+    // unique query terms in order of first occurrence (:2179-2182 uses a HashSet: order unspecified there)
+    std::vector<uint32_t> terms;
+    for (const auto &t : toks) {
+        auto it = lx->term_id.find(t);
+        if (it == lx->term_id.end() || lx->df[it->second] == 0)
+            continue; // `if let Some(postings) = self.term_postings.get(&term)` :2196
+        if (std::find(terms.begin(), terms.end(), it->second) == terms.end())
+            terms.push_back(it->second);
+    }
+    uint64_t upper = 0;
+    for (uint32_t t : terms)
+        upper += lx->df[t];
+    if (upper == 0)
+        return RLR_OK;
+    upper = std::min<uint64_t>(upper, lx->doc_terms.size()); // at most one touched entry per row
+    LEX_TRY(dev_grow(&lx->d_touched, &lx->touched_cap, upper));
+
+    const float n_docs = static_cast<float>(lx->total_docs);
+    const float avg = static_cast<float>(lx->total_length) / n_docs; // :2184-2188
+    hipStream_t s = lx->stream;
+    const uint32_t max_blocks = static_cast<uint32_t>(lx->n_cu) * 8;
+    for (uint32_t t : terms) {
+        const float df = static_cast<float>(lx->df[t]);
+        float idf = std::log((n_docs - df + 0.5f) / (df + 0.5f)); // f32 ln (:2198-2200)
+        idf = idf > 0.0f ? idf : 0.0f;                            // f32::max(0.0): NaN -> 0
+        const uint32_t cnt = lx->df[t];
+        const uint64_t off = lx->term_off[t];
+        const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, max_blocks);
+        hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_post_row + off, lx->d_post_tf + off, cnt,
+                           lx->d_doc_len, avg, idf, lx->d_scores, lx->d_touched, lx->d_ctl);
+    }
+    LEX_HIP(hipGetLastError());
+    uint32_t *d_out_n = reinterpret_cast<uint32_t *>(lx->d_out + kMaxLimit);
+    const uint32_t blocks_u = std::min<uint32_t>(static_cast<uint32_t>((upper + 255) / 256), max_blocks);
+    if (upper <= kMaxLimit) {
+        hipLaunchKernelGGL(lex_sort_kernel<true>, dim3(1), dim3(1024), 0, s, lx->d_scores, lx->d_touched, nullptr, lx->d_ctl,
+                           lim, lx->d_out, d_out_n);
+    } else {
+        LEX_TRY(dev_grow(&lx->d_keys, &lx->keys_cap, upper));
+        hipLaunchKernelGGL(lex_pack_kernel, dim3(blocks_u), dim3(256), 0, s, lx->d_scores, lx->d_touched, lx->d_ctl,
+                           lx->d_keys);
+        for (int p = 0; p < kPasses; ++p)
+            hipLaunchKernelGGL(lex_select_pass_kernel, dim3(blocks_u), dim3(256), 0, s, lx->d_keys, lx->d_ctl, lim, p);
+        hipLaunchKernelGGL(lex_collect_kernel, dim3(blocks_u), dim3(256), 0, s, lx->d_keys, lx->d_ctl, lim, lx->d_sel);
+        hipLaunchKernelGGL(lex_sort_kernel<false>, dim3(1), dim3(1024), 0, s, nullptr, nullptr, lx->d_sel, lx->d_ctl, lim,
+                           lx->d_out, d_out_n);
+    }
+    LEX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(lex_clear_kernel, dim3(blocks_u), dim3(256), 0, s, lx->d_scores, lx->d_touched, lx->d_ctl);
+    LEX_HIP(hipGetLastError());
+    LEX_HIP(hipMemsetAsync(lx->d_ctl, 0, sizeof(LexControl), s));
+    // one copy: the count sits right behind the keys; only `lim` keys can be valid
+    LEX_HIP(hipMemcpyAsync(lx->h_out + kMaxLimit, lx->d_out + kMaxLimit, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    LEX_HIP(hipMemcpyAsync(lx->h_out, lx->d_out, static_cast<size_t>(lim) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    LEX_HIP(hipStreamSynchronize(s));
+    const uint32_t n = std::min<uint32_t>(*reinterpret_cast<const uint32_t *>(lx->h_out + kMaxLimit), lim);
+    for (uint32_t i = 0; i < n; ++i) {
+        float sc;
+        uint32_t row;
+        unpack_result(lx->h_out[i], &sc, &row);
+        rows_out[i] = row;
+        scores_out[i] = sc;
+    }
+    *n_out = n;
+    return RLR_OK;
+}
+
+int32_t rlr_tokenize_ascii(const char *text, size_t len, char *out, size_t cap, size_t *out_len)
+{
+    if ((len && !text) || !out_len)
+        return set_error(RLR_E_INVALID, "null argument");
+    size_t w = 0;
+    bool first = true;
+    size_t i = 0;
+    auto alnum = [](unsigned char c) { return c >= 0x80 || (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); };
+    while (i < len) {
+        while (i < len && !alnum(static_cast<unsigned char>(text[i])))
+            ++i;
+        size_t j = i;
+        while (j < len && alnum(static_cast<unsigned char>(text[j])))
+            ++j;
+        if (j - i >= 3) { // `token.len() >= 3`: bytes
+            if (!first) {
+                if (out && w < cap)
+                    out[w] = ' ';
+                ++w;
+            }
+            for (size_t p = i; p < j; ++p) {
+                const unsigned char c = static_cast<unsigned char>(text[p]);
+                if (out && w < cap)
+                    out[w] = static_cast<char>((c >= 'A' && c <= 'Z') ? c + 32 : c);
+                ++w;
+            }
+            first = false;
+        }
+        i = j;
+    }
+    *out_len = w;
+    if (w > cap)
+        return set_error(RLR_E_RANGE, "tokenize: output needs %zu bytes, capacity is %zu", w, cap);
+    return RLR_OK;
+}
+
+} // extern "C"

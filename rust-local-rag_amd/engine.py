@@ -22,6 +22,7 @@ import numpy as np
 
 from . import _native as N
 from .index import GpuIndex, _f32
+from .lexical import LexicalIndex
 
 
 @dataclass
@@ -116,6 +117,7 @@ class SearchRequest:  # mcp_server.rs:17-31
     diversity_factor: Optional[float] = None
     weights: Optional[QueryWeights] = None
     lexical: Sequence[Tuple[str, float]] = field(default_factory=list)
+    query: Optional[str] = None   # the query text (mcp_server.rs:19); scored by the GPU LexicalIndex when given
 
 
 class RagEngine:
@@ -123,12 +125,14 @@ class RagEngine:
 
     def __init__(self, dim: int, dtype: str = "f32", device: int = 0):
         self.index = GpuIndex(dim, dtype, device)
+        self.lexical = LexicalIndex(device)          # BM25 postings in HBM (rag_engine.rs:112)
         self.dim = dim
         self._chunks: List[DocumentChunk] = []       # row -> chunk
         self._row_of: Dict[str, int] = {}            # chunk_id -> row
 
     def close(self) -> None:
         self.index.close()
+        self.lexical.close()
 
     # -- index mutation (sites rag_engine.rs:347-348, :358-384) --------------------------
     def add_document(self, document_name: str, texts: Sequence[str], embeddings, pages: Optional[Sequence[int]] = None,
@@ -143,6 +147,7 @@ class RagEngine:
             ch = DocumentChunk(cid, document_name, text, i, pages[i] if pages else 0, sections[i] if sections else None)
             self._chunks.append(ch)
             self._row_of[cid] = first + i
+            self.lexical.add_chunk(first + i, text)   # lexical_index.add_chunk(&chunk.id, &chunk.text) :382
             ids.append(cid)
         return ids
 
@@ -150,6 +155,7 @@ class RagEngine:
         dead = [r for r, ch in enumerate(self._chunks) if ch.document_name == document_name]
         if dead:
             self.index.delete_rows(dead)  # chunks.retain(|_, c| c.document_name != filename)
+            self.lexical.remove_rows(dead)
             dead_set = set(dead)
             self._chunks = [ch for r, ch in enumerate(self._chunks) if r not in dead_set]
             self._row_of = {ch.id: r for r, ch in enumerate(self._chunks)}
@@ -159,7 +165,13 @@ class RagEngine:
         return len(self._chunks)
 
     # -- helpers ---------------------------------------------------------------------------
-    def _lex(self, lexical: Sequence[Tuple[str, float]]):
+    def _lex(self, lexical: Sequence[Tuple[str, float]], query_text: Optional[str] = None, limit: int = 0):
+        if query_text is not None:
+            # `self.lexical_index.score(query, top_k.saturating_mul(5))` :505, on the GPU
+            lr, ls = self.lexical.score(query_text, limit)
+            if lr.size == 0:
+                return np.zeros(1, np.uint64), np.zeros(1, np.float32), 0
+            return np.ascontiguousarray(lr), np.ascontiguousarray(ls), int(lr.size)
         rows = [self._row_of[cid] for cid, _ in lexical if cid in self._row_of]
         scores = [s for cid, s in lexical if cid in self._row_of]
         lr = np.ascontiguousarray(rows if rows else [0], dtype=np.uint64)
@@ -178,12 +190,14 @@ class RagEngine:
 
     # -- RagEngine::search (rag_engine.rs:470-701) -----------------------------------------
     def search(self, query_embedding, top_k: int, weights: Optional[QueryWeights] = None,
-               lexical: Sequence[Tuple[str, float]] = (), stage: int = 0) -> List[SearchResult]:
+               lexical: Sequence[Tuple[str, float]] = (), stage: int = 0,
+               query_text: Optional[str] = None) -> List[SearchResult]:
+        """`lexical`: BM25 pairs computed by the caller, or `query_text`: scored by the GPU LexicalIndex."""
         q = _f32(query_embedding).ravel()
         cap = max(3 * max(top_k, 1), 1)
         hits = (N.SearchHitC * cap)()
         n = C.c_uint32()
-        lr, ls, nl = self._lex(lexical)
+        lr, ls, nl = self._lex(lexical, query_text, 5 * top_k)
         wc = weights.to_c() if weights is not None else None
         N.check(N.lib().rlr_engine_search(self.index.handle, q.ctypes.data_as(N.f32p), q.size, top_k,
                                           C.byref(wc) if wc is not None else None, lr.ctypes.data_as(N.u64p),
@@ -193,12 +207,15 @@ class RagEngine:
     # -- RagEngine::search_with_diversity (rag_engine.rs:717-759) --------------------------
     def search_with_diversity(self, query_embedding, top_k: int, diversity_factor: float,
                               weights: Optional[QueryWeights] = None,
-                              lexical: Sequence[Tuple[str, float]] = ()) -> List[SearchResult]:
+                              lexical: Sequence[Tuple[str, float]] = (),
+                              query_text: Optional[str] = None) -> List[SearchResult]:
         q = _f32(query_embedding).ravel()
         cap = max(3 * max(top_k, 1), top_k + 10)
         hits = (N.SearchHitC * cap)()
         n = C.c_uint32()
-        lr, ls, nl = self._lex(lexical)
+        lam = min(max(float(diversity_factor), 0.0), 1.0)
+        k_eff = top_k if lam == 0.0 else max(3 * top_k, top_k + 10)  # the top_k `search` sees (:728-735)
+        lr, ls, nl = self._lex(lexical, query_text, 5 * k_eff)
         wc = weights.to_c() if weights is not None else None
         N.check(N.lib().rlr_engine_search_with_diversity(
             self.index.handle, q.ctypes.data_as(N.f32p), q.size, top_k, float(diversity_factor),
@@ -270,7 +287,8 @@ class RagEngine:
         top_k = min(request.top_k if request.top_k is not None else N.DEFAULT_TOP_K, N.MAX_TOP_K)
         div = request.diversity_factor if request.diversity_factor is not None else N.DEFAULT_DIVERSITY
         div = min(max(div, 0.0), 1.0)
-        return self.search_with_diversity(request.query_embedding, top_k, div, request.weights, request.lexical)
+        return self.search_with_diversity(request.query_embedding, top_k, div, request.weights, request.lexical,
+                                          request.query)
 
 
 def format_search_results(results: Sequence[SearchResult]) -> str:

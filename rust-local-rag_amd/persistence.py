@@ -103,6 +103,7 @@ def _apply_loaded_state(engine: RagEngine, state: dict, source: str, data_dir: s
     if version < 2:
         # outdated format: clear and mark for reindex (:1664-1672)
         engine.index.upload(np.zeros((0, engine.dim), np.float32))
+        engine.lexical.clear()
         engine._chunks, engine._row_of = [], {}
         rep.needs_reindex = True
         save_to_disk(engine, data_dir, model_name, needs_reindex=True)
@@ -123,6 +124,10 @@ def _apply_loaded_state(engine: RagEngine, state: dict, source: str, data_dir: s
     engine.index.upload(rows, normalize=True)
     engine._chunks = metas
     engine._row_of = {ch.id: r for r, ch in enumerate(metas)}
+    # validate_index_sync (:1378-1388): every chunk is (re-)added to the lexical index
+    engine.lexical.clear()
+    for r, ch in enumerate(metas):
+        engine.lexical.add_chunk(r, ch.text)
     rep.n_chunks = n
     rep.needs_reindex = bool(state.get("needs_reindex", False))
     rep.document_hashes = dict(state.get("document_hashes", {}))

@@ -12,7 +12,7 @@ from conftest import ROOT, pf
 
 def _declared_symbols():
     names = set()
-    for hdr in ("rlr_gpu.h", "rlr_engine.h"):
+    for hdr in ("rlr_gpu.h", "rlr_engine.h", "rlr_lexical.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(rlr_[a-z0-9_]+)\s*\(", text))

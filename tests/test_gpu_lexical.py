@@ -1,0 +1,143 @@
+"""GPU BM25 (include/rlr_lexical.h) against the oracle restatement of LexicalIndex
+(oracle/lexical.py): rows and scores bit-exact, both selection paths, mutations, and the hybrid
+search end to end from query text."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import lexical as OL
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+VOCAB = [f"w{i:03d}x" for i in range(400)] + ["common", "frequent", "the", "of", "né", "Straße", "ÉTÉ"]
+
+
+def make_texts(n, seed, lo=3, hi=40, common_every=0):
+    rng = np.random.default_rng(seed)
+    zipf = 1.0 / np.arange(1, len(VOCAB) + 1)
+    zipf /= zipf.sum()
+    texts = []
+    for i in range(n):
+        m = int(rng.integers(lo, hi))
+        words = list(rng.choice(VOCAB, size=m, p=zipf))
+        if common_every and i % common_every == 0:
+            words.append("ubiquitous")
+        texts.append(" ".join(words) + (", " if i % 3 else " - "))
+    return texts
+
+
+def build_pair(rlr, texts):
+    lex = importlib.import_module("rust-local-rag_amd.lexical")
+    g = lex.LexicalIndex(0)
+    o = OL.LexicalIndex()
+    for r, t in enumerate(texts):
+        g.add_chunk(r, t)
+        o.add_chunk(r, t, rank=r)
+    return g, o
+
+
+def check(g, o, query, limit):
+    rows, sc = g.score(query, limit)
+    want = o.score(query, limit if limit else 0, keep_zero=False)
+    if limit == 0:
+        want = want[:8192]
+    assert [int(r) for r in rows] == [c for c, _ in want], (query, limit)
+    assert np.array_equal(bits(sc), bits([s for _, s in want])), (query, limit)
+    return len(rows)
+
+
+def test_bm25_small_corpus_bit_exact(rlr):
+    texts = make_texts(1500, seed=1)
+    g, o = build_pair(rlr, texts)
+    info = g.info()
+    assert info["total_docs"] == o.total_docs and info["total_length"] == o.total_length
+    assert info["n_terms"] == len(o.term_postings)
+    assert info["n_postings"] == sum(len(p) for p in o.term_postings.values())
+    n_hit = 0
+    for q, lim in [("w000x", 25), ("w017x w101x", 50), ("W399X, w250x; w250x w003x", 500), ("unknown words only", 10),
+                   ("né Straße été", 100), ("w005x", 0), ("the of", 1500), ("it is", 5), ("", 5),
+                   ("w001x w002x w003x w004x w005x w006x w007x w008x w009x w010x w011x", 7)]:
+        n_hit += check(g, o, q, lim)
+    assert n_hit > 500
+    g.close()
+
+
+def test_bm25_select_path_many_postings_and_ties(rlr):
+    """> 8192 touched documents -> radix select over the packed keys; short identical documents give
+    massive exact score ties that must resolve to the lower row"""
+    texts = make_texts(40000, seed=2, lo=2, hi=6, common_every=3)  # 13 334 documents hold "ubiquitous"
+    texts += ["ubiquitous rare"] * 50 + ["rare"] * 3
+    g, o = build_pair(rlr, texts)
+    for q, lim in [("ubiquitous", 100), ("ubiquitous", 1500), ("ubiquitous rare w000x", 8192), ("w000x w001x common", 300),
+                   ("ubiquitous", 0)]:
+        n = check(g, o, q, lim)
+        assert n == (lim if lim else 8192)  # every query here has more positive documents than that
+    g.close()
+
+
+def test_bm25_mutations_follow_row_compaction(rlr):
+    lex = importlib.import_module("rust-local-rag_amd.lexical")
+    texts = make_texts(300, seed=3)
+    g, o = build_pair(rlr, texts)
+    check(g, o, "w000x w001x", 40)
+    # re-add replaces (:2107-2109); a chunk without tokens is not indexed
+    g.add_chunk(5, "w000x w000x w000x brandnew")
+    o.add_chunk(5, "w000x w000x w000x brandnew", rank=5)
+    g.add_chunk(6, "a b")
+    o.add_chunk(6, "a b", rank=6)
+    assert g.contains(5) and not g.contains(6) and not g.contains(10_000)
+    check(g, o, "w000x brandnew", 40)
+    # delete rows: survivors move down, exactly like GpuIndex.delete_rows
+    dead = [0, 7, 8, 150, 299]
+    g.remove_rows(dead)
+    o2 = OL.LexicalIndex()
+    keep = [r for r in range(300) if r not in dead]
+    cur = {r: texts[r] for r in range(300)}
+    cur[5] = "w000x w000x w000x brandnew"
+    cur[6] = "a b"
+    for new_r, r in enumerate(keep):
+        o2.add_chunk(new_r, cur[r], rank=new_r)
+    assert g.info()["total_docs"] == o2.total_docs and g.info()["total_length"] == o2.total_length
+    for q in ("w000x brandnew", "w002x w003x", "common"):
+        check(g, o2, q, 60)
+    g.clear()
+    assert g.info()["total_docs"] == 0 and g.score("w000x", 5)[0].size == 0
+    g.close()
+    assert lex.tokenize("x") == []
+
+
+def test_engine_hybrid_search_from_query_text(rlr, oracle):
+    """RagEngine.search(query_text=...): GPU BM25 feeds the hybrid blend; same results as the oracle's
+    search given the oracle's lexical pairs (rag_engine.rs:505-545)."""
+    n, dim, k = 1200, 256, 10
+    texts = make_texts(n, seed=4)
+    rows = oracle.synth_rows(n, dim, seed=44)
+    eng = rlr.RagEngine(dim)
+    eng.add_document("doc.pdf", texts, rows)
+    stored = eng.index.fetch_rows(np.arange(n))
+    o = OL.LexicalIndex()
+    for r, t in enumerate(texts):
+        o.add_chunk(r, t, rank=r)
+    q = oracle.synth_query(dim, seed=45)
+    for text, div in (("w010x w020x common", 0.0), ("w001x", 0.0), ("w003x w004x", 0.4)):
+        k_eff = k if div == 0.0 else max(3 * k, k + 10)
+        pairs = [(c, float(s)) for c, s in o.score(text, 5 * k_eff, keep_zero=False)]
+        got = eng.search_with_diversity(q, k, div, query_text=text)
+        wr, wc, we, wl = oracle.search_with_diversity(stored, q, k, div, lex=pairs)
+        assert [g_.row for g_ in got] == list(wr), text
+        assert np.array_equal(bits([g_.score for g_ in got]), bits(wc)), text
+        assert np.array_equal(bits([g_.lexical_score for g_ in got]), bits(wl)), text
+    # removing a document drops its postings
+    eng.add_document("other.pdf", ["solitaryterm appears here"], oracle.synth_rows(1, dim, seed=46))
+    assert eng.lexical.score("solitaryterm", 5)[0].tolist() == [n]
+    eng.remove_document("doc.pdf")
+    # one document left: it moved to row 0 (idf of a term held by the only document is floored at 0)
+    assert eng.lexical.contains(0) and not eng.lexical.contains(1) and eng.lexical.info()["total_docs"] == 1
+    assert eng.lexical.score("solitaryterm", 5)[0].size == 0
+    eng.close()

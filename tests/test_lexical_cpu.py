@@ -1,0 +1,70 @@
+"""Oracle of the lexical term (oracle/lexical.py) against the one case the reference's own tests
+hold for LexicalIndex, plus hand-computed BM25 values and the tokenizer's edge cases."""
+import importlib
+import math
+
+import numpy as np
+
+from oracle import lexical as OL
+
+
+def test_reference_contains_and_drop_stale():
+    """rag_engine.rs:2295-2326 test_lexical_index_contains_and_drop_stale"""
+    ix = OL.LexicalIndex()
+    ix.add_chunk("chunk1", "hello world")
+    ix.add_chunk("chunk2", "foo bar baz")
+    ix.add_chunk("chunk3", "test document")
+    assert ix.contains("chunk1") and ix.contains("chunk2") and ix.contains("chunk3")
+    assert not ix.contains("chunk4")
+    ix.drop_stale({"chunk1", "chunk2"})
+    assert ix.contains("chunk1") and ix.contains("chunk2")
+    assert not ix.contains("chunk3")
+    assert ix.total_docs == 2 and ix.total_length == 5
+
+
+def test_tokenize_rules():
+    assert OL.tokenize("Hello, World! it's a DB-9 plug") == ["hello", "world", "plug"]   # < 3 bytes dropped
+    assert OL.tokenize("naïve café ÉTÉ") == ["naïve", "café", "été"]                      # Unicode lower-casing
+    assert OL.tokenize("né") == ["né"]              # 2 chars but 3 bytes: kept (`token.len()` counts bytes)
+    assert OL.tokenize("ab  __ c") == []
+    assert OL.tokenize("x86_64 abc123") == ["x86", "abc123"]
+
+
+def test_bm25_hand_computed():
+    ix = OL.LexicalIndex()
+    ix.add_chunk("a", "alpha beta beta gamma")        # len 4
+    ix.add_chunk("b", "alpha delta")                  # len 2
+    ix.add_chunk("c", "epsilon zeta eta theta iota")  # len 5 ("eta" has 3 bytes)
+    assert ix.total_docs == 3 and ix.total_length == 11
+    res = dict(ix.score("beta", 10))
+    avg = np.float32(11) / np.float32(3)
+    idf = np.float32(math.log((3 - 1 + 0.5) / (1 + 0.5)))
+    want = idf * (np.float32(2) * np.float32(2.5)) / (np.float32(2) + np.float32(1.5) * (np.float32(0.25) + np.float32(0.75) * (np.float32(4) / avg)))
+    assert set(res) == {"a"} and abs(float(res["a"]) - float(want)) < 1e-6
+    # "alpha" is in 2 of 3 docs: idf = ln(1.5/2.5) < 0 -> floored at 0 -> both documents score exactly 0.0
+    res = ix.score("alpha", 10)
+    assert [c for c, _ in res] == ["a", "b"] and all(float(s) == 0.0 for _, s in res)
+    assert ix.score("alpha", 10, keep_zero=False) == []
+    assert ix.score("it is", 10) == [] and ix.score("unknownterm", 10) == []
+    # limit truncation, sorted descending
+    res = ix.score("beta delta epsilon", 2)
+    assert len(res) == 2 and float(res[0][1]) >= float(res[1][1])
+
+
+def test_re_add_replaces_and_empty_text_is_not_indexed():
+    ix = OL.LexicalIndex()
+    ix.add_chunk("a", "one two three")
+    ix.add_chunk("a", "four five")
+    assert ix.total_docs == 1 and ix.total_length == 2 and "one" not in ix.term_postings
+    ix.add_chunk("b", "a b c")     # no token survives
+    assert not ix.contains("b") and ix.total_docs == 1
+    ix.remove_chunk("a")
+    assert ix.total_docs == 0 and ix.total_length == 0 and ix.score("four", 5) == []
+
+
+def test_library_tokenizer_ascii_exact(rlr):
+    lex = importlib.import_module("rust-local-rag_amd.lexical")
+    for text in ["Hello, World! it's a DB-9 plug", "x86_64 abc123", "", "ab cd", "The Quick brown-fox_jumps"]:
+        assert lex.tokenize_ascii(text) == OL.tokenize(text)
+        assert lex.tokenize(text) == OL.tokenize(text)
+    assert lex.tokenize("naïve café ÉTÉ né") == OL.tokenize("naïve café ÉTÉ né")
