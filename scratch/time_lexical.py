@@ -1,0 +1,27 @@
+import importlib, sys, time
+import numpy as np
+sys.path.insert(0, '.')
+lex = importlib.import_module("rust-local-rag_amd.lexical")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+rng = np.random.default_rng(0)
+V = 50000
+vocab = np.array([f"t{i:05d}" for i in range(V)])
+zipf = 1.0 / np.arange(1, V + 1); zipf /= zipf.sum()
+g = lex.LexicalIndex(0)
+t0 = time.perf_counter()
+B = 10000
+for b0 in range(0, n, B):
+    words = rng.choice(V, size=(B, 30), p=zipf)
+    for i in range(B):
+        g.add_tokens(b0 + i, vocab[words[i]])
+print("built %d docs in %.1f s" % (n, time.perf_counter() - t0), g.info(), flush=True)
+t0 = time.perf_counter(); g.score_tokens(["t00000"], 10); print("first score (commit + upload) %.2f s" % (time.perf_counter() - t0))
+for name, toks in [("rare 1 term", ["t20000"]), ("mid 3 terms", ["t00100", "t00200", "t00300"]),
+                   ("common 1 term", ["t00001"]), ("common+mid 5 terms", ["t00001", "t00002", "t00010", "t00100", "t01000"])]:
+    for lim in (500, 1500):
+        g.score_tokens(toks, lim)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            r, s = g.score_tokens(toks, lim)
+        dt = (time.perf_counter() - t0) / 20
+        print("%-20s limit %4d: %7.1f us, %d results, top %.4f" % (name, lim, dt * 1e6, len(r), s[0] if len(s) else 0))
