@@ -18,6 +18,8 @@
 //
 // The summation order differs from the reference's strict left-to-right order, so these
 // scores only NOMINATE candidates (guard band, select.hip); exact.hip re-scores them.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 #include "../../include/rlr_gpu.h"
@@ -155,6 +157,121 @@ __global__ __launch_bounds__(256) void scan_fixed_kernel(const float4 *__restric
 }
 
 // ---------------------------------------------------------------------------
+// Packed kernel: row pitch a multiple of 256 B but not of 1 KiB (384-d f32, 768-d f16, ...).
+// G = 64 / gcd(P16, 64) consecutive rows form a contiguous "pack" of exactly M = G * P16 / 64
+// wave-wide 16-byte loads, so every load instruction is still 64 lanes x 16 B of consecutive
+// addresses; a lane's position inside the pack decides which row and which query column it
+// serves (fixed per lane: the query stays in registers), loads that straddle two rows feed two
+// accumulators through a lane mask, and each row still costs one DPP wave reduction.
+// ---------------------------------------------------------------------------
+constexpr int pack_gcd(int a, int b) { return b == 0 ? a : pack_gcd(b, a % b); }
+
+template <int P16>
+struct PackShape {
+    static constexpr int G = 64 / pack_gcd(P16, 64);        // rows per pack
+    static constexpr int M = G * P16 / 64;                   // loads per pack
+    static constexpr int R = M >= 9 ? 1 : (M >= 5 ? 2 : (M >= 2 ? 4 : 8)); // packs in flight (8-14 loads per lane)
+};
+
+template <int P16, bool F16>
+__global__ __launch_bounds__(256) void scan_packed_kernel(const float4 *__restrict__ rows,
+                                                          const float *__restrict__ query,
+                                                          float *__restrict__ scores,
+                                                          uint32_t *__restrict__ g_hist,
+                                                          uint32_t n_rows, uint32_t group_rows)
+{
+    constexpr int G = PackShape<P16>::G, M = PackShape<P16>::M, R = PackShape<P16>::R;
+    constexpr int QF4 = F16 ? 2 * P16 : P16;
+    __shared__ float4 s_q[QF4];
+    __shared__ uint32_t s_hist[kHistBins];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < QF4; i += 256)
+        s_q[i] = reinterpret_cast<const float4 *>(query)[i];
+    for (int i = tid; i < kHistBins; i += 256)
+        s_hist[i] = 0;
+    __syncthreads();
+
+    float4 qv[F16 ? 2 * M : M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const int col = (j * 64 + lane) % P16;
+        if constexpr (F16) {
+            qv[2 * j] = s_q[2 * col];
+            qv[2 * j + 1] = s_q[2 * col + 1];
+        } else {
+            qv[j] = s_q[col];
+        }
+    }
+
+    const size_t last_unit = static_cast<size_t>(n_rows) * P16 - 1; // loads past the matrix end re-read its last 16 B
+    const uint32_t n_groups = (n_rows + group_rows - 1) / group_rows;
+    const uint32_t n_waves = gridDim.x * 4;
+    for (uint32_t g = blockIdx.x * 4 + wave; g < n_groups; g += n_waves) {
+        const uint32_t row0 = g * group_rows;
+        const uint32_t nr = min(group_rows, n_rows - row0);
+        float mine = 0.0f;
+        for (uint32_t r = 0; r < nr; r += R * G) {
+            float4 x[R][M];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                // packs past the group end are clamped to its last pack (their lanes are never stored)
+                const uint32_t pack_row = min(row0 + r + rr * G, row0 + ((nr - 1) / G) * G);
+                const size_t base = static_cast<size_t>(pack_row) * P16 + lane;
+#pragma unroll
+                for (int j = 0; j < M; ++j)
+                    x[rr][j] = ld16<true>(rows + min(base + j * 64, last_unit));
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                float acc[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k)
+                    acc[k] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    const int g_lo = (j * 64) / P16, g_hi = (j * 64 + 63) / P16;
+                    if (g_lo == g_hi) {
+                        if constexpr (F16)
+                            acc[g_lo] = dot8h(x[rr][j], qv[2 * j], qv[2 * j + 1], acc[g_lo]);
+                        else
+                            acc[g_lo] = dot4(x[rr][j], qv[j], acc[g_lo]);
+                    } else {
+                        float t;
+                        if constexpr (F16)
+                            t = dot8h(x[rr][j], qv[2 * j], qv[2 * j + 1], 0.0f);
+                        else
+                            t = dot4(x[rr][j], qv[j], 0.0f);
+                        const int lane_row = (j * 64 + lane) / P16;
+#pragma unroll
+                        for (int k = 0; k < G; ++k)
+                            if (k >= g_lo && k <= g_hi)
+                                acc[k] += lane_row == k ? t : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const float tot = wave_sum(acc[k]);
+                    if (static_cast<uint32_t>(lane) == r + rr * G + k)
+                        mine = tot;
+                }
+            }
+        }
+        if (static_cast<uint32_t>(lane) < nr) {
+            scores[row0 + lane] = mine;
+            if (g_hist)
+                atomicAdd(&s_hist[score_key(mine) >> 21], 1u);
+        }
+    }
+    if (g_hist) {
+        __syncthreads();
+        hist_flush(s_hist, g_hist);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Generic kernel: any dim (row pitch padded to 16 B, pad = 0), query read from LDS.
 // ---------------------------------------------------------------------------
 template <int R, bool F16>
@@ -198,7 +315,7 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(const float4 *__restr
                 float4 x[R];
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr)
-                    x[rr] = p[rr][c];
+                    x[rr] = ld16<true>(p[rr] + c);
                 if constexpr (F16) {
                     const float4 q0 = s_q[2 * c], q1 = s_q[2 * c + 1];
 #pragma unroll
@@ -306,13 +423,57 @@ bool fixed_shape(const ScanArgs &a, int *ch)
     if (elems != a.dim)
         return false;
     if (a.dtype == RLR_F16) {
-        if (c != 1 && c != 2)
+        if (c < 1 || c > 4)
             return false;
-    } else if (c < 1 || c > 4) {
+    } else if (c < 1 || c > 8 || c == 7) {
         return false;
     }
     *ch = c;
     return true;
+}
+
+// wide rows (CH >= 5: 1280/1536/2048-d f32): two rows in flight keep the kernel at 8 waves/SIMD
+template <int CH, bool F16>
+hipError_t launch_fixed_wide(const ScanArgs &a, ScanPlan p, hipStream_t s)
+{
+    p.r = 2;
+    p.group_rows = std::max<uint32_t>((p.group_rows / 2) * 2, 2);
+    p.blocks = std::max<uint32_t>(1, std::min<uint32_t>(p.blocks, ((a.n_rows + p.group_rows - 1) / p.group_rows + 3) / 4));
+    hipLaunchKernelGGL((scan_fixed_kernel<CH, 2, F16, true>), dim3(p.blocks), dim3(256), 0, s,
+                       static_cast<const float4 *>(a.rows), a.query, a.scores, a.hist, a.n_rows, p.group_rows);
+    return hipGetLastError();
+}
+
+template <int P16, bool F16>
+hipError_t launch_packed_one(const ScanArgs &a, ScanPlan p, hipStream_t s)
+{
+    constexpr uint32_t step = PackShape<P16>::R * PackShape<P16>::G; // rows per loop iteration
+    uint32_t group = std::max<uint32_t>(p.group_rows, step);
+    group = std::min<uint32_t>(64, (group / step) * step);
+    const uint32_t n_groups = (a.n_rows + group - 1) / group;
+    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_groups + 3) / 4, static_cast<uint32_t>(a.n_cu) * 8));
+    hipLaunchKernelGGL((scan_packed_kernel<P16, F16>), dim3(blocks), dim3(256), 0, s, static_cast<const float4 *>(a.rows),
+                       a.query, a.scores, a.hist, a.n_rows, group);
+    return hipGetLastError();
+}
+
+// Row pitches served by the packed kernel: the short rows (256 B and 512 B), where the generic kernel
+// leaves most lanes of a wave idle.  Measured on MI355X, 24 GB corpora, GB/s packed vs generic (both with
+// non-temporal loads; scratch/packed_ab.sh):
+//   64-d f32 6119/4053   128-d f32 6130/5898   128-d f16 5923/3520   256-d f16 6296/5935
+// From 320-d f32 / 768-d f16 upwards the two kernels are within noise of each other (6.5-6.6 TB/s), so
+// those pitches stay on the generic kernel (one instantiation instead of one per pitch).
+bool launch_packed(const ScanArgs &a, const ScanPlan &p, hipStream_t s, hipError_t *e)
+{
+    const uint32_t elems = a.dtype == RLR_F16 ? a.pitch16 * 8 : a.pitch16 * 4;
+    if (elems != a.dim || (a.variant & 0x20)) // bit 5 of RLR_SCAN_VARIANT: force the generic kernel (A/B)
+        return false;
+    const bool h = a.dtype == RLR_F16;
+    switch (a.pitch16) {
+    case 16: *e = h ? launch_packed_one<16, true>(a, p, s) : launch_packed_one<16, false>(a, p, s); return true;
+    case 32: *e = h ? launch_packed_one<32, true>(a, p, s) : launch_packed_one<32, false>(a, p, s); return true;
+    default: return false;
+    }
 }
 
 } // namespace
@@ -329,15 +490,26 @@ hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
                 p.r = 4;
                 p.group_rows = (p.group_rows / 4) * 4;
             }
-            return ch == 1 ? launch_fixed<1, true>(a, p, s) : launch_fixed<2, true>(a, p, s);
+            switch (ch) {
+            case 1: return launch_fixed<1, true>(a, p, s);
+            case 2: return launch_fixed<2, true>(a, p, s);
+            case 3: return launch_fixed_wide<3, true>(a, p, s);
+            default: return launch_fixed_wide<4, true>(a, p, s);
+            }
         }
         switch (ch) {
         case 1: return launch_fixed<1, false>(a, p, s);
         case 2: return launch_fixed<2, false>(a, p, s);
         case 3: return launch_fixed<3, false>(a, p, s);
-        default: return launch_fixed<4, false>(a, p, s);
+        case 4: return launch_fixed<4, false>(a, p, s);
+        case 5: return launch_fixed_wide<5, false>(a, p, s);
+        case 6: return launch_fixed_wide<6, false>(a, p, s);
+        default: return launch_fixed_wide<8, false>(a, p, s);
         }
     }
+    hipError_t pe = hipSuccess;
+    if (launch_packed(a, p, s, &pe))
+        return pe;
     // generic path
     const uint32_t qf4 = a.dtype == RLR_F16 ? 2 * a.pitch16 : a.pitch16;
     const size_t lds = kHistBins * sizeof(uint32_t) + static_cast<size_t>(qf4) * 16;

@@ -76,6 +76,25 @@ def test_search_topk_bit_exact(rlr, oracle, n, dim, k):
     ix.close()
 
 
+@pytest.mark.parametrize("dim,dtype", [(384, "f32"), (768, "f16"), (1536, "f32"), (1536, "f16"), (2048, "f32"), (2048, "f16"),
+                                       (1280, "f32"), (64, "f32"), (128, "f32"), (192, "f32"), (320, "f32"), (640, "f32"),
+                                       (896, "f32"), (1152, "f32"), (128, "f16"), (384, "f16"), (640, "f16"), (2304, "f16"),
+                                       (100, "f32"), (1792, "f32")])
+def test_scan_kernel_variants_bit_exact(rlr, oracle, dim, dtype):
+    """every row-pitch class of the scan: 1 KiB multiples (fixed kernel, CH 1..8), 256/512-byte rows (packed
+    kernel: several rows per wave-load group), anything else (generic); ragged row counts hit the tail packs"""
+    for n, k in ((4099, 20), (130, 130), (3, 2)):
+        rows = oracle.synth_rows(n, dim, seed=300 + dim + n, n_clusters=7, f16=(dtype == "f16"))
+        ix = make_index(rlr, rows, dtype=dtype)
+        for qi in range(2):
+            qn = oracle.normalize(oracle.synth_query(dim, seed=400 + dim + qi))
+            r, c = ix.search_topk(qn, k)
+            wr, wc = oracle_topk(oracle, rows, qn, k)
+            assert np.array_equal(r[0], wr), (dim, dtype, n)
+            assert np.array_equal(bits(c[0]), bits(wc)), (dim, dtype, n)
+        ix.close()
+
+
 def test_synthetic_fill_matches_oracle_generator(rlr, oracle):
     for dim, dtype, ncl in ((768, "f32", 0), (1024, "f16", 0), (96, "f32", 5)):
         ix = rlr.GpuIndex(dim, dtype)
