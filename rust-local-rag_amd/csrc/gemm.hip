@@ -466,6 +466,9 @@ __global__ __launch_bounds__(512) void gemm_image_kernel(const GemmArgs a, const
         RLR_COMPUTE((OFF) & 1, (OFF) & 1);                                                         \
         /* the slot just consumed takes chunk cc + 2: one full phase of lookahead for it */        \
         RLR_LOAD_A(RLR_ROT(min(cc + 2, last_c)), (OFF) & 1);                                       \
+        /* keep the LDS stores of the next query chunk down here: hoisted to the top of the phase  \
+           (hipcc does that) they wait for the loads issued a few instructions earlier */           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
         RLR_STORE_B(((OFF) & 1) ^ 1);                                                              \
         __syncthreads();                                                                           \
     } while (0)
