@@ -126,7 +126,8 @@ struct rlr_index {
     void *d_rows = nullptr;
     int n_cu = 256;
     int scan_variant = 0;
-    uint32_t batch_min = 16;  // smallest batch that takes the matrix-core path (RLR_BATCH_MIN)
+    uint32_t batch_min = 0;   // smallest batch that takes the matrix-core path; 0 = decide by the cost model,
+                              // RLR_BATCH_MIN=n forces a threshold (a huge n disables the path)
     bool image_enabled = false; // keep a binary16 nomination image of the rows for the batched GEMM
     void *d_image = nullptr;
     size_t image_cap = 0;       // bytes
@@ -639,8 +640,20 @@ constexpr uint32_t kBatchMaxQueries = 1024; // queries per batched pipeline run 
 
 bool batch_eligible(const rlr_index *ix, uint32_t nq, uint32_t k)
 {
-    return nq >= ix->batch_min && ix->batch_min > 0 && ix->dim % 128 == 0 && ix->n_rows >= 4096 &&
-           k * 8 <= batch_finish_capacity();
+    if (nq < 2 || ix->dim % 128 != 0 || ix->n_rows < 4096 || k * 8 > batch_finish_capacity())
+        return false;
+    if (ix->batch_min > 0)
+        return nq >= ix->batch_min;
+    // Cost model from the measured rates: a single-query pipeline streams the
+    // rows at ~6.5 TB/s plus ~60 us of fixed cost; a batch of up to 256 queries costs one GEMM pass
+    // (~3.7 TB/s over the row-major matrix, ~3 TB/s of binary16 over the nomination image) plus
+    // ~0.8 ms for the sample, the per-query selects and the finish kernels.
+    const double row_bytes = static_cast<double>(ix->n_rows) * ix->dim * (ix->dtype == RLR_F16 ? 2.0 : 4.0);
+    const double t_single = 60e-6 + row_bytes / 6.5e12;
+    const bool image = ix->image_enabled && ix->d_image;
+    const double pass = image ? static_cast<double>(ix->n_rows) * ix->dim * 2.0 / 3.0e12 : row_bytes / 3.7e12;
+    const double t_batch = 0.8e-3 + pass * ((nq + 255) / 256);
+    return nq * t_single > t_batch;
 }
 
 // Runs queries [q0, q0+nq) (already staged in c->d_query) through the GEMM nomination pipeline

@@ -412,6 +412,9 @@ def test_batched_mfma_sample_then_filter(rlr, oracle):
     ix.fill_synthetic(n, seed=112)
     prof = _check_batch(rlr, oracle, ix, rows, qs, 100)
     assert prof.n_batches == 1 and prof.n_batch_fallbacks == 0
+    # cost model: at 200 k rows four single scans are cheaper than one GEMM pass, eight are not
+    assert _check_batch(rlr, oracle, ix, rows, qs[:4], 100).n_batches == 0
+    assert _check_batch(rlr, oracle, ix, rows, qs[:8], 100).n_batches == 1
     ix.close()
 
 
