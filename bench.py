@@ -116,8 +116,25 @@ def cpu_baseline(args, rlr):
     }, rows, r1
 
 
+def ensure_built():
+    """librlr_gpu.so normally travels with the tree; if it does not, compile it once (hipcc is a child
+    process, nothing here touches the GPU) -- one rank builds, the others wait on the lock."""
+    so = os.path.join(ROOT, "rust-local-rag_amd", "librlr_gpu.so")
+    if os.path.exists(so):
+        return
+    import fcntl
+
+    with open(os.path.join(ROOT, "rust-local-rag_amd", ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not os.path.exists(so):
+            import __graft_entry__
+
+            __graft_entry__._load_build_module().build()
+
+
 def main():
     args = parse()
+    ensure_built()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
