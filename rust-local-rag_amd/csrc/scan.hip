@@ -356,14 +356,21 @@ struct ScanPlan {
 
 ScanPlan plan_scan(const ScanArgs &a)
 {
+    // Defaults from sweeps on MI355X (scratch/sweep_r8.sh, sweep_r8_dims.sh; GB/s at 24-30 GB corpora,
+    // old default R=4 x 8 workgroups/CU -> R=8 x 4 workgroups/CU): 768-d f32 6553 -> 6702 (6797 with
+    // 16-row groups), 512-d 6524 -> 6691, 1024-d 6541 -> 6837, 256-d 6437 -> 6496, f16 512/768/1024-d
+    // 6327/6526/6481 -> 6563/6628/6535; the gain holds from 300 k to 10 M rows.
     ScanPlan p;
     const int v = a.variant;
     const int r_code = v & 0xF;
-    p.r = r_code == 0 ? 4 : r_code;
+    // small corpora (fewer than ~3 sixteen-row groups per resident wave, < 200 k rows): more, lighter waves
+    // balance better -- 100 k rows: 55 us with R=4 x 8 workgroups/CU, 63 us with R=8 x 4
+    const bool small = (a.n_rows + 15) / 16 < static_cast<uint32_t>(a.n_cu) * 4 * 4 * 3;
+    p.r = r_code == 0 ? (small ? 4 : 8) : r_code;
     p.nt = ((v >> 4) & 1) == 0; // non-temporal row loads by default: +10 % on MI355X (6.8 vs 6.15 TB/s); bit 4 turns them off
     int blocks_per_cu = (v >> 8) & 0xFF;
     if (blocks_per_cu == 0)
-        blocks_per_cu = 8;
+        blocks_per_cu = small ? 8 : 4;
     uint32_t group = (v >> 16) & 0xFF;
     const uint32_t max_blocks = static_cast<uint32_t>(a.n_cu) * blocks_per_cu;
     if (group == 0) {
@@ -371,6 +378,8 @@ ScanPlan plan_scan(const ScanArgs &a)
         group = 64;
         while (group > 16 && (a.n_rows + group - 1) / group < max_blocks * 4 * 4)
             group >>= 1;
+        if (a.dtype == RLR_F32 && a.pitch16 == 192)
+            group = 16; // 3 KiB rows: 16-row groups measured +1.5-3 % at every corpus size
     }
     if (group > 64)
         group = 64;
