@@ -96,34 +96,16 @@ __device__ inline float chain_sum_lds(const float4 *__restrict__ p4, const float
     return s;
 }
 
+// Products of `cnt` candidate rows (row numbers in s_cand, LDS) with the query in s_q, staged in
+// s_p (cnt x p_pitch floats), then the reference-order sum of candidate `tid` (valid for tid < cnt).
+// Called by all 256 threads of the workgroup; contains one barrier.
 template <bool F16>
-__global__ __launch_bounds__(256) void rescore_staged_kernel(const float4 *__restrict__ rows, uint32_t pitch16,
-                                                             uint32_t dim, const float *__restrict__ query,
-                                                             const uint32_t *__restrict__ cand,
-                                                             const SelectState *__restrict__ st,
-                                                             uint64_t *__restrict__ packed_out, uint32_t cpb,
-                                                             uint32_t *__restrict__ hist_clear)
+__device__ __forceinline__ float staged_reference_dot(const float4 *__restrict__ rows, uint32_t pitch16, uint32_t dim,
+                                                      const float *s_q, float *s_p, const uint32_t *s_cand, uint32_t cnt,
+                                                      uint32_t tid)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_mem[];
-    const uint32_t q_floats = (dim + 7) & ~7u;      // query, zero padded to a 16-byte unit of the row dtype
-    const uint32_t p_pitch = q_floats + 4;          // product row pitch in floats (+16 B: bank spread)
-    float *s_q = s_mem;
-    float *s_p = s_mem + q_floats;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t gid = blockIdx.x * 256 + tid;
-    if (hist_clear && gid < 2 * kHistBins)
-        hist_clear[gid] = 0;
-    const uint32_t n = min(st->n_cand, st->cap);
-    const uint32_t base = blockIdx.x * cpb;
-    if (base >= n)
-        return;
-    const uint32_t cnt = min(cpb, n - base);
-    __shared__ uint32_t s_cand[16];
-    for (uint32_t i = tid; i < q_floats; i += 256)
-        s_q[i] = i < dim ? query[i] : 0.0f;
-    if (tid < cnt)
-        s_cand[tid] = cand[base + tid];
-    __syncthreads();
+    const uint32_t q_floats = (dim + 7) & ~7u;
+    const uint32_t p_pitch = q_floats + 4; // product row pitch in floats (+16 B: bank spread)
     // products: 16-byte units of the candidate rows, coalesced, kBatch independent loads in flight
     // per thread before the first is consumed; pad columns multiply to 0 and are never summed
     // (the chain stops at dim)
@@ -174,10 +156,79 @@ __global__ __launch_bounds__(256) void rescore_staged_kernel(const float4 *__res
         }
     }
     __syncthreads();
+    float sc = 0.0f;
     if (tid < cnt) {
         const float *pr = s_p + tid * p_pitch;
-        const float sc = chain_sum_lds(reinterpret_cast<const float4 *>(pr), pr, dim);
+        sc = chain_sum_lds(reinterpret_cast<const float4 *>(pr), pr, dim);
+    }
+    return sc;
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void rescore_staged_kernel(const float4 *__restrict__ rows, uint32_t pitch16,
+                                                             uint32_t dim, const float *__restrict__ query,
+                                                             const uint32_t *__restrict__ cand,
+                                                             const SelectState *__restrict__ st,
+                                                             uint64_t *__restrict__ packed_out, uint32_t cpb,
+                                                             uint32_t *__restrict__ hist_clear)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const uint32_t q_floats = (dim + 7) & ~7u;      // query, zero padded to a 16-byte unit of the row dtype
+    float *s_q = s_mem;
+    float *s_p = s_mem + q_floats;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gid = blockIdx.x * 256 + tid;
+    if (hist_clear && gid < 2 * kHistBins)
+        hist_clear[gid] = 0;
+    const uint32_t n = min(st->n_cand, st->cap);
+    const uint32_t base = blockIdx.x * cpb;
+    if (base >= n)
+        return;
+    const uint32_t cnt = min(cpb, n - base);
+    __shared__ uint32_t s_cand[16];
+    for (uint32_t i = tid; i < q_floats; i += 256)
+        s_q[i] = i < dim ? query[i] : 0.0f;
+    if (tid < cnt)
+        s_cand[tid] = cand[base + tid];
+    __syncthreads();
+    const float sc = staged_reference_dot<F16>(rows, pitch16, dim, s_q, s_p, s_cand, cnt, tid);
+    if (tid < cnt)
         packed_out[base + tid] = pack_result(sc, s_cand[tid]);
+}
+
+// The same re-score for the batched path: blockIdx.y = query, the workgroups of a query stride over
+// its guard band in groups of `cpb`; entries of band[q * band_stride ..] are packed (nominated score,
+// row) and are overwritten in place with (reference-order score, row).  st[q].pad = band length.
+template <bool F16>
+__global__ __launch_bounds__(256) void batch_rescore_kernel(const float4 *__restrict__ rows, uint32_t pitch16,
+                                                            uint32_t dim, const float *__restrict__ queries,
+                                                            uint32_t q_pitch, uint64_t *__restrict__ band,
+                                                            uint32_t band_stride, const SelectState *__restrict__ st,
+                                                            uint32_t cpb)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const uint32_t q_floats = (dim + 7) & ~7u;
+    float *s_q = s_mem;
+    float *s_p = s_mem + q_floats;
+    __shared__ uint32_t s_cand[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t q = blockIdx.y;
+    const uint32_t n = st[q].pad;
+    if (blockIdx.x * cpb >= n)
+        return;
+    const float *query = queries + static_cast<size_t>(q) * q_pitch;
+    for (uint32_t i = tid; i < q_floats; i += 256)
+        s_q[i] = i < dim ? query[i] : 0.0f;
+    uint64_t *b = band + static_cast<size_t>(q) * band_stride;
+    for (uint32_t base = blockIdx.x * cpb; base < n; base += gridDim.x * cpb) {
+        const uint32_t cnt = min(cpb, n - base);
+        __syncthreads(); // s_cand / s_p of the previous group are free (and s_q is staged)
+        if (tid < cnt)
+            s_cand[tid] = 0xFFFFFFFFu - static_cast<uint32_t>(b[base + tid] & 0xFFFFFFFFu);
+        __syncthreads();
+        const float sc = staged_reference_dot<F16>(rows, pitch16, dim, s_q, s_p, s_cand, cnt, tid);
+        if (tid < cnt)
+            b[base + tid] = pack_result(sc, s_cand[tid]);
     }
 }
 
@@ -774,6 +825,41 @@ bool launch_rescore_staged(const void *rows, uint32_t pitch16, uint32_t dim, int
     else
         hipLaunchKernelGGL(rescore_staged_kernel<false>, dim3(blocks), dim3(256), lds, s, r4, pitch16, dim, query, cand,
                            st, packed_out, cpb, hist_clear);
+    *err = hipGetLastError();
+    return true;
+}
+
+bool batch_rescore_fits(uint32_t pitch16, uint32_t dim, int dtype)
+{
+    const size_t q_bytes = static_cast<size_t>((dim + 7) & ~7u) * sizeof(float);
+    if (pitch16 * (dtype == RLR_F16 ? 8u : 4u) < ((dim + 7) & ~7u))
+        return false;
+    return 2 * q_bytes + 16 <= 60 * 1024; // the query + one candidate row of products
+}
+
+// batched staged re-score; false when the staged layout does not fit LDS for this row size
+bool launch_batch_rescore(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *queries,
+                          uint32_t q_pitch, uint32_t n_queries, uint64_t *band, uint32_t band_stride,
+                          const SelectState *st, hipStream_t s, hipError_t *err)
+{
+    const size_t q_bytes = static_cast<size_t>((dim + 7) & ~7u) * sizeof(float);
+    const size_t row_bytes = q_bytes + 16;
+    if (pitch16 * (dtype == RLR_F16 ? 8u : 4u) < ((dim + 7) & ~7u))
+        return false;
+    uint32_t cpb = 8;
+    while (cpb > 1 && q_bytes + cpb * row_bytes > 60 * 1024)
+        cpb >>= 1;
+    if (q_bytes + cpb * row_bytes > 60 * 1024)
+        return false;
+    const size_t lds = q_bytes + cpb * row_bytes;
+    const float4 *r4 = static_cast<const float4 *>(rows);
+    const dim3 grid(32, n_queries); // 32 groups of cpb candidates cover the usual band (~130 rows) in one sweep
+    if (dtype == RLR_F16)
+        hipLaunchKernelGGL(batch_rescore_kernel<true>, grid, dim3(256), lds, s, r4, pitch16, dim, queries, q_pitch, band,
+                           band_stride, st, cpb);
+    else
+        hipLaunchKernelGGL(batch_rescore_kernel<false>, grid, dim3(256), lds, s, r4, pitch16, dim, queries, q_pitch, band,
+                           band_stride, st, cpb);
     *err = hipGetLastError();
     return true;
 }

@@ -588,6 +588,80 @@ __global__ __launch_bounds__(256) void batch_finish_kernel(const float4 *__restr
         status[q] = 0u;
 }
 
+// The finish split in three so the re-score runs wide (exact.hip: batch_rescore_kernel) instead of one lane
+// per candidate inside the query's single workgroup (446 us -> see DESIGN.md):
+//   batch_band_kernel   order the nominated candidates, cut the guard band, leave it in cand[q][0..band)
+//   batch_rescore_kernel (exact.hip)  reference-order scores, in place
+//   batch_emit_kernel   order the band by the exact scores, emit k
+__global__ __launch_bounds__(1024) void batch_band_kernel(uint64_t *__restrict__ cand, uint32_t cand_stride,
+                                                          SelectState *__restrict__ st, uint32_t k, float two_eps,
+                                                          uint32_t *__restrict__ status)
+{
+    __shared__ uint64_t s_c[kFinCap];
+    __shared__ uint32_t s_band;
+    const uint32_t q = blockIdx.x;
+    const uint32_t n_raw = st[q].n_cand;
+    if (n_raw > st[q].cap || n_raw > kFinCap || n_raw < k) {
+        if (threadIdx.x == 0) {
+            status[q] = n_raw < k ? 2u : 1u;
+            st[q].pad = 0;
+        }
+        return;
+    }
+    uint32_t n_pad = 1;
+    while (n_pad < n_raw)
+        n_pad <<= 1;
+    uint64_t *c = cand + static_cast<size_t>(q) * cand_stride;
+    for (uint32_t i = threadIdx.x; i < n_pad; i += 1024)
+        s_c[i] = i < n_raw ? c[i] : 0ull;
+    if (threadIdx.x == 0)
+        s_band = 0;
+    __syncthreads();
+    bitonic_desc_lds(s_c, n_pad, 1024);
+    const float fk = key_score(static_cast<uint32_t>(s_c[k - 1] >> 32));
+    const uint32_t key_lo = score_key(fk - two_eps);
+    for (uint32_t i = threadIdx.x; i < n_raw; i += 1024)
+        if (static_cast<uint32_t>(s_c[i] >> 32) >= key_lo)
+            atomicMax(&s_band, i + 1);
+    __syncthreads();
+    const uint32_t band = s_band;
+    if (band > kBandCap) {
+        if (threadIdx.x == 0) {
+            status[q] = 1u;
+            st[q].pad = 0;
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < band; i += 1024)
+        c[i] = s_c[i];
+    if (threadIdx.x == 0) {
+        st[q].pad = band;
+        status[q] = 0u;
+    }
+}
+
+__global__ __launch_bounds__(1024) void batch_emit_kernel(const uint64_t *__restrict__ cand, uint32_t cand_stride,
+                                                          const SelectState *__restrict__ st, uint32_t k,
+                                                          uint64_t *__restrict__ out)
+{
+    __shared__ uint64_t s_c[kBandCap];
+    const uint32_t q = blockIdx.x;
+    const uint32_t band = st[q].pad;
+    if (band == 0)
+        return; // handed back to the single-query pipeline (status != 0)
+    uint32_t b_pad = 1;
+    while (b_pad < band)
+        b_pad <<= 1;
+    const uint64_t *c = cand + static_cast<size_t>(q) * cand_stride;
+    for (uint32_t i = threadIdx.x; i < b_pad; i += 1024)
+        s_c[i] = i < band ? c[i] : 0ull;
+    __syncthreads();
+    bitonic_desc_lds(s_c, b_pad, 1024);
+    uint64_t *o = out + static_cast<size_t>(q) * k;
+    for (uint32_t i = threadIdx.x; i < k; i += 1024)
+        o[i] = s_c[i];
+}
+
 } // namespace
 
 // upper bound of |nominated score - reference-order dot| for unit-norm operands
@@ -688,10 +762,27 @@ size_t image_bytes(uint32_t dim, uint64_t n_rows)
 }
 
 hipError_t launch_batch_finish(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *queries,
-                               uint32_t q_pitch, uint32_t n_queries, const uint64_t *cand, uint32_t cand_stride,
-                               const SelectState *st, uint32_t k, float two_eps, uint64_t *out, uint32_t *status,
+                               uint32_t q_pitch, uint32_t n_queries, uint64_t *cand, uint32_t cand_stride,
+                               SelectState *st, uint32_t k, float two_eps, uint64_t *out, uint32_t *status,
                                hipStream_t s)
 {
+    static const bool fused = [] {
+        const char *v = getenv("RLR_BATCH_FINISH_FUSED"); // A/B switch: the one-kernel finish
+        return v && v[0] == '1';
+    }();
+    if (!fused && batch_rescore_fits(pitch16, dim, dtype)) {
+        hipLaunchKernelGGL(batch_band_kernel, dim3(n_queries), dim3(1024), 0, s, cand, cand_stride, st, k, two_eps, status);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+        if (!launch_batch_rescore(rows, pitch16, dim, dtype, queries, q_pitch, n_queries, cand, cand_stride, st, s, &e))
+            return hipErrorInvalidValue; // cannot happen: batch_rescore_fits said yes
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL(batch_emit_kernel, dim3(n_queries), dim3(1024), 0, s, cand, cand_stride, st, k, out);
+        return hipGetLastError();
+    }
+    // rows too large for the staged layout (or RLR_BATCH_FINISH_FUSED=1): the one-kernel finish
     const size_t lds = static_cast<size_t>(dim) * sizeof(float);
     const float4 *r4 = static_cast<const float4 *>(rows);
     if (dtype == RLR_F16)

@@ -66,10 +66,17 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
 size_t image_bytes(uint32_t dim, uint64_t n_rows);
 hipError_t launch_build_image(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t n_rows,
                               uint32_t tile_begin, uint32_t tile_end, void *image, hipStream_t s);
+// batched finish = band cut (sort the nominated candidates, keep the guard band) -> staged reference-order
+// re-score of every band (exact.hip) -> final order + emit.  `cand` is overwritten; st[q].pad receives the
+// band length.
 hipError_t launch_batch_finish(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *queries,
-                               uint32_t q_pitch, uint32_t n_queries, const uint64_t *cand, uint32_t cand_stride,
-                               const SelectState *st, uint32_t k, float two_eps, uint64_t *out, uint32_t *status,
+                               uint32_t q_pitch, uint32_t n_queries, uint64_t *cand, uint32_t cand_stride,
+                               SelectState *st, uint32_t k, float two_eps, uint64_t *out, uint32_t *status,
                                hipStream_t s);
+bool batch_rescore_fits(uint32_t pitch16, uint32_t dim, int dtype);
+bool launch_batch_rescore(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *queries,
+                          uint32_t q_pitch, uint32_t n_queries, uint64_t *band, uint32_t band_stride,
+                          const SelectState *st, hipStream_t s, hipError_t *err);
 
 // ---- exact.hip : reference-order arithmetic --------------------------------
 // packed_out[i] = pack(dot_ref(query, row[cand[i]]), cand[i]) for i < min(n_cand, cap);
