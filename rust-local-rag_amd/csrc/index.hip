@@ -844,14 +844,19 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
         return RLR_OK;
     }
 
+    // Host-bound results: the last kernel of each pipeline writes its k packed results and the candidate
+    // count straight into the pinned (device-mapped) host buffer -- no D2H copy operation on the stream.
+    const bool host_direct = !d_out_user;
+    uint64_t *q_out = host_direct ? h_res : d_out;
+    uint64_t *q_meta = host_direct ? h_meta : d_meta;
     if (!timed || nq == 1) {
         // (with profiling on, a single query's four events are read after the one final sync)
         for (uint32_t q = 0; q < nq; ++q)
-            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, d_meta + q, timed));
+            RLR_HIP(enqueue_query(ix, c, q, p, q_out + static_cast<size_t>(q) * p.k, q_meta + q, timed));
     } else {
         // one query at a time so the four events can be read back per query
         for (uint32_t q = 0; q < nq; ++q) {
-            RLR_HIP(enqueue_query(ix, c, q, p, d_out + static_cast<size_t>(q) * p.k, d_meta + q, true));
+            RLR_HIP(enqueue_query(ix, c, q, p, q_out + static_cast<size_t>(q) * p.k, q_meta + q, true));
             RLR_HIP(hipStreamSynchronize(s));
             float a = 0, b = 0, d = 0;
             RLR_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
@@ -863,9 +868,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
             total_ms += a + b + d;
         }
     }
-    if (!d_out_user) // results and counts are contiguous in the context buffer: one copy
-        RLR_HIP(hipMemcpyAsync(h_res, c->d_out, res_bytes, hipMemcpyDeviceToHost, s));
-    else
+    if (!host_direct)
         RLR_HIP(hipMemcpyAsync(h_meta, d_meta, nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     RLR_HIP(hipStreamSynchronize(s));
     if (timed && nq == 1) {
@@ -885,9 +888,8 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
         n_cand_total += nc;
         if (nc > p.cap || nc > kLdsSortCap) {
             n_retry++;
-            RLR_TRY(big_query(ix, c, q, p, nc, /*rescan=*/nq > 1, d_out + static_cast<size_t>(q) * p.k));
-            RLR_TRY(fetch_results(static_cast<size_t>(q) * p.k, p.k));
-            refetch = true;
+            RLR_TRY(big_query(ix, c, q, p, nc, /*rescan=*/nq > 1, q_out + static_cast<size_t>(q) * p.k));
+            refetch = !host_direct;
         }
     }
     if (refetch)
@@ -1230,10 +1232,11 @@ int32_t rlr_search_topk_device(rlr_index *ix, const float *queries, uint32_t n_q
         RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, static_cast<uint64_t *>(d_packed_out), &p, nullptr));
     } else {
         // fewer rows than k: produce the n_rows results, then spread them into k-strided slots
-        RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, nullptr, &p, nullptr));
+        const uint64_t *h_res = nullptr;
+        RLR_TRY(run_search(ix, c, queries, n_queries, k, guard_eps, nullptr, &p, &h_res));
         RLR_HIP(hipMemsetAsync(d_packed_out, 0, static_cast<size_t>(n_queries) * k * sizeof(uint64_t), c->stream));
-        RLR_HIP(hipMemcpy2DAsync(d_packed_out, static_cast<size_t>(k) * 8, c->d_out, static_cast<size_t>(p.k) * 8,
-                                 static_cast<size_t>(p.k) * 8, n_queries, hipMemcpyDeviceToDevice, c->stream));
+        RLR_HIP(hipMemcpy2DAsync(d_packed_out, static_cast<size_t>(k) * 8, h_res, static_cast<size_t>(p.k) * 8,
+                                 static_cast<size_t>(p.k) * 8, n_queries, hipMemcpyHostToDevice, c->stream));
         RLR_HIP(hipStreamSynchronize(c->stream));
     }
     // run_search has synchronised the context stream, so the results are complete; a later
