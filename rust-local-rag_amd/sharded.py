@@ -266,3 +266,55 @@ def sharded_mmr(pool_rows, pool_scores, pool_sizes, k: int, lam: float, *, rank:
         mmr_out[qs, :P] = np.ascontiguousarray(blk[:, P:2 * P]).view(np.float32)
         n_out[qs] = blk[:, 2 * P].astype(np.uint32)
     return order_out, mmr_out, n_out
+
+
+class ReplicatedIndex:
+    """Replicas-only mode (last bullet): the corpus fits one GPU, every rank holds a
+    full copy and the QUERIES are sharded -- rank r answers queries r, r + world, ... -- so a batch of
+    queries costs no data-path collective for the search itself; one all-gather returns everybody's
+    results to every rank (skip it with `gather=False` when each rank only needs its own answers)."""
+
+    def __init__(self, dim: int, dtype: str = "f32", device: int = 0, group=None, rank: Optional[int] = None,
+                 world: Optional[int] = None, index: Optional[GpuIndex] = None, tensor_device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.group = group
+        self.rank = rank if rank is not None else (self.dist.get_rank(group) if self.dist else 0)
+        self.world = world if world is not None else (self.dist.get_world_size(group) if self.dist else 1)
+        self.index = index if index is not None else GpuIndex(dim, dtype, device)
+        self.dim = dim
+        self.torch = torch
+        # tensors handed to the collective: the GPU for RCCL; the gloo test passes "cpu"
+        self.dev = torch.device(tensor_device) if tensor_device is not None else torch.device("cuda", device)
+
+    def my_queries(self, nq: int) -> np.ndarray:
+        return np.arange(self.rank, nq, self.world)
+
+    def search_topk(self, queries, k: int, gather: bool = True):
+        """-> (rows int64 [Q, k'], cos f32 [Q, k']); with gather=False only this rank's queries
+        (`my_queries(Q)`) are filled in, the others are -1 / NaN."""
+        q = _f32(queries).reshape(-1, self.dim)
+        nq = q.shape[0]
+        kk = min(k, len(self.index))
+        rows = np.full((nq, kk), -1, dtype=np.int64)
+        cos = np.full((nq, kk), np.nan, dtype=np.float32)
+        mine = self.my_queries(nq)
+        if mine.size and kk:
+            r, c = self.index.search_topk(q[mine], k)
+            rows[mine], cos[mine] = r.astype(np.int64), c
+        if gather and self.world > 1 and self.dist is not None and kk:
+            torch = self.torch
+            per = (nq + self.world - 1) // self.world
+            buf = np.zeros((per, 2 * kk), dtype=np.int64)
+            buf[: mine.size, :kk] = rows[mine]
+            buf[: mine.size, kk:] = cos[mine].view(np.uint32).astype(np.int64)
+            out = torch.empty((self.world * per, 2 * kk), dtype=torch.int64, device=self.dev)
+            self.dist.all_gather_into_tensor(out, torch.from_numpy(buf).to(self.dev), group=self.group)
+            allr = out.cpu().numpy().reshape(self.world, per, 2 * kk)
+            for r in range(self.world):
+                qs = np.arange(r, nq, self.world)
+                rows[qs] = allr[r, : qs.size, :kk]
+                cos[qs] = allr[r, : qs.size, kk:].astype(np.uint32).view(np.float32)
+        return rows, cos

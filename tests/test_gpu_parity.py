@@ -359,6 +359,28 @@ def test_sharded_diversity_world1_winner_exchange_path(rlr, oracle):
         sh.index.close()
 
 
+def test_replicated_index_world1_and_query_sharding(rlr, oracle):
+    """replicas-only mode: every rank holds the corpus, queries are dealt round-robin"""
+    import importlib
+    import torch  # noqa: F401
+    sharded = importlib.import_module("rust-local-rag_amd.sharded")
+    n, dim, k = 3000, 768, 15
+    rows = oracle.synth_rows(n, dim, seed=707)
+    qs = np.stack([oracle.normalize(oracle.synth_query(dim, seed=710 + i)) for i in range(5)])
+    rep = sharded.ReplicatedIndex(dim, "f32", device=0, rank=0, world=1)
+    rep.index.upload(rows)
+    r, c = rep.search_topk(qs, k)
+    for i in range(5):
+        wr, wc = oracle_topk(oracle, rows, qs[i], k)
+        assert np.array_equal(r[i].astype(np.uint64), wr) and np.array_equal(bits(c[i]), bits(wc))
+    # rank 1 of 2 (no process group: gather is skipped) answers only its own queries
+    rep1 = sharded.ReplicatedIndex(dim, "f32", device=0, rank=1, world=2, index=rep.index)
+    assert rep1.my_queries(5).tolist() == [1, 3]
+    r1, c1 = rep1.search_topk(qs, k, gather=False)
+    assert np.array_equal(r1[[1, 3]], r[[1, 3]]) and (r1[[0, 2, 4]] == -1).all() and np.isnan(c1[0]).all()
+    rep.index.close()
+
+
 def test_mmr_select_values_entry_equals_index_pools(rlr, oracle):
     import torch
     rows = oracle.synth_rows(3000, 768, seed=93, n_clusters=9)

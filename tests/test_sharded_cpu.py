@@ -206,3 +206,63 @@ def test_winner_exchange_plan_is_consistent_across_ranks():
         rebuilt = np.array(recv)[perm].reshape(len(my_q), P)
         for j, q in enumerate(my_q):
             assert np.array_equal(rebuilt[j, : sizes[q]], pools[q, : sizes[q]])
+
+
+# ---- replicas-only mode: queries dealt round-robin, results all-gathered ---------------------------
+class _OracleIndex:
+    """stands in for GpuIndex on the CPU: exact top-k by the oracle"""
+
+    def __init__(self, rows, O):
+        self.rows, self.O = rows, O
+
+    def __len__(self):
+        return len(self.rows)
+
+    def search_topk(self, qs, k):
+        out_r, out_c = [], []
+        for q in np.asarray(qs, dtype=np.float32).reshape(-1, self.rows.shape[1]):
+            e = self.O.scan(self.rows, q)
+            order = np.lexsort((np.arange(len(e)), -e.astype(np.float64)))[:k]
+            out_r.append(order.astype(np.uint64)); out_c.append(e[order])
+        return np.stack(out_r), np.stack(out_c)
+
+
+def _replica_worker(rank, world, port, n, dim, k, seed, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sharded = importlib.import_module("rust-local-rag_amd.sharded")
+        from oracle import oracle as O
+
+        rows = O.synth_rows(n, dim, seed)
+        qs = np.stack([O.normalize(O.synth_query(dim, seed + 1 + i)) for i in range(5)])
+        rep = sharded.ReplicatedIndex(dim, index=_OracleIndex(rows, O), tensor_device="cpu")
+        r, c = rep.search_topk(qs, k)
+        ret[rank] = (r.copy(), c.copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_replicated_queries(oracle):
+    import torch.multiprocessing as mp
+
+    n, dim, k, seed, world = 500, 48, 7, 123, 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_replica_worker, args=(r, world, port, n, dim, k, seed, ret)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    rows = oracle.synth_rows(n, dim, seed)
+    want = _OracleIndex(rows, oracle).search_topk(
+        np.stack([oracle.normalize(oracle.synth_query(dim, seed + 1 + i)) for i in range(5)]), k)
+    for rank in range(world):
+        r, c = ret[rank]
+        assert np.array_equal(r.astype(np.uint64), want[0])
+        assert np.array_equal(c.view(np.uint32), want[1].view(np.uint32))
