@@ -103,3 +103,9 @@ def test_search_result_json_skips_none_fields(rlr):
     assert set(r.to_json()) == {"text", "score", "document", "chunk_id", "chunk_index", "page_number", "section"}
     r.embedding_score = 0.4
     assert "embedding_score" in r.to_json()
+
+
+def test_integration_doc_shows_a_binding_for_every_symbol():
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in sorted(_declared_symbols()) if n not in doc]
+    assert not missing, f"INTEGRATION.md shows no reference-side binding for {missing}"
