@@ -310,6 +310,7 @@ struct rlr_lexical {
     std::vector<uint32_t> doc_len;                                     // row -> token count
     uint64_t total_docs = 0, total_length = 0, n_postings = 0, n_live_terms = 0;
     bool dirty = true;
+    bool workspace_dirty = false; // a score call failed after enqueuing work: accumulators / control may be non-zero
     // ---- device CSR
     std::vector<uint64_t> term_off;
     uint32_t *d_post_row = nullptr, *d_post_tf = nullptr, *d_doc_len = nullptr;
@@ -589,6 +590,13 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     LEX_HIP(hipSetDevice(lx->device));
     if (lx->dirty)
         LEX_TRY(commit(lx));
+    if (lx->workspace_dirty) { // restore the all-zero invariant a failed call may have broken
+        LEX_HIP(hipStreamSynchronize(lx->stream));
+        if (lx->d_scores)
+            LEX_HIP(hipMemset(lx->d_scores, 0, lx->scores_cap * sizeof(float)));
+        LEX_HIP(hipMemset(lx->d_ctl, 0, sizeof(LexControl)));
+        lx->workspace_dirty = false;
+    }
 
     // unique query terms in order of first occurrence (:2179-2182 uses a HashSet: order unspecified there)
     std::vector<uint32_t> terms;
@@ -610,6 +618,7 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     const float n_docs = static_cast<float>(lx->total_docs);
     const float avg = static_cast<float>(lx->total_length) / n_docs; // :2184-2188
     hipStream_t s = lx->stream;
+    lx->workspace_dirty = true; // cleared below once the whole pipeline has run
     const uint32_t max_blocks = static_cast<uint32_t>(lx->n_cu) * 8;
     for (uint32_t t : terms) {
         const float df = static_cast<float>(lx->df[t]);
@@ -645,6 +654,7 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     LEX_HIP(hipMemcpyAsync(lx->h_out + kMaxLimit, lx->d_out + kMaxLimit, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     LEX_HIP(hipMemcpyAsync(lx->h_out, lx->d_out, static_cast<size_t>(lim) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     LEX_HIP(hipStreamSynchronize(s));
+    lx->workspace_dirty = false;
     const uint32_t n = std::min<uint32_t>(*reinterpret_cast<const uint32_t *>(lx->h_out + kMaxLimit), lim);
     for (uint32_t i = 0; i < n; ++i) {
         float sc;
