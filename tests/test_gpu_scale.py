@@ -1,7 +1,8 @@
-"""Size-independent properties at a corpus far beyond what the oracle can scan in seconds
-(3 M x 768 f32 = 9.2 GB, generated on the device): sortedness, self-consistency of the emitted
-scores with the reference-order re-score, top-k-ness against a random sample, idempotence,
-single == batched == sharded, and a delete round trip."""
+"""Size-independent properties at BASELINE.json's full per-GPU sizes, far beyond what the oracle can scan
+in seconds (corpora generated on the device): config 3 = 10 M x 768 f32 (30.7 GB) with 256 batched queries,
+config 5's per-GPU share = 6.25 M x 1024 binary16 with 1024 batched queries and MMR 0.7.  Checked:
+sortedness, self-consistency of the emitted scores with the reference-order re-score, top-k-ness against a
+random sample, idempotence, single == batched == sharded, MMR batch == MMR single, a delete round trip."""
 import numpy as np
 import pytest
 
@@ -9,7 +10,7 @@ from conftest import bits
 
 pytestmark = pytest.mark.gpu
 
-N, DIM, K, SEED = 3_000_000, 768, 100, 0x5EED0003
+N, DIM, K, SEED = 10_000_000, 768, 100, 0x5EED0003
 
 
 @pytest.fixture(scope="module")
@@ -48,12 +49,12 @@ def test_sorted_exact_and_topk_against_sample(rlr, big):
 
 
 def test_batched_equals_single_at_scale(rlr, big):
-    qs = _queries(rlr, 32, seed=6)
+    qs = _queries(rlr, 256, seed=6)                                      # BASELINE config 3: 256 batched queries
     big.profile_read(reset=True)
     rb, cb = big.search_topk(qs, K)
     prof = big.profile_read()
     assert prof.n_batches == 1 and prof.n_batch_fallbacks == 0
-    for i in range(0, 32, 5):
+    for i in range(0, 256, 37):
         r1, c1 = big.search_topk(qs[i], K)
         assert np.array_equal(r1[0], rb[i]) and np.array_equal(bits(c1[0]), bits(cb[i]))
     big.enable_batch_image(True)                                         # and through the nomination image
@@ -71,6 +72,31 @@ def test_sharded_equals_single_at_scale(rlr, big):
         rm, cm = mi.search_topk(q, K)
         assert np.array_equal(r1, rm) and np.array_equal(bits(c1), bits(cm))
     mi.close()
+
+
+def test_config5_shard_batched_search_and_mmr(rlr):
+    """6.25 M x 1024 binary16 rows (50 M / 8 GPUs), 1024 batched queries, pool 300, MMR lambda 0.7"""
+    n, dim, nq, k, lam = 6_250_000, 1024, 1024, 100, 0.7
+    ix = rlr.GpuIndex(dim, "f16")
+    ix.fill_synthetic(n, seed=0x5EED0005, n_clusters=4096)
+    rng = np.random.default_rng(9)
+    qs = np.stack([rlr.normalize(rng.standard_normal(dim).astype(np.float32)) for _ in range(nq)])
+    pool = max(3 * k, k + 10)
+    r, c = ix.search_topk(qs, pool)
+    assert r.shape == (nq, pool)
+    for i in (0, 511, 1023):                                             # batched == single, scores == reference order
+        r1, c1 = ix.search_topk(qs[i], pool)
+        assert np.array_equal(r1[0], r[i]) and np.array_equal(bits(c1[0]), bits(c[i]))
+        assert np.array_equal(bits(c[i]), bits(ix.score_rows(qs[i], r[i])))
+        assert (np.diff(c[i]) <= 0).all()
+    scores = (np.float32(0.7) * c).astype(np.float32)
+    order, mmr, cnt = ix.mmr_select_batch(r, scores, np.full(nq, pool, np.uint32), k, lam)
+    assert (cnt == k).all()
+    for i in (0, 300, 1023):                                             # batched MMR == single MMR
+        o1, m1 = ix.mmr_select(r[i], scores[i], k, lam)
+        assert np.array_equal(o1, order[i, :k]) and np.array_equal(bits(m1[1:]), bits(mmr[i, 1:k]))
+        assert order[i, 0] == 0 and len(set(order[i, :k].tolist())) == k  # first pick = best score, no repeats
+    ix.close()
 
 
 def test_delete_round_trip(rlr):
