@@ -640,6 +640,41 @@ __global__ __launch_bounds__(1024) void batch_band_kernel(uint64_t *__restrict__
     }
 }
 
+__global__ __launch_bounds__(1024) void batch_tighten_kernel(uint64_t *__restrict__ cand, uint32_t cand_stride,
+                                                             SelectState *__restrict__ st, uint32_t k, float two_eps,
+                                                             float *__restrict__ tau)
+{
+    __shared__ uint64_t s_c[kFinCap];
+    __shared__ uint32_t s_keep;
+    const uint32_t q = blockIdx.x;
+    const uint32_t n_raw = st[q].n_cand;
+    if (n_raw > st[q].cap || n_raw > kFinCap || n_raw < k)
+        return; // the old threshold stays; the finish flags the query if the list ends up unusable
+    uint32_t n_pad = 1;
+    while (n_pad < n_raw)
+        n_pad <<= 1;
+    uint64_t *c = cand + static_cast<size_t>(q) * cand_stride;
+    for (uint32_t i = threadIdx.x; i < n_pad; i += 1024)
+        s_c[i] = i < n_raw ? c[i] : 0ull;
+    if (threadIdx.x == 0)
+        s_keep = 0;
+    __syncthreads();
+    bitonic_desc_lds(s_c, n_pad, 1024);
+    const float fk = key_score(static_cast<uint32_t>(s_c[k - 1] >> 32));
+    const uint32_t key_lo = score_key(fk - two_eps);
+    for (uint32_t i = threadIdx.x; i < n_raw; i += 1024)
+        if (static_cast<uint32_t>(s_c[i] >> 32) >= key_lo)
+            atomicMax(&s_keep, i + 1);
+    __syncthreads();
+    const uint32_t keep = s_keep;
+    for (uint32_t i = threadIdx.x; i < keep; i += 1024)
+        c[i] = s_c[i];
+    if (threadIdx.x == 0) {
+        st[q].n_cand = keep;
+        tau[q] = key_lo == 0 ? -__builtin_inff() : key_score(key_lo);
+    }
+}
+
 __global__ __launch_bounds__(1024) void batch_emit_kernel(const uint64_t *__restrict__ cand, uint32_t cand_stride,
                                                           const SelectState *__restrict__ st, uint32_t k,
                                                           uint64_t *__restrict__ out)
@@ -791,6 +826,13 @@ hipError_t launch_batch_finish(const void *rows, uint32_t pitch16, uint32_t dim,
     else
         hipLaunchKernelGGL(batch_finish_kernel<false>, dim3(n_queries), dim3(256), lds, s, r4, pitch16, dim, queries,
                            q_pitch, cand, cand_stride, st, k, two_eps, out, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_tighten(uint64_t *cand, uint32_t cand_stride, SelectState *st, uint32_t n_queries, uint32_t k,
+                                float two_eps, float *tau, hipStream_t s)
+{
+    hipLaunchKernelGGL(batch_tighten_kernel, dim3(n_queries), dim3(1024), 0, s, cand, cand_stride, st, k, two_eps, tau);
     return hipGetLastError();
 }
 

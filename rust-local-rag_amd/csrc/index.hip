@@ -675,6 +675,16 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     S = (S + 255) / 256 * 256;
     if (S * 2 >= n)
         S = n;
+    // Bootstrap: materialising and radix-selecting S rows per query costs 4 passes over nq x S floats
+    // (2.4 GB for 1024 queries x 587 k rows).  When S is large, only a quarter of it (S1) goes that way;
+    // its threshold filters the rows [S1, S) in the GEMM epilogue (about 3 k extra candidates), one sort
+    // per query tightens the threshold to the k-th score of all S rows, and the main pass starts from the
+    // same threshold the full-size sample would have given.
+    const uint64_t S2 = S;
+    uint64_t S1 = std::max<uint64_t>(65536, (S2 / 4 + 255) / 256 * 256);
+    const bool bootstrap = S2 < n && S1 * 2 <= S2 && !getenv("RLR_BATCH_NO_BOOTSTRAP");
+    if (bootstrap)
+        S = S1;
     const uint64_t s_stride = (S + 3) / 4 * 4;
 
     // workspace
@@ -729,8 +739,17 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     RLR_HIP(launch_batch_select(c->d_sample, static_cast<uint32_t>(S), s_stride, nq, c->d_bhist, c->d_bstate, two_eps,
                                 c->d_tau, c->d_bcand, fin_cap, ix->n_cu, s));
     if (timed) RLR_HIP(hipEventRecord(c->bev[2], s));
+    uint32_t rest_begin = static_cast<uint32_t>(S);
+    if (bootstrap) {
+        // 2b. rows [S1, S2) against the small sample's threshold, then tighten it
+        RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, static_cast<uint32_t>(S1),
+                                     static_cast<uint32_t>(S2), c->d_qfrag, nq, c->d_tau, c->d_bcand, fin_cap, c->d_bstate,
+                                     nullptr, 0, image, s));
+        RLR_HIP(launch_batch_tighten(c->d_bcand, fin_cap, c->d_bstate, nq, p.k, two_eps, c->d_tau, s));
+        rest_begin = static_cast<uint32_t>(S2);
+    }
     // 3. the rest of the corpus, filtered in the GEMM epilogue
-    RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, static_cast<uint32_t>(S), n, c->d_qfrag, nq,
+    RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, rest_begin, n, c->d_qfrag, nq,
                                  c->d_tau, c->d_bcand, fin_cap, c->d_bstate, nullptr, 0, image, s));
     if (timed) RLR_HIP(hipEventRecord(c->bev[3], s));
     // 4. per-query finish: band, reference-order re-score, order, emit

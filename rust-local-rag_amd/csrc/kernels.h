@@ -73,6 +73,10 @@ hipError_t launch_batch_finish(const void *rows, uint32_t pitch16, uint32_t dim,
                                uint32_t q_pitch, uint32_t n_queries, uint64_t *cand, uint32_t cand_stride,
                                SelectState *st, uint32_t k, float two_eps, uint64_t *out, uint32_t *status,
                                hipStream_t s);
+// per query: order the candidates collected so far, move the threshold up to (k-th nominated score - band),
+// drop what falls below it (st[q].n_cand, tau[q] updated); queries with a short or overflowed list are left alone
+hipError_t launch_batch_tighten(uint64_t *cand, uint32_t cand_stride, SelectState *st, uint32_t n_queries, uint32_t k,
+                                float two_eps, float *tau, hipStream_t s);
 bool batch_rescore_fits(uint32_t pitch16, uint32_t dim, int dtype);
 bool launch_batch_rescore(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *queries,
                           uint32_t q_pitch, uint32_t n_queries, uint64_t *band, uint32_t band_stride,

@@ -4,7 +4,7 @@ import importlib, sys, time, json
 import numpy as np
 sys.path.insert(0, '.')
 rlr = importlib.import_module("rust-local-rag_amd")
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 6_250_000
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 6_250_000
 dim, nq, k, lam = 1024, 1024, 100, 0.7
 eng = rlr.RagEngine(dim, "f16")
 t0 = time.perf_counter(); eng.index.fill_synthetic(n, seed=0x5EED0005, n_clusters=500); fill = time.perf_counter() - t0
@@ -13,6 +13,8 @@ rng = np.random.default_rng(5)
 qs = rng.standard_normal((nq, dim)).astype(np.float32)
 qn = np.stack([rlr.normalize(q) for q in qs])
 ix = eng.index
+if "--image" in sys.argv:
+    ix.enable_batch_image(True)
 # raw batched top-308 search
 ix.search_topk(qn[:64], 308)
 ix.profile_read(reset=True); ix.profile_enable(True)
