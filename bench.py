@@ -140,6 +140,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher (nothing has touched the GPU yet);
+        # one rank per GPU over RCCL, as the driver's own `torch.distributed.run` command line does
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.exit(subprocess.call(cmd))
 
     import torch
 
