@@ -867,7 +867,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     // count straight into the pinned (device-mapped) host buffer -- no D2H copy operation on the stream.
     const bool host_direct = !d_out_user;
     uint64_t *q_out = host_direct ? h_res : d_out;
-    uint64_t *q_meta = host_direct ? h_meta : d_meta;
+    uint64_t *q_meta = h_meta; // the candidate count always goes straight to the host (the overflow check needs it)
     if (!timed || nq == 1) {
         // (with profiling on, a single query's four events are read after the one final sync)
         for (uint32_t q = 0; q < nq; ++q)
@@ -887,8 +887,6 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
             total_ms += a + b + d;
         }
     }
-    if (!host_direct)
-        RLR_HIP(hipMemcpyAsync(h_meta, d_meta, nq * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     RLR_HIP(hipStreamSynchronize(s));
     if (timed && nq == 1) {
         float a = 0, b = 0, d = 0;
