@@ -178,11 +178,22 @@ int32_t rlr_fetch_rows_device(rlr_index *idx, const uint64_t *rows, uint32_t n, 
 int32_t rlr_mmr_select_values(rlr_index *idx, const void *d_values, const float *pool_scores,
                               const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k,
                               float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out);
+/* The same search split in two so the caller's collective can be queued behind the scan without a host
+ * round trip (the sharded step: begin -> all-gather -> rlr_merge_topk -> end).  begin() enqueues the
+ * pipelines on the caller's `stream` itself, so whatever is queued there next is ordered behind them;
+ * `*ticket_out` keeps the search context until end().  end() joins and reports in *n_overflow_out how many queries overflowed their guard
+ * band (massive exact ties): their slots of d_packed_out start with the all-ones word instead of results --
+ * rlr_merge_topk reports such a query with n_out[q] = 0xFFFFFFFF on every rank -- and the caller re-runs the
+ * step with rlr_search_topk_device.  Batched / profiled / k > rows calls run synchronously inside begin() and hand
+ * back a NULL ticket (end() is then a no-op). */
+int32_t rlr_search_topk_device_begin(rlr_index *idx, const float *queries, uint32_t n_queries, uint32_t k,
+                                     float guard_eps, void *d_packed_out, void *stream, void **ticket_out);
+int32_t rlr_search_topk_device_end(rlr_index *idx, void *ticket, uint32_t *n_overflow_out);
 /* The exchange step's merge: `d_gathered` is the all-gathered buffer, world x n_queries x k packed
  * u64 (rank-major), on device `device_id`; bases[r] = first global row of rank r's shard
  * (ascending).  Emits per query the global top-k as (global row, score) to host buffers, ordered
  * (score desc, global row asc); n_out[q] = number of valid results (<= k; unused slots get row
- * ~0 and NaN).  world <= 16, world * k <= 8192.  Runs on `stream` (hipStream_t or NULL) and
+ * ~0 and NaN), or 0xFFFFFFFF when a shard marked the query invalid (rlr_search_topk_device_begin).  world <= 16, world * k <= 8192.  Runs on `stream` (hipStream_t or NULL) and
  * returns after it has finished. */
 int32_t rlr_merge_topk(int32_t device_id, const void *d_gathered, uint32_t world, uint32_t n_queries,
                        uint32_t k, const uint64_t *bases, uint64_t *rows_out, float *cos_out,

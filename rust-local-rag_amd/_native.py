@@ -76,6 +76,9 @@ PROTOTYPES = [
     ("rlr_index_enable_batch_image", C.c_int32, [_H, C.c_int32]),
     ("rlr_search_topk", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, u64p, f32p, u32p]),
     ("rlr_search_topk_device", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]),
+    ("rlr_search_topk_device_begin", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p,
+                                                 C.POINTER(C.c_void_p)]),
+    ("rlr_search_topk_device_end", C.c_int32, [_H, C.c_void_p, u32p]),
     ("rlr_merge_topk", C.c_int32, [C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, u64p, f32p, u32p,
                                    C.c_void_p]),
     ("rlr_pack_result", C.c_uint64, [C.c_float, C.c_uint32]),

@@ -111,6 +111,11 @@ struct Ctx {
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
     bool hist_dirty = false; // a pipeline was enqueued and did not complete: d_hist may hold counts
+    // rlr_search_topk_device_begin / _end
+    hipStream_t pending_stream = nullptr;
+    uint32_t pending_q = 0, pending_k = 0;
+    bool pending_timed = false;
+    const uint64_t *pending_meta = nullptr;
 };
 
 } // namespace
@@ -396,8 +401,13 @@ __global__ __launch_bounds__(1024) void sort_emit_kernel(uint64_t *__restrict__ 
     const uint32_t n_raw = st->n_cand;
     if (threadIdx.x == 0 && meta)
         *meta = n_raw; // travels to the host with the results: one D2H per call
-    if (n_raw > st->cap || n_raw > 4096)
-        return; // band overflow: the host re-runs this query on the large-candidate path
+    if (n_raw > st->cap || n_raw > 4096) {
+        // band overflow: the host re-runs this query on the large-candidate path.  The all-ones word marks
+        // the slot invalid for consumers that read it before the host has looked (the sharded merge).
+        if (threadIdx.x == 0)
+            out[0] = ~0ull;
+        return;
+    }
     if (n_raw <= 1024) {
         // rank sort: keys are unique (the row number is part of the key), so the number of larger
         // keys is the output position -- one pass, two barriers, instead of a log^2 network.
@@ -456,13 +466,16 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
 {
     __shared__ uint64_t s[8192];
     __shared__ uint32_t s_valid;
+    __shared__ uint32_t s_valid_overflow;
     const uint32_t q = blockIdx.x;
     const uint32_t n = world * k;
     uint32_t n_pad = 1;
     while (n_pad < n)
         n_pad <<= 1;
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         s_valid = 0;
+        s_valid_overflow = 0;
+    }
     __syncthreads();
     uint32_t valid = 0;
     for (uint32_t i = threadIdx.x; i < n_pad; i += 256) {
@@ -470,7 +483,9 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
         if (i < n) {
             const uint32_t r = i / k, j = i - r * k;
             const uint64_t p = gathered[(static_cast<size_t>(r) * n_queries + q) * k + j];
-            if (p != 0) {
+            if (p == ~0ull) {
+                s_valid_overflow = 1u; // a shard's guard band overflowed: this query has to be redone everywhere
+            } else if (p != 0) {
                 const uint64_t local = 0xFFFFFFFFull - (p & 0xFFFFFFFFull);
                 const uint64_t glob = bases.base[r] + local;
                 v = (p & 0xFFFFFFFF00000000ull) | (0xFFFFFFFFull - glob);
@@ -521,7 +536,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
         cos_out[static_cast<size_t>(q) * k + i] = key_score(static_cast<uint32_t>(v >> 32));
     }
     if (threadIdx.x == 0)
-        n_out[q] = m;
+        n_out[q] = s_valid_overflow ? 0xFFFFFFFFu : m;
 }
 
 __global__ void emit_kernel(const uint64_t *__restrict__ packed, uint32_t n, uint64_t *__restrict__ out, uint32_t k)
@@ -1259,6 +1274,114 @@ int32_t rlr_search_topk_device(rlr_index *ix, const float *queries, uint32_t n_q
     // run_search has synchronised the context stream, so the results are complete; a later
     // enqueue on `user` is ordered after them.
     (void)user;
+    return RLR_OK;
+}
+
+// Asynchronous flavour for the sharded step: begin() enqueues the pipelines and makes `stream` wait for
+// them, so the caller can queue its collective and merge behind the scan without a host round trip; end()
+// joins, reports queries whose guard band overflowed (their slots in d_packed_out are not valid: the caller
+// re-runs the step through rlr_search_topk_device) and returns the context.
+int32_t rlr_search_topk_device_begin(rlr_index *ix, const float *queries, uint32_t n_queries, uint32_t k, float guard_eps,
+                                     void *d_packed_out, void *stream, void **ticket_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (!ticket_out)
+        return fail(RLR_E_INVALID, "ticket_out is null");
+    *ticket_out = nullptr;
+    if (n_queries && k && (!queries || !d_packed_out))
+        return fail(RLR_E_INVALID, "queries / d_packed_out is null");
+    RLR_TRY(use_device(ix));
+    // anything but the plain single-query pipelines runs synchronously (ticket stays null)
+    const bool timed = ix->profiling; // one query: its four events are read in end()
+    if (n_queries == 0 || k == 0 || ix->n_rows == 0 || k > ix->n_rows || (timed && n_queries > 1) ||
+        batch_eligible(ix, n_queries, k))
+        return rlr_search_topk_device(ix, queries, n_queries, k, guard_eps, d_packed_out, stream);
+    Ctx *c = nullptr;
+    RLR_TRY(ctx_acquire(ix, &c));
+    CtxLease lease(ix);
+    lease.c = c; // released on every error path below
+    SearchPlan p;
+    p.k = k;
+    p.two_eps = 2.0f * (guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim));
+    p.cap = kLdsSortCap;
+    RLR_TRY(ctx_prepare(ix, c, n_queries, p));
+    const size_t q_bytes = static_cast<size_t>(n_queries) * ix->q_pitch * sizeof(float);
+    RLR_TRY(pin_reserve(c, q_bytes + (static_cast<size_t>(n_queries) * k + n_queries) * sizeof(uint64_t)));
+    float *h_q = static_cast<float *>(c->h_pin);
+    uint64_t *h_meta = reinterpret_cast<uint64_t *>(static_cast<char *>(c->h_pin) + q_bytes) + static_cast<size_t>(n_queries) * k;
+    if (ix->q_pitch != ix->dim)
+        std::memset(h_q, 0, q_bytes);
+    for (uint32_t q = 0; q < n_queries; ++q)
+        std::memcpy(h_q + static_cast<size_t>(q) * ix->q_pitch, queries + static_cast<size_t>(q) * ix->dim,
+                    ix->dim * sizeof(float));
+    // The pipelines go on the CALLER's stream: whatever it queues next (all-gather, merge) is ordered behind
+    // them by the stream itself.  (A cross-stream event wait was measured first: +20 us per step.)  The
+    // context's own stream is idle -- every earlier use of this context ended with a synchronisation.
+    hipStream_t own = c->stream;
+    c->stream = static_cast<hipStream_t>(stream);
+    hipStream_t s = c->stream;
+    c->hist_dirty = true;
+    hipError_t e = hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s);
+    uint64_t *out = static_cast<uint64_t *>(d_packed_out);
+    for (uint32_t q = 0; q < n_queries && e == hipSuccess; ++q)
+        e = enqueue_query(ix, c, q, p, out + static_cast<size_t>(q) * k, h_meta + q, timed);
+    c->stream = own;
+    if (e != hipSuccess)
+        return fail(RLR_E_HIP, "enqueue on the caller's stream failed: %s", hipGetErrorString(e));
+    c->pending_stream = s;
+    c->pending_timed = timed;
+    c->pending_q = n_queries;
+    c->pending_meta = h_meta;
+    c->pending_k = k;
+    lease.c = nullptr; // the ticket owns the context until end()
+    *ticket_out = c;
+    return RLR_OK;
+}
+
+int32_t rlr_search_topk_device_end(rlr_index *ix, void *ticket, uint32_t *n_overflow_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (n_overflow_out)
+        *n_overflow_out = 0;
+    if (!ticket)
+        return RLR_OK; // begin() ran synchronously
+    Ctx *c = static_cast<Ctx *>(ticket);
+    CtxLease lease(ix);
+    lease.c = c;
+    RLR_TRY(use_device(ix));
+    RLR_HIP(hipStreamSynchronize(c->pending_stream));
+    uint32_t over = 0;
+    uint64_t n_cand = 0;
+    for (uint32_t q = 0; q < c->pending_q; ++q) {
+        const uint32_t nc = static_cast<uint32_t>(c->pending_meta[q]);
+        n_cand += nc;
+        over += nc > kLdsSortCap;
+    }
+    c->hist_dirty = false;
+    float t_scan = 0, t_sel = 0, t_res = 0;
+    if (c->pending_timed) {
+        RLR_HIP(hipEventElapsedTime(&t_scan, c->ev[0], c->ev[1]));
+        RLR_HIP(hipEventElapsedTime(&t_sel, c->ev[1], c->ev[2]));
+        RLR_HIP(hipEventElapsedTime(&t_res, c->ev[2], c->ev[3]));
+    }
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        ix->prof.n_searches += c->pending_q;
+        ix->prof.n_candidates += n_cand;
+        ix->prof.n_retries += over;
+        if (c->pending_timed) {
+            ix->prof.n_scan_launches += c->pending_q;
+            ix->prof.scan_ms += t_scan;
+            ix->prof.select_ms += t_sel;
+            ix->prof.rescore_ms += t_res;
+            ix->prof.total_ms += t_scan + t_sel + t_res;
+            ix->prof.scan_bytes += static_cast<uint64_t>(c->pending_q) * ix->n_rows * ix->dim * (ix->dtype == RLR_F16 ? 2 : 4);
+        }
+    }
+    c->pending_q = 0;
+    c->pending_timed = false;
+    if (n_overflow_out)
+        *n_overflow_out = over;
     return RLR_OK;
 }
 

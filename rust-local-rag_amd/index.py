@@ -128,6 +128,20 @@ class GpuIndex:
         N.check(self._L.rlr_search_topk_device(self._h, _fp(q), q.shape[0], k, guard_eps,
                                                C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
+    def search_topk_device_begin(self, queries, k: int, d_out_ptr: int, stream: int = 0, guard_eps: float = -1.0):
+        """enqueue the search, make `stream` wait for it, return a ticket for search_topk_device_end"""
+        q = _f32(queries).reshape(-1, self.dim)
+        t = C.c_void_p()
+        N.check(self._L.rlr_search_topk_device_begin(self._h, _fp(q), q.shape[0], k, guard_eps, C.c_void_p(d_out_ptr),
+                                                     C.c_void_p(stream), C.byref(t)))
+        return t
+
+    def search_topk_device_end(self, ticket) -> int:
+        """join; -> number of queries whose results are invalid (guard band overflow: redo synchronously)"""
+        n = C.c_uint32()
+        N.check(self._L.rlr_search_topk_device_end(self._h, ticket, C.byref(n)))
+        return n.value
+
     def score_rows(self, query, rows) -> np.ndarray:
         q = _f32(query).ravel()
         rows = _u64(rows).ravel()

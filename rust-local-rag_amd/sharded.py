@@ -113,7 +113,7 @@ class ShardedIndex:
     def upload_shard(self, rows_global) -> None:
         self.index.upload(_f32(rows_global)[self.lo:self.hi])
 
-    def search_topk(self, queries, k: int):
+    def search_topk(self, queries, k: int, _redo: bool = False):
         """-> (global rows int64 [Q,k'], cos f32 [Q,k']) identical on every rank."""
         torch = self.torch
         q = _f32(queries).reshape(-1, self.dim)
@@ -125,7 +125,12 @@ class ShardedIndex:
             self._cos_h = np.zeros((nq, k), dtype=np.float32)
             self._n_h = np.zeros(nq, dtype=np.uint32)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
-        self.index.search_topk_device(q, k, self._local.data_ptr(), stream)
+        if _redo:
+            self.index.search_topk_device(q, k, self._local.data_ptr(), stream)   # synchronous, handles overflow
+            ticket = None
+        else:
+            # the collective and the merge are queued behind the scan: no host round trip in between
+            ticket = self.index.search_topk_device_begin(q, k, self._local.data_ptr(), stream)
         if self.world > 1 or (self.dist is not None and os.environ.get("RLR_BENCH_FORCE_DIST") == "1"):
             # the exchange step: world x k x 8 B per query over xGMI (RCCL all-gather)
             self.dist.all_gather_into_tensor(self._gath.view(self.world * nq, k), self._local, group=self.group)
@@ -137,6 +142,13 @@ class ShardedIndex:
         N.check(N.lib().rlr_merge_topk(self.dev.index, C.c_void_p(gathered.data_ptr()), self.world, nq, k,
                                        self._bases_h.ctypes.data_as(N.u64p), rows_h.ctypes.data_as(N.u64p),
                                        cos_h.ctypes.data_as(N.f32p), n_h.ctypes.data_as(N.u32p), C.c_void_p(stream)))
+        if ticket is not None:
+            self.index.search_topk_device_end(ticket)
+        # A shard whose guard band overflowed (massive exact ties) marks its slot; the marker travels through the
+        # all-gather, so every rank sees it in the merged counts and takes the same branch: redo the step on
+        # the synchronous path, which handles the overflow.
+        if not _redo and nq and (n_h[:nq] == 0xFFFFFFFF).any():
+            return self.search_topk(queries, k, _redo=True)
         n_valid = int(n_h[0]) if nq else 0
         return rows_h[:, :n_valid].astype(np.int64), cos_h[:, :n_valid].copy()
 

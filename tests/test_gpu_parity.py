@@ -359,6 +359,37 @@ def test_sharded_diversity_world1_winner_exchange_path(rlr, oracle):
         sh.index.close()
 
 
+def test_sharded_step_overflow_marker_forces_a_consistent_redo(rlr, oracle):
+    """the asynchronous sharded step (begin -> merge -> end): a shard whose guard band overflows marks its slot,
+    the merge reports the marker, the step is redone on the synchronous path -- results still exact"""
+    import importlib
+    import torch  # noqa: F401
+    sharded = importlib.import_module("rust-local-rag_amd.sharded")
+    base = oracle.synth_rows(3000, 768, seed=21)
+    q = oracle.synth_query(768, seed=22)
+    dup = oracle.normalize(q + np.float32(0.01) * base[0])
+    rows = np.concatenate([base, np.repeat(dup[None, :], 6000, axis=0)])
+    sh = sharded.ShardedIndex(768, len(rows), "f32", device=0, rank=0, world=1)
+    sh.upload_shard(rows)
+    qn = oracle.normalize(q)
+    # the marker itself: begin/end + merge, without the redo
+    local = torch.zeros((1, 10), dtype=torch.int64, device="cuda")
+    t = sh.index.search_topk_device_begin(qn, 10, local.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert sh.index.search_topk_device_end(t) == 1
+    torch.cuda.synchronize()
+    assert int(local[0, 0].item()) == -1                       # all-ones word
+    # the full step recovers
+    r, c = sh.search_topk(qn, 10)
+    assert r[0].tolist() == list(range(3000, 3010))
+    assert np.all(bits(c[0]) == bits([oracle.dot(qn, dup)])[0])
+    # and an ordinary query goes through the asynchronous path unchanged
+    q2 = oracle.normalize(oracle.synth_query(768, seed=23) - q)
+    r2, c2 = sh.search_topk(q2, 10)
+    wr, wc = oracle_topk(oracle, rows, q2, 10)
+    assert np.array_equal(r2[0].astype(np.uint64), wr) and np.array_equal(bits(c2[0]), bits(wc))
+    sh.index.close()
+
+
 def test_replicated_index_world1_and_query_sharding(rlr, oracle):
     """replicas-only mode: every rank holds the corpus, queries are dealt round-robin"""
     import importlib
