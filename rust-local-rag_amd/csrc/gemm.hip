@@ -339,10 +339,11 @@ __global__ __launch_bounds__(256) void build_image_kernel(const unsigned char *_
 constexpr int kRGI = 4;          // row groups per wave in the image kernel
 constexpr int kNBI = kNB / 2;    // query column blocks per wave
 
-template <bool MATERIALISE>
-__device__ __forceinline__ void gemm_image_epilogue(const GemmArgs &a, f32x4 (&acc)[kRGI][kNBI], uint32_t row0,
+template <bool MATERIALISE, int NBW>
+__device__ __forceinline__ void gemm_image_epilogue(const GemmArgs &a, f32x4 (&acc)[kRGI][NBW], uint32_t row0,
                                                     uint32_t last_row, uint32_t q0, int lane)
 {
+    constexpr int kNBI = NBW; // column blocks of this wave tile
     const uint32_t qcol = q0 + (lane & 15);
     if constexpr (MATERIALISE) {
 #pragma unroll
@@ -494,7 +495,111 @@ __global__ __launch_bounds__(512) void gemm_image_kernel(const GemmArgs a, const
 #undef RLR_LOAD_A
 #undef RLR_STORE_B
 #undef RLR_LOAD_B
-    gemm_image_epilogue<MATERIALISE>(a, acc, row0, last_row, qb * kQB + wq * (kNBI * 16), lane);
+    gemm_image_epilogue<MATERIALISE, kNBI>(a, acc, row0, last_row, qb * kQB + wq * (kNBI * 16), lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resident-query GEMM over the image: a workgroup keeps ALL K of 64 queries in LDS (dim/32 x 4 KB,
+// loaded once) and streams 512 rows past them, so the main loop has no LDS stores and no barriers:
+// every wave (64 rows x 64 queries, 16 accumulator tiles) runs its own software pipeline -- A
+// fragments straight from the image through a four-chunk register ring (three chunks of lookahead),
+// B fragments from LDS one K-step ahead.  The price: the rows are read once per 64-query group
+// (groups of one row block are adjacent workgroups of one XCD, so the re-reads hit its L2 -- FETCH_SIZE
+// stays at one pass), which is why this kernel only serves batches of <= 128 queries: there it does a
+// quarter / half of the 256-wide kernel's MFMA work and the pass is HBM-bound on the binary16 image;
+// at 256 queries it measured 7.0 ms against 5.2 ms.
+// ---------------------------------------------------------------------------------------------
+constexpr int kResQ = 64;               // queries per workgroup
+constexpr int kResNB = kResQ / 16;      // column blocks per wave (all waves share the queries)
+constexpr int kResRows = 512;           // rows per workgroup: 8 waves x 64
+constexpr int kResMaxKsteps = 36;       // dim <= 1152: 36 x 4 KB = 144 KB of the CU's 160 KB LDS
+constexpr int kResSlots = 4;            // A ring: chunks in flight per wave
+
+template <bool MATERIALISE>
+__global__ __launch_bounds__(512) void gemm_resident_kernel(const GemmArgs a, const half8 *__restrict__ image,
+                                                            uint32_t n_qgroups)
+{
+    __shared__ half8 s_b[kResMaxKsteps * kResNB * 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t bid = blockIdx.x;
+    const uint32_t rg512 = (bid / (8 * n_qgroups)) * 8 + (bid & 7); // row group relative to row_begin
+    const uint32_t qg = (bid >> 3) % n_qgroups;
+    const uint32_t n_rows = a.row_end - a.row_begin;
+    if (rg512 * kResRows >= n_rows)
+        return;
+
+    // the query group's fragments for every K-step: qfrag is [qblock 256][kstep][colblock 16][lane]
+    const half8 *bsrc = a.qfrag + static_cast<size_t>(qg / 4) * a.n_ksteps * kNB * 64 + (qg % 4) * kResNB * 64;
+    for (uint32_t i = tid; i < a.n_ksteps * kResNB * 64; i += 512) {
+        const uint32_t ks = i / (kResNB * 64), r = i % (kResNB * 64);
+        s_b[i] = bsrc[static_cast<size_t>(ks) * kNB * 64 + r];
+    }
+    __syncthreads();
+
+    const uint32_t row0 = a.row_begin + rg512 * kResRows + wave * 64;
+    if (row0 >= a.row_end)
+        return; // (no barrier below)
+    const uint32_t last_row = a.row_end - 1;
+    const uint32_t n_chunks = a.n_ksteps / kKsChunk;
+    const uint32_t tile = a.row_begin / kBM + rg512 * 2 + (wave >> 2);
+    const half8 *ap = image + (static_cast<size_t>(tile) * n_chunks * 8 + 2 * (wave & 3)) * 4 * 64 + lane;
+
+    f32x4 acc[kRGI][kResNB];
+#pragma unroll
+    for (int rg = 0; rg < kRGI; ++rg)
+#pragma unroll
+        for (int nb = 0; nb < kResNB; ++nb)
+            acc[rg][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    half8 ring[kResSlots][kRGI][kKsChunk];
+    const uint32_t last_c = n_chunks - 1;
+#define RLR_RES_LOAD_A(CHUNK, SLOT)                                                                \
+    _Pragma("unroll") for (int rg = 0; rg < kRGI; ++rg) _Pragma("unroll") for (int ks = 0; ks < kKsChunk; ++ks) \
+        ring[SLOT][rg][ks] = ap[static_cast<size_t>(CHUNK) * (8 * 4 * 64) + (rg * 2 + ks) * 64]
+#pragma unroll
+    for (int sl = 0; sl < kResSlots; ++sl) {
+        RLR_RES_LOAD_A(min(static_cast<uint32_t>(sl), last_c), sl);
+        // issue order = consumption order: loads return in order, so a younger slot 0 would make the
+        // loop's first wait a full drain (hipcc reverses the four slots otherwise)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    const half8 *sb = s_b + lane;
+    half8 bq[2][kResNB];
+#pragma unroll
+    for (int nb = 0; nb < kResNB; ++nb)
+        bq[0][nb] = sb[nb * 64];
+
+#pragma unroll 1
+    for (uint32_t c = 0; c < n_chunks; c += kResSlots) {
+#pragma unroll
+        for (int sl = 0; sl < kResSlots; ++sl) {
+            const uint32_t cc = c + sl; // n_chunks is a multiple of kResSlots: no tail, no branch
+            {
+#pragma unroll
+                for (int ks = 0; ks < kKsChunk; ++ks) {
+                    // B fragments of the next K-step (clamped re-read at the very end)
+                    const uint32_t next = min(cc * kKsChunk + ks + 1, a.n_ksteps - 1);
+#pragma unroll
+                    for (int nb = 0; nb < kResNB; ++nb)
+                        bq[(ks + 1) & 1][nb] = sb[(static_cast<size_t>(next) * kResNB + nb) * 64];
+#pragma unroll
+                    for (int nb = 0; nb < kResNB; ++nb)
+#pragma unroll
+                        for (int rg = 0; rg < kRGI; ++rg)
+                            acc[rg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[sl][rg][ks], bq[ks & 1][nb],
+                                                                                 acc[rg][nb], 0, 0, 0);
+                }
+                RLR_RES_LOAD_A(min(cc + kResSlots, last_c), sl);
+                __builtin_amdgcn_sched_barrier(0); // keep the refill here: sunk towards its use it is no ring
+            }
+        }
+    }
+#undef RLR_RES_LOAD_A
+    gemm_image_epilogue<MATERIALISE, kResNB>(a, acc, row0, last_row, qg * kResQ, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -750,6 +855,22 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
     const uint32_t n_rt = (row_end - row_begin + kBM - 1) / kBM;
     const uint32_t grid = ((n_rt + 7) / 8) * 8 * a.n_qblocks;
     const bool mat = scores != nullptr;
+    static const uint32_t resident_max = [] {
+        const char *v = getenv("RLR_GEMM_RESIDENT_MAX"); // largest batch served by the resident-query kernel
+        return v ? static_cast<uint32_t>(strtoul(v, nullptr, 0)) : 128u;
+    }();
+    if (image && n_queries <= resident_max && row_begin % kBM == 0 && a.n_ksteps <= kResMaxKsteps &&
+        a.n_ksteps % (kKsChunk * kResSlots) == 0) {
+        const half8 *img = static_cast<const half8 *>(image);
+        const uint32_t n_qg = (n_queries + kResQ - 1) / kResQ;
+        const uint32_t n_rg = (row_end - row_begin + kResRows - 1) / kResRows;
+        const uint32_t rgrid = ((n_rg + 7) / 8) * 8 * n_qg;
+        if (mat)
+            hipLaunchKernelGGL((gemm_resident_kernel<true>), dim3(rgrid), dim3(512), 0, s, a, img, n_qg);
+        else
+            hipLaunchKernelGGL((gemm_resident_kernel<false>), dim3(rgrid), dim3(512), 0, s, a, img, n_qg);
+        return hipGetLastError();
+    }
     if (image && row_begin % kBM == 0 && (a.n_ksteps / kKsChunk) % 4 == 0) {
         const half8 *img = static_cast<const half8 *>(image);
         if (mat)
