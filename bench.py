@@ -49,6 +49,8 @@ def parse():
                     help="keep the binary16 nomination image for the batched path (rlr_index_enable_batch_image)")
     ap.add_argument("--settle-ms", type=float, default=500.0,
                     help="untimed clock/power settle phase before the warmup steps (0 disables)")
+    ap.add_argument("--image-scan", action="store_true",
+                    help="single queries nominate over the binary16 image too (half the scan bytes; same results)")
     ap.add_argument("--batch", type=int, default=1,
                     help="queries per step; >= 16 takes the matrix-core (MFMA) batched path (BASELINE config 3 uses 256)")
     return ap.parse_args()
@@ -195,8 +197,8 @@ def main():
     fill_s = time.perf_counter() - t0
     ix = sh.index
     n_local = len(ix)
-    if args.image:
-        ix.enable_batch_image(True)
+    if args.image or args.image_scan:
+        ix.enable_batch_image(True, single_query=args.image_scan)
 
     force_sharded = os.environ.get("RLR_BENCH_FORCE_SHARDED") == "1" or force_dist  # rehearse the N>1 code path on one GPU
 
@@ -244,6 +246,9 @@ def main():
 
     elem = 2 if args.dtype == "f16" else 4
     scan_ms = prof.scan_ms / max(prof.n_scan_launches, 1)
+    image_scan = args.image_scan and args.dtype == "f32"
+    if image_scan:
+        elem = 2  # the nomination scan streams the binary16 image: those are the bytes this kernel has to read
     bytes_per_launch = n_local * args.dim * elem
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     batched = args.batch > 1
@@ -297,6 +302,10 @@ def main():
         out["stages_ms"] = {"gemm": gemm_ms, "select_and_finish": prof.batch_other_ms / prof.n_batches}
         out["band_retries"] = prof.n_batch_fallbacks
         out["dtype"] = f"{args.dtype} rows, f16 MFMA nomination + f32 reference-order re-score"
+    if image_scan and not batched:
+        out["roofline"]["kernel"] = "scan_image_kernel"
+        out["dtype"] = "f32 rows, binary16 nomination scan over the image + f32 reference-order re-score"
+        out["config"]["workload"] += "; single-query nomination over the binary16 image (opt-in, +dim*2 B/row of HBM)"
     t = pmc_traffic(bytes_per_launch) if not batched else None
     if t:
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t[0], f"profiles/{t[1]} (rocprofv3 --pmc)"

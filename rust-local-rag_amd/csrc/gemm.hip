@@ -499,6 +499,96 @@ __global__ __launch_bounds__(512) void gemm_image_kernel(const GemmArgs a, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Single-query scan over the image: the HBM-bound scan of scan.hip at half the bytes.  The image is a
+// binary16 copy of the rows, so a query that only needs NOMINATED scores (the exact re-score reads the
+// f32 rows of the few candidates) can stream 2 B per element instead of 4.  A wave owns one (tile, wave)
+// slot of the image = 32 rows: per K-chunk its four fragments are 4 KB contiguous; a lane holds 8 halfs
+// of row (lane & 15) at k-group (lane >> 4), multiplies them with the matching 8 query halfs from LDS
+// (v_dot2_f32_f16: exact products, f32 accumulate) and the four k-groups of a row meet in two
+// cross-lane adds at the end.  Same outputs as scan.hip: scores[row] and the digit-1 histogram.
+// |nominated - reference| <= nomination_eps (both operands rounded to binary16), as in the batched path.
+// ---------------------------------------------------------------------------------------------
+template <int kScanImgChunks> // K-chunks in flight per wave (4 loads of 1 KiB each)
+__global__ __launch_bounds__(256) void scan_image_kernel(const half8 *__restrict__ image, const float *__restrict__ query,
+                                                         float *__restrict__ scores, uint32_t *__restrict__ g_hist,
+                                                         uint32_t n_rows, uint32_t n_chunks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    half8 *s_q = reinterpret_cast<half8 *>(s_raw);                                   // n_chunks * 8 half8
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_raw + static_cast<size_t>(n_chunks) * 8 * 16);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // query -> binary16 (round to nearest even), 8 consecutive k per entry
+    for (uint32_t i = tid; i < n_chunks * 8; i += 256) {
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = static_cast<_Float16>(query[i * 8 + j]);
+        s_q[i] = v;
+    }
+    for (int i = tid; i < kHistBins; i += 256)
+        s_hist[i] = 0;
+    __syncthreads();
+
+    const uint32_t n_slots = ((n_rows + kBM - 1) / kBM) * 8; // (tile, image wave) pairs, 32 rows each
+    const uint32_t n_waves = gridDim.x * 4;
+    const int g = lane >> 4;
+    for (uint32_t slot = blockIdx.x * 4 + wave; slot < n_slots; slot += n_waves) {
+        const uint32_t tile = slot >> 3, w = slot & 7;
+        const half8 *ap = image + (static_cast<size_t>(tile) * n_chunks * 8 + w) * 4 * 64 + lane;
+        float acc0 = 0.0f, acc1 = 0.0f;
+        for (uint32_t c0 = 0; c0 < n_chunks; c0 += kScanImgChunks) {
+            half8 x[kScanImgChunks][4];
+#pragma unroll
+            for (int cc = 0; cc < kScanImgChunks; ++cc) {
+                const uint32_t c = min(c0 + cc, n_chunks - 1); // clamped re-read past the end, not used
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    x[cc][f] = __builtin_nontemporal_load(ap + static_cast<size_t>(c) * (8 * 4 * 64) + f * 64);
+            }
+#pragma unroll
+            for (int cc = 0; cc < kScanImgChunks; ++cc) {
+                if (c0 + cc < n_chunks) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const half8 q = s_q[((c0 + cc) * 2 + ks) * 4 + g];
+                        const half8 a = x[cc][ks];     // row group 0
+                        const half8 b = x[cc][2 + ks]; // row group 1
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const half2v qq = {q[2 * j], q[2 * j + 1]};
+                            acc0 = __builtin_amdgcn_fdot2(half2v{a[2 * j], a[2 * j + 1]}, qq, acc0, false);
+                            acc1 = __builtin_amdgcn_fdot2(half2v{b[2 * j], b[2 * j + 1]}, qq, acc1, false);
+                        }
+                    }
+                }
+            }
+        }
+        // the four k-groups of a row sit 16 lanes apart
+        acc0 += __shfl_xor(acc0, 16);
+        acc0 += __shfl_xor(acc0, 32);
+        acc1 += __shfl_xor(acc1, 16);
+        acc1 += __shfl_xor(acc1, 32);
+        const uint32_t row = tile * kBM + w * 32 + lane; // lanes 0..31: row groups 0 and 1 back to back
+        if (lane < 32 && row < n_rows) {
+            const float v = lane < 16 ? acc0 : acc1;
+            scores[row] = v;
+            if (g_hist)
+                atomicAdd(&s_hist[score_key(v) >> 21], 1u);
+        }
+    }
+    if (g_hist) {
+        __syncthreads();
+        for (int i = tid; i < kHistBins; i += 256) {
+            const uint32_t c = s_hist[i];
+            if (c)
+                atomicAdd(&g_hist[i], c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Resident-query GEMM over the image: a workgroup keeps ALL K of 64 queries in LDS (dim/32 x 4 KB,
 // loaded once) and streams 512 rows past them, so the main loop has no LDS stores and no barriers:
 // every wave (64 rows x 64 queries, 16 accumulator tiles) runs its own software pipeline -- A
@@ -908,6 +998,35 @@ hipError_t launch_build_image(const void *rows, uint32_t pitch16, uint32_t dim, 
     else
         hipLaunchKernelGGL(build_image_kernel<false>, dim3(blocks), dim3(256), 0, s, r, pitch16 * 16, n_rows, n_chunks,
                            tile_begin, tile_end, static_cast<half8 *>(image));
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_image(const void *image, uint32_t n_rows, uint32_t dim, const float *query, float *scores,
+                             uint32_t *hist, int n_cu, hipStream_t s)
+{
+    if (n_rows == 0)
+        return hipSuccess;
+    const uint32_t n_chunks = dim / 64;
+    const uint32_t n_slots = ((n_rows + kBM - 1) / kBM) * 8;
+    // 3 chunks in flight x 4 workgroups per CU: 6.42 TB/s at 10 M x 768; the other combinations of 2-6 chunks and
+    // 2-16 workgroups per CU measured 6.25-6.43 (scratch/sweep_img.sh)
+    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_slots + 3) / 4, static_cast<uint32_t>(n_cu) * 4));
+    const size_t lds = static_cast<size_t>(n_chunks) * 8 * 16 + kHistBins * sizeof(uint32_t);
+    static const int tune = [] {
+        const char *v = getenv("RLR_SCAN_IMAGE_VARIANT"); // chunks in flight | workgroups per CU << 8
+        return v ? static_cast<int>(strtol(v, nullptr, 0)) : 0;
+    }();
+    const int nc = (tune & 0xFF) ? (tune & 0xFF) : 3;
+    uint32_t grid = blocks;
+    if ((tune >> 8) & 0xFF)
+        grid = std::max<uint32_t>(1, std::min<uint32_t>((n_slots + 3) / 4, static_cast<uint32_t>(n_cu) * ((tune >> 8) & 0xFF)));
+    const half8 *img = static_cast<const half8 *>(image);
+    switch (nc) {
+    case 2: hipLaunchKernelGGL(scan_image_kernel<2>, dim3(grid), dim3(256), lds, s, img, query, scores, hist, n_rows, n_chunks); break;
+    case 4: hipLaunchKernelGGL(scan_image_kernel<4>, dim3(grid), dim3(256), lds, s, img, query, scores, hist, n_rows, n_chunks); break;
+    case 6: hipLaunchKernelGGL(scan_image_kernel<6>, dim3(grid), dim3(256), lds, s, img, query, scores, hist, n_rows, n_chunks); break;
+    default: hipLaunchKernelGGL(scan_image_kernel<3>, dim3(grid), dim3(256), lds, s, img, query, scores, hist, n_rows, n_chunks); break;
+    }
     return hipGetLastError();
 }
 

@@ -134,6 +134,7 @@ struct rlr_index {
     uint32_t batch_min = 0;   // smallest batch that takes the matrix-core path; 0 = decide by the cost model,
                               // RLR_BATCH_MIN=n forces a threshold (a huge n disables the path)
     bool image_enabled = false; // keep a binary16 nomination image of the rows for the batched GEMM
+    bool image_scan = false;    // single queries nominate over the image too (half the bytes of f32 rows)
     void *d_image = nullptr;
     size_t image_cap = 0;       // bytes
     std::mutex mu;
@@ -360,6 +361,7 @@ struct SearchPlan {
     uint32_t k;        // per query, already clamped to n_rows
     uint32_t cap;      // candidate capacity
     float two_eps;
+    float two_eps_img; // band when the nomination scan ran over the binary16 image
 };
 
 int32_t ctx_prepare(rlr_index *ix, Ctx *c, uint32_t nq, const SearchPlan &p)
@@ -549,6 +551,20 @@ __global__ void emit_kernel(const uint64_t *__restrict__ packed, uint32_t n, uin
 
 namespace {
 
+// f32 rows with an up-to-date image and the opt-in set: the nomination scan reads the binary16 image
+bool scan_over_image(const rlr_index *ix)
+{
+    return ix->image_scan && ix->image_enabled && ix->d_image && ix->dtype == RLR_F32;
+}
+
+// band for image-nominated scores: the nomination bound, scaled like the caller scaled guard_eps
+float image_two_eps(const rlr_index *ix, float guard_eps)
+{
+    const float dflt = rlr_default_guard_eps(ix->dim);
+    const float scale = guard_eps > dflt ? guard_eps / dflt : 1.0f;
+    return 2.0f * nomination_eps(ix->dim, ix->dtype) * scale;
+}
+
 // Enqueue the whole pipeline for query `qi` on the context's stream:
 //   scan (+digit-1 histogram) -> digit-2 histogram (bin search folded in) -> collect (bin search
 //   folded in) -> LDS-staged reference-order re-score (clears the histograms for the next query)
@@ -576,10 +592,17 @@ hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p
     sa.dtype = ix->dtype;
     sa.n_cu = ix->n_cu;
     sa.variant = ix->scan_variant;
-    if ((e = launch_scan(sa, s)) != hipSuccess) return e;
+    const bool img = scan_over_image(ix);
+    if (img)
+        e = launch_scan_image(ix->d_image, n, ix->dim, dq, c->d_scores, hist1, ix->n_cu, s);
+    else
+        e = launch_scan(sa, s);
+    if (e != hipSuccess) return e;
     if (timed && (e = hipEventRecord(c->ev[1], s)) != hipSuccess) return e;
     if ((e = launch_hist2_find1(c->d_scores, n, hist1, hist2, st, p.k, p.cap, ix->n_cu, s)) != hipSuccess) return e;
-    if ((e = launch_collect_find2(c->d_scores, n, hist2, st, p.two_eps, c->d_cand, ix->n_cu, s)) != hipSuccess) return e;
+    if ((e = launch_collect_find2(c->d_scores, n, hist2, st, img ? p.two_eps_img : p.two_eps, c->d_cand, ix->n_cu, s)) !=
+        hipSuccess)
+        return e;
     if (timed && (e = hipEventRecord(c->ev[2], s)) != hipSuccess) return e;
     const uint32_t n_max = std::min<uint32_t>(p.cap, kLdsSortCap);
     if (!launch_rescore_staged(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st, c->d_packed, n_max,
@@ -809,6 +832,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     p.k = std::min<uint32_t>(k_req, n);
     const float eps = guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim);
     p.two_eps = 2.0f * eps;
+    p.two_eps_img = image_two_eps(ix, eps);
     p.cap = kLdsSortCap;
     *plan_out = p;
     if (h_results)
@@ -940,7 +964,8 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
             ix->prof.select_ms += select_ms;
             ix->prof.rescore_ms += rescore_ms;
             ix->prof.total_ms += total_ms;
-            ix->prof.scan_bytes += static_cast<uint64_t>(nq) * ix->n_rows * ix->dim * (ix->dtype == RLR_F16 ? 2 : 4);
+            ix->prof.scan_bytes += static_cast<uint64_t>(nq) * ix->n_rows * ix->dim *
+                                   ((ix->dtype == RLR_F16 || scan_over_image(ix)) ? 2 : 4);
         }
     }
     return RLR_OK;
@@ -1168,6 +1193,7 @@ int32_t rlr_index_enable_batch_image(rlr_index *ix, int32_t enable)
     RLR_TRY(use_device(ix));
     if (!enable) {
         ix->image_enabled = false;
+        ix->image_scan = false;
         if (ix->d_image)
             (void)hipFree(ix->d_image);
         ix->d_image = nullptr;
@@ -1176,6 +1202,9 @@ int32_t rlr_index_enable_batch_image(rlr_index *ix, int32_t enable)
     }
     if (ix->dim % 64 != 0)
         return fail(RLR_E_INVALID, "the nomination image needs dim %% 64 == 0 (dim = %u)", ix->dim);
+    ix->image_scan = (enable & 2) != 0;
+    if (ix->image_enabled && ix->d_image)
+        return RLR_OK; // already built and kept in sync by the mutators
     ix->image_enabled = true;
     return sync_image(ix, 0);
 }
@@ -1303,6 +1332,7 @@ int32_t rlr_search_topk_device_begin(rlr_index *ix, const float *queries, uint32
     SearchPlan p;
     p.k = k;
     p.two_eps = 2.0f * (guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim));
+    p.two_eps_img = image_two_eps(ix, p.two_eps * 0.5f);
     p.cap = kLdsSortCap;
     RLR_TRY(ctx_prepare(ix, c, n_queries, p));
     const size_t q_bytes = static_cast<size_t>(n_queries) * ix->q_pitch * sizeof(float);
@@ -1375,7 +1405,8 @@ int32_t rlr_search_topk_device_end(rlr_index *ix, void *ticket, uint32_t *n_over
             ix->prof.select_ms += t_sel;
             ix->prof.rescore_ms += t_res;
             ix->prof.total_ms += t_scan + t_sel + t_res;
-            ix->prof.scan_bytes += static_cast<uint64_t>(c->pending_q) * ix->n_rows * ix->dim * (ix->dtype == RLR_F16 ? 2 : 4);
+            ix->prof.scan_bytes += static_cast<uint64_t>(c->pending_q) * ix->n_rows * ix->dim *
+                                   ((ix->dtype == RLR_F16 || scan_over_image(ix)) ? 2 : 4);
         }
     }
     c->pending_q = 0;

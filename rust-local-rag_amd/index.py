@@ -106,9 +106,10 @@ class GpuIndex:
     def fill_synthetic(self, n_rows: int, seed: int, row0: int = 0, n_clusters: int = 0) -> None:
         N.check(self._L.rlr_index_fill_synthetic(self._h, n_rows, row0, seed, n_clusters))
 
-    def enable_batch_image(self, on: bool = True) -> None:
-        """binary16 nomination image for the batched matrix-core path (dim * 2 bytes per row)"""
-        N.check(self._L.rlr_index_enable_batch_image(self._h, int(on)))
+    def enable_batch_image(self, on: bool = True, single_query: bool = False) -> None:
+        """binary16 nomination image for the batched matrix-core path (dim * 2 bytes per row);
+        single_query=True lets single queries over f32 rows nominate from it too (half the scan bytes)"""
+        N.check(self._L.rlr_index_enable_batch_image(self._h, (1 | (2 if single_query else 0)) if on else 0))
 
     # -- hot path ------------------------------------------------------------
     def search_topk(self, queries, k: int, guard_eps: float = -1.0):

@@ -503,6 +503,38 @@ def test_batched_mfma_falls_back_on_duplicate_flood(rlr, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("dim", [768, 1024, 128, 1600])
+def test_single_query_nomination_over_the_image_is_exact(rlr, oracle, dim):
+    """enable_batch_image(single_query=True): the scan streams the binary16 image, the wider band is re-scored from
+    the f32 rows -- rows and scores identical to the oracle, for ragged row counts and after mutations"""
+    for n, k in ((4099, 25), (300, 300), (20000, 100)):
+        rows = oracle.synth_rows(n, dim, seed=900 + dim + n, n_clusters=11)
+        ix = make_index(rlr, rows)
+        ix.enable_batch_image(True, single_query=True)
+        for qi in range(2):
+            qn = oracle.normalize(oracle.synth_query(dim, seed=950 + dim + qi))
+            r, c = ix.search_topk(qn, k)
+            wr, wc = oracle_topk(oracle, rows, qn, k)
+            assert np.array_equal(r[0], wr), (dim, n)
+            assert np.array_equal(bits(c[0]), bits(wc)), (dim, n)
+        if n == 4099:
+            extra = oracle.synth_rows(300, dim, seed=77 + dim)
+            ix.append(extra)
+            ix.delete_rows([0, 255, 256, 4100])
+            cur = np.delete(np.concatenate([rows, extra]), [0, 255, 256, 4100], axis=0)
+            qn = oracle.normalize(extra[7] + oracle.synth_query(dim, seed=5) * np.float32(0.2))
+            r, c = ix.search_topk(qn, k)
+            wr, wc = oracle_topk(oracle, cur, qn, k)
+            assert np.array_equal(r[0], wr) and np.array_equal(bits(c[0]), bits(wc))
+            # a few queries at once take the per-query pipelines (below the batch threshold) -- same scan
+            qs = np.stack([oracle.normalize(oracle.synth_query(dim, seed=960 + i)) for i in range(3)])
+            r3, c3 = ix.search_topk(qs, k)
+            for i in range(3):
+                wr, wc = oracle_topk(oracle, cur, qs[i], k)
+                assert np.array_equal(r3[i], wr) and np.array_equal(bits(c3[i]), bits(wc))
+        ix.close()
+
+
 def test_merge_topk_kernel_matches_torch_merge_and_global_oracle(rlr, oracle):
     """Four shards searched one after the other on the one GPU, their packed results laid out as an
     all-gather would deliver them, merged by rlr_merge_topk: must equal the global oracle and the
