@@ -632,7 +632,8 @@ __global__ __launch_bounds__(64) void mmr_greedy_kernel(const float *__restrict_
         __syncthreads();
         if (lane == 0) {
             out_order[n_sel] = last;
-            out_mmr[n_sel] = key_score(static_cast<uint32_t>(best >> 32));
+            // the logged value, bit for bit (the compare above ran on the -0 -> +0 canonical form)
+            out_mmr[n_sel] = one_minus * rel[last] - lambda * max_sim[last];
             rem[best_p] = rem[n_rem - 1]; // swap_remove(best_idx)
         }
         n_sel++;
@@ -725,8 +726,10 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
             sim[j] = alive[j] ? g_last[lane + 64 * j] : 0.0f;
         float best_m = neg_inf;
         uint32_t best_pos = 0xFFFFFFFFu;
+        float raw[J];
 #pragma unroll
         for (int j = 0; j < J; ++j) {
+            raw[j] = 0.0f;
             if (!alive[j])
                 continue;
             if (finite_f(sim[j]))
@@ -736,6 +739,7 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
             const float t0 = one_minus * rel[j];
             const float t1 = lambda * ms[j];
             float m = t0 - t1;
+            raw[j] = m; // what the reference logs (sign of zero included)
             if (!finite_f(m))
                 continue;
             if (m == 0.0f)
@@ -750,10 +754,12 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
             break;
         const uint32_t wp = wave_min_u32(best_m == wm ? best_pos : 0xFFFFFFFFu);
         uint32_t win = 0;
+        float win_raw = 0.0f;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             if (alive[j] && pos[j] == wp) {
                 win = lane + 64 * j + 1;
+                win_raw = raw[j];
                 alive[j] = false;
             }
         }
@@ -766,9 +772,10 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
         for (int j = 0; j < J; ++j)
             if (alive[j] && pos[j] == n_rem - 1)
                 pos[j] = wp;
+        const float wm_raw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, win_raw), src));
         if (lane == 0) {
             out_order[n_sel] = last;
-            out_mmr[n_sel] = wm;
+            out_mmr[n_sel] = wm_raw;
         }
         n_sel++;
         n_rem--;

@@ -1,0 +1,95 @@
+"""Randomised differential test on the GPU: search_topk (single queries, small and large batches, with and without
+the nomination image / image scan, f32 and f16 rows, every row-pitch class, duplicate / zero / NaN rows) and MMR
+against the oracle.  Found the sign-of-zero difference in the logged MMR value at lambda = 1 (fixed in exact.hip).
+Standalone: python tests/test_gpu_fuzz.py <seconds> [seed]."""
+import importlib
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DIMS = [64, 100, 128, 192, 256, 320, 384, 512, 640, 768, 896, 1000, 1024, 1152, 1280, 1536, 2048]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def fuzz(budget: float, seed0: int):
+    rlr = importlib.import_module("rust-local-rag_amd")
+    from oracle import oracle as O
+
+    def otopk(rows, qn, k):
+        e = O.scan(rows, qn)
+        key = np.where(np.isnan(e), -np.inf, e)
+        order = np.lexsort((np.arange(len(e)), -key.astype(np.float64)))[:k]
+        return order.astype(np.uint64), e[order]
+
+    rng = np.random.default_rng(seed0)
+    t_end = time.time() + budget
+    n_cases = n_q = 0
+    while time.time() < t_end:
+        dim = int(rng.choice(DIMS)); dtype = str(rng.choice(["f32", "f32", "f16"]))
+        n = int(rng.choice([1, 2, 17, 63, 64, 65, 255, 256, 257, 1000, 4095, 4096, 4097, 9000, 20011]))
+        ncl = int(rng.choice([0, 0, 3, 50]))
+        seed = int(rng.integers(1, 1 << 30))
+        rows = O.synth_rows(n, dim, seed=seed, n_clusters=ncl, f16=(dtype == "f16"))
+        # special rows: duplicates, zeros, a NaN row, a scaled row
+        if n > 20 and rng.random() < 0.5:
+            rows[5] = rows[3]; rows[n - 1] = rows[3]; rows[7] = 0
+            if dtype == "f32" and rng.random() < 0.5: rows[9, 0] = np.nan
+        ix = rlr.GpuIndex(dim, dtype); ix.upload(rows)
+        mode = str(rng.choice(["plain", "image", "image_scan"])) if dim % 64 == 0 else "plain"
+        if mode != "plain": ix.enable_batch_image(True, single_query=(mode == "image_scan"))
+        nq = int(rng.choice([1, 1, 2, 5, 20, 40]))
+        k = int(min(rng.choice([1, 5, 10, 100, 300, 1000]), max(n, 1) + 3))
+        qs = np.stack([O.normalize(O.synth_query(dim, seed=seed + 7 + i)) for i in range(nq)])
+        if rng.random() < 0.3 and n > 3: qs[0] = O.normalize(rows[3].copy()) if np.isfinite(rows[3]).all() and rows[3].any() else qs[0]
+        r, c = ix.search_topk(qs, k)
+        for i in range(nq):
+            wr, wc = otopk(rows, qs[i], k)
+            ok = np.array_equal(r[i], wr) and np.array_equal(bits(c[i]), bits(wc))
+            if not ok:
+                print("MISMATCH", dict(dim=dim, dtype=dtype, n=n, ncl=ncl, seed=seed, mode=mode, nq=nq, k=k, q=i)); raise AssertionError("see the MISMATCH line above")
+            n_q += 1
+        # MMR on the first query's pool
+        if n >= 3 and np.isfinite(c[0]).all():
+            P = min(len(r[0]), 60); kk = int(rng.integers(1, P + 1)); lam = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
+            sc = (np.float32(0.7) * c[0][:P]).astype(np.float32)
+            o, m = ix.mmr_select(r[0][:P], sc, kk, lam)
+            wo, wm = O.mmr(rows[r[0][:P].astype(np.int64)], sc, kk, lam)
+            if not (np.array_equal(o, wo) and np.array_equal(bits(m[1:]), bits(wm[1:]))):
+                print("MMR MISMATCH", dict(dim=dim, dtype=dtype, n=n, seed=seed, P=P, kk=kk, lam=lam)); raise AssertionError("see the MISMATCH line above")
+        ix.close(); n_cases += 1
+    return n_cases, n_q
+
+
+def test_fuzz_against_the_oracle():
+    n_cases, n_q = fuzz(20.0, 20261004)
+    assert n_cases > 100 and n_q > 500
+
+
+def test_mmr_logged_value_keeps_the_sign_of_zero(rlr, oracle):
+    """lambda = 1: (1 - lambda) * rel is -0.0 for a negative relevance and the reference logs -0.0 - 0.0 = -0.0"""
+    rows = oracle.synth_rows(17, 1152, seed=470119562, f16=True)
+    ix = rlr.GpuIndex(1152, "f16")
+    ix.upload(rows)
+    q = oracle.normalize(oracle.synth_query(1152, seed=470119562 + 7))
+    r, c = ix.search_topk(q, 17)
+    sc = (np.float32(0.7) * c[0]).astype(np.float32)
+    o, m = ix.mmr_select(r[0], sc, 17, 1.0)
+    wo, wm = oracle.mmr(rows[r[0].astype(np.int64)], sc, 17, 1.0)
+    assert np.array_equal(o, wo) and np.array_equal(bits(m[1:]), bits(wm[1:]))
+    assert np.signbit(wm[1]) and wm[1] == 0.0          # the case that used to differ
+    ob, mb, nb = ix.mmr_select_batch(r, sc[None, :], np.array([17], np.uint32), 17, 1.0)
+    assert np.array_equal(ob[0, :17], wo) and np.array_equal(bits(mb[0, 1:17]), bits(wm[1:]))
+    ix.close()
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, ".")
+    print("fuzz ok: %d corpora, %d queries" % fuzz(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0,
+                                                  int(sys.argv[2]) if len(sys.argv) > 2 else 1))
