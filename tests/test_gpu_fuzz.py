@@ -67,6 +67,71 @@ def fuzz(budget: float, seed0: int):
     return n_cases, n_q
 
 
+def fuzz_engine(budget: float, seed0: int):
+    """RagEngine level: documents added / replaced / removed, hybrid search from caller pairs and from query text
+    (GPU BM25), weight overrides, stage-1 candidates + reranker blend, search_with_diversity -- against the oracle."""
+    rlr = importlib.import_module("rust-local-rag_amd")
+    from oracle import oracle as O
+    from oracle import lexical as OL
+
+    rng = np.random.default_rng(seed0)
+    vocab = [f"t{i:03d}w" for i in range(120)]
+    t_end = time.time() + budget
+    n_cases = 0
+    while time.time() < t_end:
+        dim = int(rng.choice([64, 256, 384, 768]))
+        eng = rlr.RagEngine(dim)
+        texts_of, n_docs = {}, int(rng.integers(1, 6))
+        for d in range(n_docs):
+            m = int(rng.choice([1, 7, 60, 400]))
+            texts_of[f"doc{d}.pdf"] = [" ".join(rng.choice(vocab, size=int(rng.integers(1, 25)))) for _ in range(m)]
+            eng.add_document(f"doc{d}.pdf", texts_of[f"doc{d}.pdf"],
+                             O.synth_rows(m, dim, seed=int(rng.integers(1, 1 << 30)), n_clusters=int(rng.choice([0, 4]))))
+        if n_docs > 1 and rng.random() < 0.5:     # drop one, replace another
+            eng.remove_document("doc0.pdf")
+            texts_of.pop("doc0.pdf")
+            m = int(rng.integers(1, 50))
+            texts_of["doc1.pdf"] = [" ".join(rng.choice(vocab, size=5)) for _ in range(m)]
+            eng.add_document("doc1.pdf", texts_of["doc1.pdf"], O.synth_rows(m, dim, seed=int(rng.integers(1, 1 << 30))))
+        n = len(eng)
+        stored = eng.index.fetch_rows(np.arange(n))
+        all_texts = [ch.text for ch in eng._chunks]
+        olex = OL.LexicalIndex()
+        for r, t in enumerate(all_texts):
+            olex.add_chunk(r, t, rank=r)
+        for _ in range(4):
+            q = O.synth_query(dim, seed=int(rng.integers(1, 1 << 30)))
+            k = int(rng.choice([1, 3, 5, 10, 50, 100]))
+            div = float(rng.choice([0.0, 0.0, 0.3, 0.7, 1.0]))
+            we, wl = (0.7, 0.3)
+            w = None
+            if rng.random() < 0.4:
+                we, wl = float(rng.choice([0.0, 0.2, 1.0])), float(rng.choice([0.0, 0.5, 0.9]))
+                w = rlr.QueryWeights(embedding=we, lexical=wl)
+            k_eff = k if div == 0.0 else max(3 * k, k + 10)
+            if rng.random() < 0.5:               # GPU BM25 from the query text
+                text = " ".join(rng.choice(vocab, size=int(rng.integers(1, 5))))
+                pairs = [(int(c), float(sc)) for c, sc in olex.score(text, 5 * k_eff, keep_zero=False)]
+                got = eng.search_with_diversity(q, k, div, weights=w, query_text=text)
+            else:                                 # caller-supplied pairs, ties and zeros included
+                m = int(rng.integers(0, min(n, 12) + 1))
+                rows_l = rng.choice(n, size=m, replace=False)
+                pairs = [(int(r), float(rng.choice([0.0, 0.5, 2.25, 7.0]))) for r in rows_l]
+                got = eng.search_with_diversity(q, k, div, weights=w, lexical=[(eng._chunks[r].id, sc) for r, sc in pairs])
+            wr, wc, we_o, wl_o = O.search_with_diversity(stored, q, k, div, w_e=we, w_l=wl, lex=pairs)
+            ctx = dict(dim=dim, n=n, k=k, div=div, we=we, wl=wl, pairs=len(pairs), seed0=seed0, case=n_cases)
+            assert [g.row for g in got] == list(wr), ctx
+            assert np.array_equal(bits([g.score for g in got]), bits(wc)), ctx
+            assert np.array_equal(bits([g.lexical_score for g in got]), bits(wl_o)), ctx
+        eng.close()
+        n_cases += 1
+    return n_cases
+
+
+def test_fuzz_engine_against_the_oracle():
+    assert fuzz_engine(15.0, 4242) > 20
+
+
 def test_fuzz_against_the_oracle():
     n_cases, n_q = fuzz(20.0, 20261004)
     assert n_cases > 100 and n_q > 500
@@ -91,5 +156,7 @@ def test_mmr_logged_value_keeps_the_sign_of_zero(rlr, oracle):
 
 if __name__ == "__main__":
     sys.path.insert(0, ".")
-    print("fuzz ok: %d corpora, %d queries" % fuzz(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0,
-                                                  int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    print("fuzz ok: %d corpora, %d queries" % fuzz(secs, seed))
+    print("engine fuzz ok: %d engines" % fuzz_engine(secs / 2, seed))
