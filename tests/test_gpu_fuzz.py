@@ -132,6 +132,60 @@ def test_fuzz_engine_against_the_oracle():
     assert fuzz_engine(15.0, 4242) > 20
 
 
+def fuzz_lexical(budget: float, seed0: int):
+    """GPU BM25 alone: random vocabularies (ASCII and not), add / replace / remove sequences, random limits."""
+    lex = importlib.import_module("rust-local-rag_amd.lexical")
+    from oracle import lexical as OL
+
+    rng = np.random.default_rng(seed0)
+    t_end = time.time() + budget
+    n_cases = 0
+    while time.time() < t_end:
+        V = int(rng.choice([5, 40, 400]))
+        vocab = [f"w{i}q" for i in range(V)] + ["Straße", "ÉTÉ", "naïve", "日本語テキスト", "ab", "x"]
+        n = int(rng.choice([1, 3, 50, 700, 9000]))
+        texts = [" ".join(rng.choice(vocab, size=int(rng.integers(0, 12)))) + rng.choice(["", ".", " --", "!?"]) for _ in range(n)]
+        g = lex.LexicalIndex(0)
+        for r, t in enumerate(texts):
+            g.add_chunk(r, t)
+        cur = list(texts)
+        for _ in range(int(rng.integers(0, 4))):           # mutations
+            if rng.random() < 0.5 and len(cur) > 1:
+                dead = sorted(set(int(x) for x in rng.choice(len(cur), size=int(rng.integers(1, min(len(cur), 6))), replace=False)))
+                g.remove_rows(dead)
+                cur = [t for r, t in enumerate(cur) if r not in set(dead)]
+            else:
+                r = int(rng.integers(0, len(cur) + 1))
+                t = " ".join(rng.choice(vocab, size=int(rng.integers(0, 8))))
+                g.add_chunk(r, t)
+                if r == len(cur):
+                    cur.append(t)
+                else:
+                    cur[r] = t
+        o = OL.LexicalIndex()
+        for r, t in enumerate(cur):
+            o.add_chunk(r, t, rank=r)
+        info = g.info()
+        assert info["total_docs"] == o.total_docs and info["total_length"] == o.total_length, (seed0, n_cases)
+        for _ in range(5):
+            q = " ".join(rng.choice(vocab, size=int(rng.integers(0, 6))))
+            lim = int(rng.choice([0, 1, 5, 100, 1500, 8192]))
+            rows, sc = g.score(q, lim)
+            want = o.score(q, lim, keep_zero=False)
+            if lim == 0:
+                want = want[:8192]
+            ctx = dict(seed0=seed0, case=n_cases, q=q, lim=lim, n=len(cur))
+            assert [int(r) for r in rows] == [c for c, _ in want], ctx
+            assert np.array_equal(bits(sc), bits([x for _, x in want])), ctx
+        g.close()
+        n_cases += 1
+    return n_cases
+
+
+def test_fuzz_lexical_against_the_oracle():
+    assert fuzz_lexical(10.0, 555) > 10
+
+
 def test_fuzz_against_the_oracle():
     n_cases, n_q = fuzz(20.0, 20261004)
     assert n_cases > 100 and n_q > 500
@@ -160,3 +214,4 @@ if __name__ == "__main__":
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     print("fuzz ok: %d corpora, %d queries" % fuzz(secs, seed))
     print("engine fuzz ok: %d engines" % fuzz_engine(secs / 2, seed))
+    print("lexical fuzz ok: %d indexes" % fuzz_lexical(secs / 2, seed))

@@ -140,6 +140,15 @@ def test_duplicate_chunks_overflow_the_guard_band(rlr, oracle):
     assert list(got_rows[0]) == list(range(3000, 3010))
     assert np.all(bits(got_cos[0]) == bits([oracle.dot(qn, dup)])[0])
     assert ix.profile_read().n_retries >= 1
+    # the same flood when the scan nominates over the binary16 image (wider band), single query and three at once
+    # (the large-candidate path then re-scans with the f32 kernel against the image-derived threshold)
+    ix.enable_batch_image(True, single_query=True)
+    q2 = oracle.normalize(oracle.synth_query(768, seed=23))
+    for qs in (qn[None, :], np.stack([q2, qn, q2])):
+        r, c = ix.search_topk(qs, 10)
+        for i in range(len(qs)):
+            wr, wc = oracle_topk(oracle, rows, qs[i], 10)
+            assert np.array_equal(r[i], wr) and np.array_equal(bits(c[i]), bits(wc))
     ix.close()
 
 
