@@ -49,6 +49,7 @@ def parse():
                     help="keep the binary16 nomination image for the batched path (rlr_index_enable_batch_image)")
     ap.add_argument("--settle-ms", type=float, default=500.0,
                     help="untimed clock/power settle phase before the warmup steps (0 disables)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational optional-mode measurement")
     ap.add_argument("--image-scan", action="store_true",
                     help="single queries nominate over the binary16 image too (half the scan bytes; same results)")
     ap.add_argument("--batch", type=int, default=1,
@@ -309,6 +310,37 @@ def main():
     t = pmc_traffic(bytes_per_launch) if not batched else None
     if t:
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t[0], f"profiles/{t[1]} (rocprofv3 --pmc)"
+    # Informational, outside the timed region above: the same workload with the opt-in binary16 nomination image
+    # (identical results, the scan streams half the bytes).  Never the headline `value`.
+    if (world == 1 and not batched and not args.image_scan and not args.no_extras and args.dtype == "f32"
+            and args.dim % 64 == 0 and n_local * args.dim * 2 < 100e9):
+        try:
+            ix.enable_batch_image(True, single_query=True)
+            for i in range(20):
+                step(i % n_q)
+            ix.profile_read(reset=True)
+            ix.profile_enable(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                alt = step((args.warmup + i) % n_q)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            ix.profile_enable(False)
+            p2 = ix.profile_read()
+            k_ms = p2.scan_ms / max(p2.n_scan_launches, 1)
+            same = bool(last is not None and np.array_equal(alt[0], last[0]) and
+                        np.array_equal(alt[1].view(np.uint32), last[1].view(np.uint32)))
+            out["optional_modes"] = {"image_scan": {
+                "what": "single queries nominate over the binary16 image (rlr_index_enable_batch_image(idx, 3)); "
+                        "+dim*2 B/row of HBM, results identical",
+                "value": args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
+                "kernel": "scan_image_kernel", "kernel_ms": k_ms, "bytes_per_launch": n_local * args.dim * 2,
+                "achieved_GBps": n_local * args.dim * 2 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
+                "same_result_as_the_f32_scan_on_the_last_query": same}}
+            ix.enable_batch_image(False)
+        except Exception as e:  # never let the extra measurement take the headline line down
+            out["optional_modes"] = {"image_scan": {"error": str(e)}}
     if world == 1 and not args.no_cpu and O is not None:
         base, sample_rows, want = cpu_baseline(args, rlr)
         out["cpu_baseline"] = base
