@@ -186,6 +186,48 @@ def test_fuzz_lexical_against_the_oracle():
     assert fuzz_lexical(10.0, 555) > 10
 
 
+def fuzz_scale(budget: float, seed0: int):
+    """Corpora too large for the oracle (generated on the device): every batch shape x nomination mode must give
+    the same rows and score bits as the plain single-query f32 pipeline, whose own results are checked through
+    size-independent properties (emitted score == reference-order re-score, nothing in a random sample beats the
+    k-th result)."""
+    rlr = importlib.import_module("rust-local-rag_amd")
+    rng = np.random.default_rng(seed0)
+    t_end = time.time() + budget
+    n_cases = 0
+    while time.time() < t_end:
+        dim = int(rng.choice([256, 768, 1024, 1152]))
+        dtype = str(rng.choice(["f32", "f32", "f16"]))
+        n = int(rng.choice([5000, 70_000, 300_001, 1_500_000]))
+        k = int(rng.choice([1, 10, 100, 300]))
+        ix = rlr.GpuIndex(dim, dtype)
+        ix.fill_synthetic(n, seed=int(rng.integers(1, 1 << 30)), n_clusters=int(rng.choice([0, 64])))
+        nq = int(rng.choice([2, 8, 40, 64, 130, 300]))
+        qs = np.stack([rlr.normalize(rng.standard_normal(dim).astype(np.float32)) for _ in range(nq)])
+        base = [ix.search_topk(qs[i], k) for i in range(min(nq, 4))]           # plain single-query pipeline
+        for i, (r, c) in enumerate(base):
+            assert np.array_equal(bits(c[0]), bits(ix.score_rows(qs[i], r[0]))), ("rescore", dim, dtype, n, k)
+            sample = rng.choice(n, size=min(n, 20000), replace=False).astype(np.uint64)
+            sc = ix.score_rows(qs[i], sample)
+            assert sc[~np.isin(sample, r[0])].max(initial=-2.0) <= c[0][-1], ("topk", dim, dtype, n, k)
+        for mode in ("plain", "image", "image_scan"):
+            if mode != "plain":
+                ix.enable_batch_image(True, single_query=(mode == "image_scan"))
+            rb, cb = ix.search_topk(qs, k)
+            for i, (r, c) in enumerate(base):
+                ctx = dict(mode=mode, dim=dim, dtype=dtype, n=n, k=k, nq=nq, q=i, seed0=seed0, case=n_cases)
+                assert np.array_equal(rb[i], r[0]) and np.array_equal(bits(cb[i]), bits(c[0])), ctx
+            r1, c1 = ix.search_topk(qs[0], k)
+            assert np.array_equal(r1[0], base[0][0][0]) and np.array_equal(bits(c1[0]), bits(base[0][1][0])), (mode, "single")
+        ix.close()
+        n_cases += 1
+    return n_cases
+
+
+def test_fuzz_batch_shapes_and_nomination_modes_at_scale():
+    assert fuzz_scale(15.0, 31337) >= 3
+
+
 def test_fuzz_against_the_oracle():
     n_cases, n_q = fuzz(20.0, 20261004)
     assert n_cases > 100 and n_q > 500
@@ -215,3 +257,4 @@ if __name__ == "__main__":
     print("fuzz ok: %d corpora, %d queries" % fuzz(secs, seed))
     print("engine fuzz ok: %d engines" % fuzz_engine(secs / 2, seed))
     print("lexical fuzz ok: %d indexes" % fuzz_lexical(secs / 2, seed))
+    print("scale fuzz ok: %d corpora" % fuzz_scale(secs / 2, seed))
