@@ -123,9 +123,84 @@ def fuzz_engine(budget: float, seed0: int):
             assert [g.row for g in got] == list(wr), ctx
             assert np.array_equal(bits([g.score for g in got]), bits(wc)), ctx
             assert np.array_equal(bits([g.lexical_score for g in got]), bits(wl_o)), ctx
+        # stage-1 candidates (what a reranker receives) + the blend with a random reranker answer
+        q = O.synth_query(dim, seed=int(rng.integers(1, 1 << 30)))
+        k = int(rng.choice([1, 5, 20]))
+        cands = eng.search(q, k, stage=1)
+        wr, wc, _, _ = O.search(stored, q, k, stage=1)
+        assert [g.row for g in cands] == list(wr) and np.array_equal(bits([g.score for g in cands]), bits(wc)), ("stage1", seed0, n_cases)
+        m = int(rng.integers(0, len(cands) + 1))
+        picks = rng.permutation(len(cands))[:m]
+        rel = rng.random(m).astype(np.float32)
+        final = eng.finish_with_reranker(cands, [(cands[int(p_)].chunk_id, float(rel[j])) for j, p_ in enumerate(picks)], k)
+        bi, bs, _, _ = O.blend(wr, wc, [int(wr[int(p_)]) for p_ in picks], rel, k)
+        assert [g.row for g in final] == [int(wr[int(i)]) for i in bi], ("blend", seed0, n_cases)
+        assert np.array_equal(bits([g.score for g in final]), bits(bs)), ("blend scores", seed0, n_cases)
+        # get_embedding_candidates and the batched diversity entry point
+        cnt = int(rng.choice([1, 10, 200]))
+        ec = eng.get_embedding_candidates(q, cnt)
+        er, es = O.embedding_candidates(stored, q, cnt)
+        assert [eng._row_of[c] for c, _ in ec] == list(er) and np.array_equal(bits([x for _, x in ec]), bits(es)), ("ec", seed0, n_cases)
+        nqb = int(rng.choice([2, 5, 30]))
+        qb = np.stack([O.synth_query(dim, seed=int(rng.integers(1, 1 << 30))) for _ in range(nqb)])
+        kb, divb = int(rng.choice([3, 10])), float(rng.choice([0.0, 0.5]))
+        got_b = eng.search_with_diversity_batch(qb, kb, divb)
+        for i in range(nqb):
+            wr, wc, _, _ = O.search_with_diversity(stored, qb[i], kb, divb)
+            assert [g.row for g in got_b[i]] == list(wr) and np.array_equal(bits([g.score for g in got_b[i]]), bits(wc)), ("batch div", seed0, n_cases, i)
         eng.close()
         n_cases += 1
     return n_cases
+
+
+def fuzz_multi(budget: float, seed0: int):
+    """in-process multi-shard index (several shards on one GPU) against the single index: search (single and
+    batched), row scoring / fetching, MMR across shards"""
+    rlr = importlib.import_module("rust-local-rag_amd")
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(seed0)
+    t_end = time.time() + budget
+    n_cases = 0
+    while time.time() < t_end:
+        dim = int(rng.choice([64, 384, 768, 1024]))
+        dtype = str(rng.choice(["f32", "f16"]))
+        n = int(rng.choice([1, 5, 77, 1000, 12000]))
+        shards = int(rng.choice([1, 2, 3, 5]))
+        rows = O.synth_rows(n, dim, seed=int(rng.integers(1, 1 << 30)), n_clusters=int(rng.choice([0, 6])), f16=(dtype == "f16"))
+        if n > 10:
+            rows[n - 1] = rows[0]                                   # a cross-shard exact tie
+        one = rlr.GpuIndex(dim, dtype)
+        one.upload(rows)
+        mi = rlr.MultiGpuIndex(dim, [0] * shards, dtype)
+        mi.upload(rows)
+        nq = int(rng.choice([1, 3, 20]))
+        k = int(rng.choice([1, 10, 100]))
+        qs = np.stack([O.normalize(O.synth_query(dim, seed=int(rng.integers(1, 1 << 30)))) for _ in range(nq)])
+        if n > 10:
+            qs[0] = O.normalize(rows[0].copy())
+        r1, c1 = one.search_topk(qs, k)
+        rm, cm = mi.search_topk(qs, k)
+        ctx = dict(dim=dim, dtype=dtype, n=n, shards=shards, nq=nq, k=k, seed0=seed0, case=n_cases)
+        assert np.array_equal(r1, rm) and np.array_equal(bits(c1), bits(cm)), ctx
+        pick = rng.choice(n, size=min(n, 9), replace=False).astype(np.uint64)
+        assert np.array_equal(bits(one.score_rows(qs[0], pick)), bits(mi.score_rows(qs[0], pick))), ctx
+        assert np.array_equal(one.fetch_rows(pick).view(np.uint32), mi.fetch_rows(pick).view(np.uint32)), ctx
+        P = min(r1.shape[1], 40)
+        if P >= 2:
+            sc = (np.float32(0.7) * c1[0][:P]).astype(np.float32)
+            kk, lam = int(rng.integers(1, P + 1)), float(rng.choice([0.0, 0.4, 1.0]))
+            o1, m1 = one.mmr_select(r1[0][:P], sc, kk, lam)
+            om, mm = mi.mmr_select(r1[0][:P], sc, kk, lam)
+            assert np.array_equal(o1, om) and np.array_equal(bits(m1[1:]), bits(mm[1:])), ("mmr", ctx)
+        one.close()
+        mi.close()
+        n_cases += 1
+    return n_cases
+
+
+def test_fuzz_multi_shard_index():
+    assert fuzz_multi(10.0, 808) > 10
 
 
 def test_fuzz_engine_against_the_oracle():
@@ -258,3 +333,4 @@ if __name__ == "__main__":
     print("engine fuzz ok: %d engines" % fuzz_engine(secs / 2, seed))
     print("lexical fuzz ok: %d indexes" % fuzz_lexical(secs / 2, seed))
     print("scale fuzz ok: %d corpora" % fuzz_scale(secs / 2, seed))
+    print("multi-shard fuzz ok: %d corpora" % fuzz_multi(secs / 2, seed))
