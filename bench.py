@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the informational optional-mode measurement")
     ap.add_argument("--image-scan", action="store_true",
                     help="single queries nominate over the binary16 image too (half the scan bytes; same results)")
+    ap.add_argument("--q8-scan", action="store_true",
+                    help="single queries nominate over the 8-bit copy (a quarter of the scan bytes; same results)")
     ap.add_argument("--batch", type=int, default=1,
                     help="queries per step; >= 16 takes the matrix-core (MFMA) batched path (BASELINE config 3 uses 256)")
     return ap.parse_args()
@@ -198,8 +200,8 @@ def main():
     fill_s = time.perf_counter() - t0
     ix = sh.index
     n_local = len(ix)
-    if args.image or args.image_scan:
-        ix.enable_batch_image(True, single_query=args.image_scan)
+    if args.image or args.image_scan or args.q8_scan:
+        ix.enable_batch_image(args.image or args.image_scan, single_query=args.image_scan, q8=args.q8_scan)
 
     force_sharded = os.environ.get("RLR_BENCH_FORCE_SHARDED") == "1" or force_dist  # rehearse the N>1 code path on one GPU
 
@@ -248,8 +250,11 @@ def main():
     elem = 2 if args.dtype == "f16" else 4
     scan_ms = prof.scan_ms / max(prof.n_scan_launches, 1)
     image_scan = args.image_scan and args.dtype == "f32"
+    q8_scan = args.q8_scan and args.dtype == "f32"
     if image_scan:
         elem = 2  # the nomination scan streams the binary16 image: those are the bytes this kernel has to read
+    if q8_scan:
+        elem = 1  # one byte per element (+ 4 B of scale per row, not counted)
     bytes_per_launch = n_local * args.dim * elem
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     batched = args.batch > 1
@@ -303,7 +308,11 @@ def main():
         out["stages_ms"] = {"gemm": gemm_ms, "select_and_finish": prof.batch_other_ms / prof.n_batches}
         out["band_retries"] = prof.n_batch_fallbacks
         out["dtype"] = f"{args.dtype} rows, f16 MFMA nomination + f32 reference-order re-score"
-    if image_scan and not batched:
+    if q8_scan and not batched:
+        out["roofline"]["kernel"] = "q8_scan_kernel"
+        out["dtype"] = "f32 rows, 8-bit nomination scan + f32 reference-order re-score"
+        out["config"]["workload"] += "; single-query nomination over the 8-bit copy (opt-in, +dim+4 B/row of HBM)"
+    elif image_scan and not batched:
         out["roofline"]["kernel"] = "scan_image_kernel"
         out["dtype"] = "f32 rows, binary16 nomination scan over the image + f32 reference-order re-score"
         out["config"]["workload"] += "; single-query nomination over the binary16 image (opt-in, +dim*2 B/row of HBM)"
@@ -312,7 +321,7 @@ def main():
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t[0], f"profiles/{t[1]} (rocprofv3 --pmc)"
     # Informational, outside the timed region above: the same workload with the opt-in binary16 nomination image
     # (identical results, the scan streams half the bytes).  Never the headline `value`.
-    if (world == 1 and not batched and not args.image_scan and not args.no_extras and args.dtype == "f32"
+    if (world == 1 and not batched and not args.image_scan and not args.q8_scan and not args.no_extras and args.dtype == "f32"
             and args.dim % 64 == 0 and n_local * args.dim * 2 < 100e9):
         try:
             ix.enable_batch_image(True, single_query=True)

@@ -110,6 +110,7 @@ struct Ctx {
     // pinned host
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
+    std::vector<float> q_norm; // ||q||_2 of the staged queries (band of the 8-bit nomination scan)
     bool hist_dirty = false; // a pipeline was enqueued and did not complete: d_hist may hold counts
     // rlr_search_topk_device_begin / _end
     hipStream_t pending_stream = nullptr;
@@ -135,6 +136,14 @@ struct rlr_index {
                               // RLR_BATCH_MIN=n forces a threshold (a huge n disables the path)
     bool image_enabled = false; // keep a binary16 nomination image of the rows for the batched GEMM
     bool image_scan = false;    // single queries nominate over the image too (half the bytes of f32 rows)
+    // optional 8-bit nomination copy for single queries (q8.hip): a quarter of the f32 bytes
+    bool q8_enabled = false;
+    void *d_q8 = nullptr;        // cap_rows x dim bytes
+    float *d_q8_scale = nullptr; // cap_rows
+    uint32_t *d_q8_stats = nullptr; // [0] max row error norm (float bits), [1] max scale (float bits), [2] an Inf row exists
+    uint64_t q8_cap_rows = 0;
+    float q8_delta = 0.0f, q8_scale_max = 0.0f;
+    bool q8_has_inf = false;
     void *d_image = nullptr;
     size_t image_cap = 0;       // bytes
     std::mutex mu;
@@ -301,9 +310,42 @@ int32_t ensure_rows(rlr_index *ix, uint64_t want_rows)
     return RLR_OK;
 }
 
+// (Re)build the 8-bit nomination copy for rows >= first_row; the error / scale maxima only ever grow between
+// full rebuilds (a delete keeps the old maxima: conservative).
+int32_t sync_q8(rlr_index *ix, uint64_t first_row)
+{
+    if (!ix->q8_enabled)
+        return RLR_OK;
+    const uint64_t want = std::max<uint64_t>(ix->cap_rows, ix->n_rows);
+    if (ix->q8_cap_rows < want || !ix->d_q8) {
+        if (ix->d_q8) (void)hipFree(ix->d_q8);
+        if (ix->d_q8_scale) (void)hipFree(ix->d_q8_scale);
+        ix->d_q8 = nullptr;
+        ix->d_q8_scale = nullptr;
+        ix->q8_cap_rows = 0;
+        RLR_HIP(hipMalloc(&ix->d_q8, std::max<uint64_t>(want, 1) * ix->dim));
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_q8_scale), std::max<uint64_t>(want, 1) * sizeof(float)));
+        ix->q8_cap_rows = want;
+        first_row = 0;
+    }
+    if (!ix->d_q8_stats)
+        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_q8_stats), 4 * sizeof(uint32_t)));
+    if (first_row == 0)
+        RLR_HIP(hipMemset(ix->d_q8_stats, 0, 4 * sizeof(uint32_t)));
+    RLR_HIP(launch_q8_build(ix->d_rows, ix->pitch16, ix->dim, static_cast<uint32_t>(first_row),
+                            static_cast<uint32_t>(ix->n_rows), ix->d_q8, ix->d_q8_scale, ix->d_q8_stats, nullptr));
+    uint32_t h[4] = {0, 0, 0, 0};
+    RLR_HIP(hipMemcpy(h, ix->d_q8_stats, sizeof(h), hipMemcpyDeviceToHost));
+    std::memcpy(&ix->q8_delta, &h[0], 4);
+    std::memcpy(&ix->q8_scale_max, &h[1], 4);
+    ix->q8_has_inf = h[2] != 0;
+    return RLR_OK;
+}
+
 // (Re)build the nomination image for every tile that holds a row >= first_row.
 int32_t sync_image(rlr_index *ix, uint64_t first_row)
 {
+    RLR_TRY(sync_q8(ix, first_row));
     if (!ix->image_enabled)
         return RLR_OK;
     const size_t need = image_bytes(ix->dim, std::max<uint64_t>(ix->cap_rows, ix->n_rows));
@@ -557,6 +599,36 @@ bool scan_over_image(const rlr_index *ix)
     return ix->image_scan && ix->image_enabled && ix->d_image && ix->dtype == RLR_F32;
 }
 
+// ||q||_2 per staged query, rounded up (only the 8-bit nomination band needs it)
+void stage_query_norms(const rlr_index *ix, Ctx *c, const float *queries, uint32_t nq)
+{
+    if (!ix->q8_enabled)
+        return;
+    c->q_norm.resize(nq);
+    for (uint32_t q = 0; q < nq; ++q) {
+        double s2 = 0.0;
+        const float *v = queries + static_cast<size_t>(q) * ix->dim;
+        for (uint32_t i = 0; i < ix->dim; ++i)
+            s2 += static_cast<double>(v[i]) * v[i];
+        c->q_norm[q] = std::isfinite(s2) ? static_cast<float>(std::sqrt(s2) * 1.000001) : 1.0f;
+    }
+}
+
+// f32 rows with an up-to-date 8-bit copy: the nomination scan reads one byte per element
+bool scan_over_q8(const rlr_index *ix)
+{
+    return ix->q8_enabled && ix->d_q8 && !ix->q8_has_inf && ix->dtype == RLR_F32;
+}
+
+// band for 8-bit-nominated scores of a query of norm q_norm (Cauchy-Schwarz on the stored row error norms)
+float q8_two_eps(const rlr_index *ix, float q_norm, float guard_eps)
+{
+    const float dflt = rlr_default_guard_eps(ix->dim);
+    const float scale = guard_eps > dflt ? guard_eps / dflt : 1.0f;
+    const float qn = q_norm * 1.0001f + 1e-30f;
+    return 2.0f * (ix->q8_delta * qn + q8_arith_eps(ix->dim, ix->q8_scale_max, qn) + dflt) * scale;
+}
+
 // band for image-nominated scores: the nomination bound, scaled like the caller scaled guard_eps
 float image_two_eps(const rlr_index *ix, float guard_eps)
 {
@@ -592,16 +664,20 @@ hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p
     sa.dtype = ix->dtype;
     sa.n_cu = ix->n_cu;
     sa.variant = ix->scan_variant;
-    const bool img = scan_over_image(ix);
-    if (img)
+    const bool q8 = scan_over_q8(ix);
+    const bool img = !q8 && scan_over_image(ix);
+    if (q8)
+        e = launch_q8_scan(ix->d_q8, ix->d_q8_scale, n, ix->dim, dq, c->d_scores, hist1, ix->n_cu, s);
+    else if (img)
         e = launch_scan_image(ix->d_image, n, ix->dim, dq, c->d_scores, hist1, ix->n_cu, s);
     else
         e = launch_scan(sa, s);
     if (e != hipSuccess) return e;
     if (timed && (e = hipEventRecord(c->ev[1], s)) != hipSuccess) return e;
     if ((e = launch_hist2_find1(c->d_scores, n, hist1, hist2, st, p.k, p.cap, ix->n_cu, s)) != hipSuccess) return e;
-    if ((e = launch_collect_find2(c->d_scores, n, hist2, st, img ? p.two_eps_img : p.two_eps, c->d_cand, ix->n_cu, s)) !=
-        hipSuccess)
+    const float band = q8 ? q8_two_eps(ix, qi < c->q_norm.size() ? c->q_norm[qi] : 1.0f, p.two_eps * 0.5f)
+                          : (img ? p.two_eps_img : p.two_eps);
+    if ((e = launch_collect_find2(c->d_scores, n, hist2, st, band, c->d_cand, ix->n_cu, s)) != hipSuccess)
         return e;
     if (timed && (e = hipEventRecord(c->ev[2], s)) != hipSuccess) return e;
     const uint32_t n_max = std::min<uint32_t>(p.cap, kLdsSortCap);
@@ -856,6 +932,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     for (uint32_t q = 0; q < nq; ++q)
         std::memcpy(h_q + static_cast<size_t>(q) * ix->q_pitch, queries + static_cast<size_t>(q) * ix->dim,
                     ix->dim * sizeof(float));
+    stage_query_norms(ix, c, queries, nq);
     hipStream_t s = c->stream;
     c->hist_dirty = true; // cleared when every enqueued pipeline has run to its histogram-clearing stage
     RLR_HIP(hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s));
@@ -965,7 +1042,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
             ix->prof.rescore_ms += rescore_ms;
             ix->prof.total_ms += total_ms;
             ix->prof.scan_bytes += static_cast<uint64_t>(nq) * ix->n_rows * ix->dim *
-                                   ((ix->dtype == RLR_F16 || scan_over_image(ix)) ? 2 : 4);
+                                   (scan_over_q8(ix) ? 1 : (ix->dtype == RLR_F16 || scan_over_image(ix)) ? 2 : 4);
         }
     }
     return RLR_OK;
@@ -1076,6 +1153,9 @@ int32_t rlr_index_destroy(rlr_index *ix)
         ctx_free(c);
     if (ix->d_rows)
         (void)hipFree(ix->d_rows);
+    if (ix->d_q8) (void)hipFree(ix->d_q8);
+    if (ix->d_q8_scale) (void)hipFree(ix->d_q8_scale);
+    if (ix->d_q8_stats) (void)hipFree(ix->d_q8_stats);
     if (ix->d_image)
         (void)hipFree(ix->d_image);
     delete ix;
@@ -1191,22 +1271,44 @@ int32_t rlr_index_enable_batch_image(rlr_index *ix, int32_t enable)
 {
     RLR_TRY(check_handle(ix));
     RLR_TRY(use_device(ix));
-    if (!enable) {
+    const bool want_image = (enable & 3) != 0, want_q8 = (enable & 4) != 0;
+    if (!want_q8 && ix->q8_enabled) {
+        ix->q8_enabled = false;
+        if (ix->d_q8) (void)hipFree(ix->d_q8);
+        if (ix->d_q8_scale) (void)hipFree(ix->d_q8_scale);
+        ix->d_q8 = nullptr;
+        ix->d_q8_scale = nullptr;
+        ix->q8_cap_rows = 0;
+    }
+    if (!want_image) {
         ix->image_enabled = false;
         ix->image_scan = false;
         if (ix->d_image)
             (void)hipFree(ix->d_image);
         ix->d_image = nullptr;
         ix->image_cap = 0;
-        return RLR_OK;
     }
-    if (ix->dim % 64 != 0)
-        return fail(RLR_E_INVALID, "the nomination image needs dim %% 64 == 0 (dim = %u)", ix->dim);
-    ix->image_scan = (enable & 2) != 0;
-    if (ix->image_enabled && ix->d_image)
-        return RLR_OK; // already built and kept in sync by the mutators
-    ix->image_enabled = true;
-    return sync_image(ix, 0);
+    if (want_q8 && !ix->q8_enabled) {
+        if (ix->dtype != RLR_F32 || ix->dim % 16 != 0 || ix->dim > 1024)
+            return fail(RLR_E_INVALID, "the 8-bit nomination copy needs f32 rows and dim %% 16 == 0, dim <= 1024 (dim = %u)",
+                        ix->dim);
+        ix->q8_enabled = true;
+        RLR_TRY(sync_q8(ix, 0));
+    }
+    if (want_image) {
+        if (ix->dim % 64 != 0)
+            return fail(RLR_E_INVALID, "the nomination image needs dim %% 64 == 0 (dim = %u)", ix->dim);
+        ix->image_scan = (enable & 2) != 0;
+        if (!(ix->image_enabled && ix->d_image)) {
+            ix->image_enabled = true;
+            const bool q8 = ix->q8_enabled;
+            ix->q8_enabled = false; // the 8-bit copy is current: rebuild the image only
+            const int32_t st = sync_image(ix, 0);
+            ix->q8_enabled = q8;
+            RLR_TRY(st);
+        }
+    }
+    return RLR_OK;
 }
 
 int32_t rlr_index_fill_synthetic(rlr_index *ix, uint64_t n_rows, uint64_t row0, uint64_t seed, uint32_t n_clusters)
@@ -1344,6 +1446,7 @@ int32_t rlr_search_topk_device_begin(rlr_index *ix, const float *queries, uint32
     for (uint32_t q = 0; q < n_queries; ++q)
         std::memcpy(h_q + static_cast<size_t>(q) * ix->q_pitch, queries + static_cast<size_t>(q) * ix->dim,
                     ix->dim * sizeof(float));
+    stage_query_norms(ix, c, queries, n_queries);
     // The pipelines go on the CALLER's stream: whatever it queues next (all-gather, merge) is ordered behind
     // them by the stream itself.  (A cross-stream event wait was measured first: +20 us per step.)  The
     // context's own stream is idle -- every earlier use of this context ended with a synchronisation.
@@ -1406,7 +1509,7 @@ int32_t rlr_search_topk_device_end(rlr_index *ix, void *ticket, uint32_t *n_over
             ix->prof.rescore_ms += t_res;
             ix->prof.total_ms += t_scan + t_sel + t_res;
             ix->prof.scan_bytes += static_cast<uint64_t>(c->pending_q) * ix->n_rows * ix->dim *
-                                   ((ix->dtype == RLR_F16 || scan_over_image(ix)) ? 2 : 4);
+                                   (scan_over_q8(ix) ? 1 : (ix->dtype == RLR_F16 || scan_over_image(ix)) ? 2 : 4);
         }
     }
     c->pending_q = 0;

@@ -1,0 +1,222 @@
+// q8.hip -- optional 8-bit nomination copy of f32 rows for single-query scans.
+//
+// The scan of scan.hip only NOMINATES candidates; the reference-order re-score of exact.hip makes the
+// result exact.  So the scan may read any approximation of the rows whose error is BOUNDED: here one byte per
+// element (k = round(x / s_r), s_r = max|x| / 127 per row, stored biased by 128) plus the row's scale -- a
+// quarter of the f32 bytes.  For the band the library keeps, per index,
+//     delta_max = max_r || x_r - s_r k_r ||_2      (computed exactly at build time, rounded up)
+// and Cauchy-Schwarz gives | q . x_r - q . (s_r k_r) | <= ||q||_2 * delta_max for every row; the f32
+// evaluation of the quantised dot adds at most arith_eps (below).  A row holding a NaN gets a NaN scale, hence a
+// NaN nominated score, ordered last exactly like its reference dot; a row holding an Inf (whose reference dot may
+// be +inf, -inf or NaN depending on the query) switches the index back to the f32 scan.
+// Everything after the scan (select, re-score from the f32 master rows, sort) is the ordinary pipeline with
+// the wider band; results are identical to the f32 scan.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/rlr_gpu.h"
+
+#include <algorithm>
+
+namespace rlr {
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline float wave_max_abs(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+__device__ inline float wave_add_all(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off);
+    return v;
+}
+
+// one wavefront per row: scale, bytes, exact quantisation error norm
+__global__ __launch_bounds__(256) void q8_build_kernel(const float *__restrict__ rows, uint32_t pitch_floats, uint32_t dim,
+                                                       uint32_t row_begin, uint32_t n_rows, uint8_t *__restrict__ q8,
+                                                       float *__restrict__ scale, uint32_t *__restrict__ stats)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t row = row_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows)
+        return;
+    const float *x = rows + static_cast<size_t>(row) * pitch_floats;
+    float m = 0.0f;
+    bool has_nan = false, has_inf = false;
+    for (uint32_t e = lane; e < dim; e += 64) {
+        const float v = x[e];
+        has_nan |= v != v;
+        has_inf |= __builtin_fabsf(v) > 3.4028234e38f;
+        m = fmaxf(m, __builtin_fabsf(v));
+    }
+    has_nan = __ballot(has_nan) != 0;
+    has_inf = __ballot(has_inf) != 0;
+    const bool bad = has_nan || has_inf;
+    m = wave_max_abs(m);
+    const float s = (bad || m == 0.0f) ? 1.0f : m / 127.0f;
+    float err2 = 0.0f;
+    uint8_t *out = q8 + static_cast<size_t>(row) * dim;
+    for (uint32_t e = lane; e < dim; e += 64) {
+        const float v = bad ? 0.0f : x[e];
+        float k = __builtin_rintf(v / s);
+        k = fminf(fmaxf(k, -127.0f), 127.0f);
+        const float d = v - s * k;
+        err2 += d * d;
+        out[e] = static_cast<uint8_t>(static_cast<int>(k) + 128);
+    }
+    err2 = wave_add_all(err2);
+    if (lane == 0) {
+        // a NaN element makes the reference dot NaN (ordered last): the scan reproduces that through a NaN scale.
+        // An Inf element can make it +inf, -inf or NaN depending on the query: no bounded nomination exists, the
+        // index stops using the 8-bit copy (stats[2]).
+        scale[row] = bad ? __builtin_bit_cast(float, 0x7FC00000u) : s;
+        if (has_inf && !has_nan)
+            atomicOr(&stats[2], 1u);
+        // rounded up: the f32 sum of dim squares is within dim * 2^-24 relative of the exact one
+        const float delta = __builtin_sqrtf(err2) * 1.001f + 1e-30f;
+        if (!bad) {
+            atomicMax(&stats[0], __builtin_bit_cast(uint32_t, delta)); // non-negative floats order like their bits
+            atomicMax(&stats[1], __builtin_bit_cast(uint32_t, s));
+        }
+    }
+}
+
+// byte b of dword w as float (v_cvt_f32_ubyte{0..3})
+template <int B>
+__device__ inline float ubyte_f32(uint32_t w)
+{
+    return static_cast<float>((w >> (8 * B)) & 0xFFu);
+}
+
+__device__ inline float dot16_u8(u32x4 x, const float (&q)[16], float acc)
+{
+    acc = __builtin_fmaf(ubyte_f32<0>(x[0]), q[0], acc);
+    acc = __builtin_fmaf(ubyte_f32<1>(x[0]), q[1], acc);
+    acc = __builtin_fmaf(ubyte_f32<2>(x[0]), q[2], acc);
+    acc = __builtin_fmaf(ubyte_f32<3>(x[0]), q[3], acc);
+    acc = __builtin_fmaf(ubyte_f32<0>(x[1]), q[4], acc);
+    acc = __builtin_fmaf(ubyte_f32<1>(x[1]), q[5], acc);
+    acc = __builtin_fmaf(ubyte_f32<2>(x[1]), q[6], acc);
+    acc = __builtin_fmaf(ubyte_f32<3>(x[1]), q[7], acc);
+    acc = __builtin_fmaf(ubyte_f32<0>(x[2]), q[8], acc);
+    acc = __builtin_fmaf(ubyte_f32<1>(x[2]), q[9], acc);
+    acc = __builtin_fmaf(ubyte_f32<2>(x[2]), q[10], acc);
+    acc = __builtin_fmaf(ubyte_f32<3>(x[2]), q[11], acc);
+    acc = __builtin_fmaf(ubyte_f32<0>(x[3]), q[12], acc);
+    acc = __builtin_fmaf(ubyte_f32<1>(x[3]), q[13], acc);
+    acc = __builtin_fmaf(ubyte_f32<2>(x[3]), q[14], acc);
+    acc = __builtin_fmaf(ubyte_f32<3>(x[3]), q[15], acc);
+    return acc;
+}
+
+// dim <= 1024, dim % 16 == 0: a row is one 16-byte load per lane (lanes >= dim/16 idle), the lane's 16 query
+// values live in registers.  R rows in flight per wave, groups of <= 64 rows, scores parked per lane as in scan.hip.
+template <int R>
+__global__ __launch_bounds__(256) void q8_scan_kernel(const uint8_t *__restrict__ q8, const float *__restrict__ scale,
+                                                      const float *__restrict__ query, float *__restrict__ scores,
+                                                      uint32_t *__restrict__ g_hist, uint32_t n_rows, uint32_t dim,
+                                                      uint32_t group_rows)
+{
+    __shared__ uint32_t s_hist[kHistBins];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < kHistBins; i += 256)
+        s_hist[i] = 0;
+    const uint32_t p16 = dim / 16;
+    const bool active = static_cast<uint32_t>(lane) < p16;
+    float qv[16];
+    float qs = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        qv[b] = active ? query[lane * 16 + b] : 0.0f;
+        qs += qv[b];
+    }
+    const float bias = 128.0f * qs; // the bytes are biased by 128: subtract 128 * (this lane's query slice sum)
+    __syncthreads();
+
+    const uint32_t n_groups = (n_rows + group_rows - 1) / group_rows;
+    const uint32_t n_waves = gridDim.x * 4;
+    for (uint32_t g = blockIdx.x * 4 + wave; g < n_groups; g += n_waves) {
+        const uint32_t row0 = g * group_rows;
+        const uint32_t nr = min(group_rows, n_rows - row0);
+        float mine = 0.0f;
+        for (uint32_t r = 0; r < nr; r += R) {
+            u32x4 x[R];
+            float sc[R];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const uint32_t row = min(row0 + r + rr, row0 + nr - 1);
+                const u32x4 *p = reinterpret_cast<const u32x4 *>(q8 + static_cast<size_t>(row) * dim) + lane;
+                x[rr] = active ? __builtin_nontemporal_load(p) : u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+                sc[rr] = scale[row];
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const float acc = dot16_u8(x[rr], qv, 0.0f) - bias;
+                const float tot = wave_sum(acc);
+                const float v = sc[rr] * tot;
+                if (static_cast<uint32_t>(lane) == r + rr)
+                    mine = v; // NaN scale -> NaN score -> ordered last, like the reference dot of a row holding a NaN
+            }
+        }
+        if (static_cast<uint32_t>(lane) < nr) {
+            scores[row0 + lane] = mine;
+            if (g_hist)
+                atomicAdd(&s_hist[score_key(mine) >> 21], 1u);
+        }
+    }
+    if (g_hist) {
+        __syncthreads();
+        for (int i = tid; i < kHistBins; i += 256) {
+            const uint32_t c = s_hist[i];
+            if (c)
+                atomicAdd(&g_hist[i], c);
+        }
+    }
+}
+
+} // namespace
+
+hipError_t launch_q8_build(const void *rows, uint32_t pitch16, uint32_t dim, uint32_t row_begin, uint32_t n_rows, void *q8,
+                           float *scale, uint32_t *stats, hipStream_t s)
+{
+    if (row_begin >= n_rows)
+        return hipSuccess;
+    const uint32_t blocks = (n_rows - row_begin + 3) / 4;
+    hipLaunchKernelGGL(q8_build_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float *>(rows), pitch16 * 4, dim,
+                       row_begin, n_rows, static_cast<uint8_t *>(q8), scale, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_q8_scan(const void *q8, const float *scale, uint32_t n_rows, uint32_t dim, const float *query,
+                          float *scores, uint32_t *hist, int n_cu, hipStream_t s)
+{
+    if (n_rows == 0)
+        return hipSuccess;
+    constexpr int R = 8;
+    const uint32_t group = 64;
+    const uint32_t n_groups = (n_rows + group - 1) / group;
+    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_groups + 3) / 4, static_cast<uint32_t>(n_cu) * 8));
+    hipLaunchKernelGGL(q8_scan_kernel<R>, dim3(blocks), dim3(256), 0, s, static_cast<const uint8_t *>(q8), scale, query,
+                       scores, hist, n_rows, dim, group);
+    return hipGetLastError();
+}
+
+// | f32 evaluation of (scale * sum (byte - 128) * q) - exact value | for ||q||_2 <= q_norm: every intermediate is
+// at most 256 * ||q||_1 <= 256 * sqrt(dim) * q_norm, 16 chained FMAs + 6 reduction levels + bias and scale
+// roundings (< 32 roundings), times the largest row scale.
+float q8_arith_eps(uint32_t dim, float scale_max, float q_norm)
+{
+    return 32.0f * 5.9604645e-8f * 256.0f * __builtin_sqrtf(static_cast<float>(dim)) * q_norm * scale_max * 1.0625f;
+}
+
+} // namespace rlr

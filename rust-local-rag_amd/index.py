@@ -106,10 +106,13 @@ class GpuIndex:
     def fill_synthetic(self, n_rows: int, seed: int, row0: int = 0, n_clusters: int = 0) -> None:
         N.check(self._L.rlr_index_fill_synthetic(self._h, n_rows, row0, seed, n_clusters))
 
-    def enable_batch_image(self, on: bool = True, single_query: bool = False) -> None:
-        """binary16 nomination image for the batched matrix-core path (dim * 2 bytes per row);
-        single_query=True lets single queries over f32 rows nominate from it too (half the scan bytes)"""
-        N.check(self._L.rlr_index_enable_batch_image(self._h, (1 | (2 if single_query else 0)) if on else 0))
+    def enable_batch_image(self, on: bool = True, single_query: bool = False, q8: bool = False) -> None:
+        """Optional nomination copies of the rows (results never change, only the bytes the scan streams):
+        on            binary16 image for the batched matrix-core path (dim * 2 bytes per row)
+        single_query  single queries over f32 rows nominate from that image too (half the scan bytes)
+        q8            8-bit copy + per-row scale for single queries (a quarter of the scan bytes; dim * 1 + 4 B/row)"""
+        flags = (1 if (on or single_query) else 0) | (2 if single_query else 0) | (4 if q8 else 0)
+        N.check(self._L.rlr_index_enable_batch_image(self._h, flags))
 
     # -- hot path ------------------------------------------------------------
     def search_topk(self, queries, k: int, guard_eps: float = -1.0):

@@ -42,8 +42,10 @@ def fuzz(budget: float, seed0: int):
             rows[5] = rows[3]; rows[n - 1] = rows[3]; rows[7] = 0
             if dtype == "f32" and rng.random() < 0.5: rows[9, 0] = np.nan
         ix = rlr.GpuIndex(dim, dtype); ix.upload(rows)
-        mode = str(rng.choice(["plain", "image", "image_scan"])) if dim % 64 == 0 else "plain"
-        if mode != "plain": ix.enable_batch_image(True, single_query=(mode == "image_scan"))
+        mode = str(rng.choice(["plain", "image", "image_scan", "q8"])) if dim % 64 == 0 else "plain"
+        if mode == "q8":
+            if dtype == "f32" and dim <= 1024: ix.enable_batch_image(False, q8=True)
+        elif mode != "plain": ix.enable_batch_image(True, single_query=(mode == "image_scan"))
         nq = int(rng.choice([1, 1, 2, 5, 20, 40]))
         k = int(min(rng.choice([1, 5, 10, 100, 300, 1000]), max(n, 1) + 3))
         qs = np.stack([O.normalize(O.synth_query(dim, seed=seed + 7 + i)) for i in range(nq)])
@@ -285,8 +287,12 @@ def fuzz_scale(budget: float, seed0: int):
             sample = rng.choice(n, size=min(n, 20000), replace=False).astype(np.uint64)
             sc = ix.score_rows(qs[i], sample)
             assert sc[~np.isin(sample, r[0])].max(initial=-2.0) <= c[0][-1], ("topk", dim, dtype, n, k)
-        for mode in ("plain", "image", "image_scan"):
-            if mode != "plain":
+        for mode in ("plain", "image", "image_scan", "q8"):
+            if mode == "q8":
+                if dtype != "f32" or dim > 1024:
+                    continue
+                ix.enable_batch_image(True, q8=True)
+            elif mode != "plain":
                 ix.enable_batch_image(True, single_query=(mode == "image_scan"))
             rb, cb = ix.search_topk(qs, k)
             for i, (r, c) in enumerate(base):

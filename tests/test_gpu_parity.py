@@ -544,6 +544,45 @@ def test_single_query_nomination_over_the_image_is_exact(rlr, oracle, dim):
         ix.close()
 
 
+@pytest.mark.parametrize("dim", [768, 1024, 64, 400])
+def test_single_query_nomination_over_the_8bit_copy_is_exact(rlr, oracle, dim):
+    """enable_batch_image(q8=True): one byte per element + a per-row scale; the band comes from the stored row error
+    norms (Cauchy-Schwarz), the re-score from the f32 rows -- rows and scores identical to the oracle, including
+    unnormalised queries, NaN rows, mutations; an Inf row switches the index back to the f32 scan"""
+    for n, k in ((4099, 25), (300, 300), (20000, 100)):
+        rows = oracle.synth_rows(n, dim, seed=1900 + dim + n, n_clusters=11)
+        if n == 4099:
+            rows[17, 3] = np.nan
+            rows[18] = 0
+        ix = make_index(rlr, rows)
+        ix.enable_batch_image(False, q8=True)
+        for qi in range(3):
+            qn = oracle.normalize(oracle.synth_query(dim, seed=1950 + dim + qi))
+            if qi == 2:
+                qn = (qn * np.float32(3.5)).astype(np.float32)       # not unit norm: the band scales with ||q||
+            r, c = ix.search_topk(qn, k)
+            wr, wc = oracle_topk(oracle, rows, qn, k)
+            assert np.array_equal(r[0], wr), (dim, n, qi)
+            assert np.array_equal(bits(c[0]), bits(wc)), (dim, n, qi)
+        if n == 4099:
+            extra = oracle.synth_rows(300, dim, seed=177 + dim) * np.float32(2.0)   # longer rows: larger scales / errors
+            ix.append(extra)
+            ix.delete_rows([0, 255, 256, 4100])
+            cur = np.delete(np.concatenate([rows, extra]), [0, 255, 256, 4100], axis=0)
+            qs = np.stack([oracle.normalize(oracle.synth_query(dim, seed=1960 + i)) for i in range(3)])
+            r3, c3 = ix.search_topk(qs, k)
+            for i in range(3):
+                wr, wc = oracle_topk(oracle, cur, qs[i], k)
+                assert np.array_equal(r3[i], wr) and np.array_equal(bits(c3[i]), bits(wc)), (dim, i)
+            cur2 = cur.copy()
+            cur2[5, 0] = np.inf                                     # an Inf row: the index falls back to the f32 scan
+            ix.upload(cur2)
+            r, c = ix.search_topk(qs[0], k)
+            wr, wc = oracle_topk(oracle, cur2, qs[0], k)
+            assert np.array_equal(r[0], wr) and np.array_equal(bits(c[0]), bits(wc))
+        ix.close()
+
+
 def test_merge_topk_kernel_matches_torch_merge_and_global_oracle(rlr, oracle):
     """Four shards searched one after the other on the one GPU, their packed results laid out as an
     all-gather would deliver them, merged by rlr_merge_topk: must equal the global oracle and the
