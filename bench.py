@@ -319,37 +319,45 @@ def main():
     t = pmc_traffic(bytes_per_launch) if not batched else None
     if t:
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t[0], f"profiles/{t[1]} (rocprofv3 --pmc)"
-    # Informational, outside the timed region above: the same workload with the opt-in binary16 nomination image
-    # (identical results, the scan streams half the bytes).  Never the headline `value`.
-    if (world == 1 and not batched and not args.image_scan and not args.q8_scan and not args.no_extras and args.dtype == "f32"
-            and args.dim % 64 == 0 and n_local * args.dim * 2 < 100e9):
-        try:
-            ix.enable_batch_image(True, single_query=True)
-            for i in range(20):
-                step(i % n_q)
-            ix.profile_read(reset=True)
-            ix.profile_enable(True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                alt = step((args.warmup + i) % n_q)
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            ix.profile_enable(False)
-            p2 = ix.profile_read()
-            k_ms = p2.scan_ms / max(p2.n_scan_launches, 1)
-            same = bool(last is not None and np.array_equal(alt[0], last[0]) and
-                        np.array_equal(alt[1].view(np.uint32), last[1].view(np.uint32)))
-            out["optional_modes"] = {"image_scan": {
-                "what": "single queries nominate over the binary16 image (rlr_index_enable_batch_image(idx, 3)); "
-                        "+dim*2 B/row of HBM, results identical",
-                "value": args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
-                "kernel": "scan_image_kernel", "kernel_ms": k_ms, "bytes_per_launch": n_local * args.dim * 2,
-                "achieved_GBps": n_local * args.dim * 2 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
-                "same_result_as_the_f32_scan_on_the_last_query": same}}
+    # Informational, outside the timed region above: the same workload with the opt-in nomination copies (identical
+    # results, the scan streams a half / a quarter of the bytes).  Never the headline `value`.
+    if (world == 1 and not batched and not args.image_scan and not args.q8_scan and not args.no_extras
+            and args.dtype == "f32" and args.dim % 64 == 0 and n_local * args.dim * 3 < 100e9):
+        out["optional_modes"] = {}
+        modes = [("image_scan", dict(on=True, single_query=True), 2, "scan_image_kernel",
+                  "single queries nominate over the binary16 image (rlr_index_enable_batch_image(idx, 3)); "
+                  "+dim*2 B/row of HBM, results identical")]
+        if args.dim <= 1024:
+            modes.append(("q8_scan", dict(on=False, q8=True), 1, "q8_scan_kernel",
+                          "single queries nominate over the 8-bit copy with per-row scales "
+                          "(rlr_index_enable_batch_image(idx, 4)); +dim+4 B/row of HBM, results identical"))
+        for name, kw, eb, kern, what in modes:
+            try:
+                ix.enable_batch_image(**kw)
+                for i in range(20):
+                    step(i % n_q)
+                ix.profile_read(reset=True)
+                ix.profile_enable(True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    alt = step((args.warmup + i) % n_q)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                ix.profile_enable(False)
+                p2 = ix.profile_read()
+                k_ms = p2.scan_ms / max(p2.n_scan_launches, 1)
+                same = bool(last is not None and np.array_equal(alt[0], last[0]) and
+                            np.array_equal(alt[1].view(np.uint32), last[1].view(np.uint32)))
+                out["optional_modes"][name] = {
+                    "what": what, "value": args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
+                    "kernel": kern, "kernel_ms": k_ms, "bytes_per_launch": n_local * args.dim * eb,
+                    "achieved_GBps": n_local * args.dim * eb / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
+                    "candidates_per_query": p2.n_candidates / max(p2.n_searches, 1),
+                    "same_result_as_the_f32_scan_on_the_last_query": same}
+            except Exception as e:  # never let the extra measurement take the headline line down
+                out["optional_modes"][name] = {"error": str(e)}
             ix.enable_batch_image(False)
-        except Exception as e:  # never let the extra measurement take the headline line down
-            out["optional_modes"] = {"image_scan": {"error": str(e)}}
     if world == 1 and not args.no_cpu and O is not None:
         base, sample_rows, want = cpu_baseline(args, rlr)
         out["cpu_baseline"] = base

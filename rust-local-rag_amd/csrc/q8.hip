@@ -16,6 +16,7 @@
 #include "../../include/rlr_gpu.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace rlr {
 
@@ -202,12 +203,24 @@ hipError_t launch_q8_scan(const void *q8, const float *scale, uint32_t n_rows, u
 {
     if (n_rows == 0)
         return hipSuccess;
-    constexpr int R = 8;
-    const uint32_t group = 64;
+    static const int tune = [] {
+        const char *v = getenv("RLR_Q8_VARIANT"); // rows in flight | workgroups per CU << 8 | group rows << 16
+        return v ? static_cast<int>(strtol(v, nullptr, 0)) : 0;
+    }();
+    const int r = (tune & 0xFF) ? (tune & 0xFF) : 8;
+    const uint32_t bpc = ((tune >> 8) & 0xFF) ? ((tune >> 8) & 0xFF) : 8;
+    // 8 rows in flight x 8 workgroups per CU x 32-row groups: 6.13 TB/s at 10 M x 768; 4-16 rows, 4-16 workgroups
+    // and 16/64-row groups measured 5.86-6.13 (scratch/sweep_q8.sh)
+    uint32_t group = ((tune >> 16) & 0xFF) ? ((tune >> 16) & 0xFF) : 32;
+    group = std::max<uint32_t>(static_cast<uint32_t>(r), group / r * r);
     const uint32_t n_groups = (n_rows + group - 1) / group;
-    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_groups + 3) / 4, static_cast<uint32_t>(n_cu) * 8));
-    hipLaunchKernelGGL(q8_scan_kernel<R>, dim3(blocks), dim3(256), 0, s, static_cast<const uint8_t *>(q8), scale, query,
-                       scores, hist, n_rows, dim, group);
+    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_groups + 3) / 4, static_cast<uint32_t>(n_cu) * bpc));
+    const uint8_t *p = static_cast<const uint8_t *>(q8);
+    switch (r) {
+    case 4: hipLaunchKernelGGL(q8_scan_kernel<4>, dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group); break;
+    case 16: hipLaunchKernelGGL(q8_scan_kernel<16>, dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group); break;
+    default: hipLaunchKernelGGL(q8_scan_kernel<8>, dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group); break;
+    }
     return hipGetLastError();
 }
 
