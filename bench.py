@@ -64,11 +64,12 @@ def queries_without_oracle(rlr, dim, n, seed):
     return np.stack([rlr.normalize(rng.standard_normal(dim).astype(np.float32)) for _ in range(n)])
 
 
-def pmc_traffic(bytes_per_launch):
+def pmc_traffic(bytes_per_launch, kernel):
     """HBM bytes per launch of the scan kernel from the committed rocprofv3 --pmc passes of
     this same command (profiles/rNN_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
     separate passes).  PMC counters cannot be read from inside the process, so the figure is
-    quoted from the newest summary whose byte count matches this run's shape; else null."""
+    quoted from the newest summary of the SAME kernel whose byte count matches this run's shape
+    (within 5 %); any other shape -- a shard of an N > 1 run, other dims -- reports null."""
     import glob
 
     best = None
@@ -76,9 +77,10 @@ def pmc_traffic(bytes_per_launch):
         try:
             d = json.load(open(f))
             t = float(d["pmc"]["hbm_bytes_per_launch"])
+            name = str(d.get("kernel", ""))
         except Exception:
             continue
-        if abs(t - bytes_per_launch) <= 0.05 * bytes_per_launch:
+        if kernel in name and abs(t - bytes_per_launch) <= 0.05 * bytes_per_launch:
             best = (t, os.path.basename(f))
     return best
 
@@ -163,6 +165,8 @@ def main():
     rlr = importlib.import_module("rust-local-rag_amd")
     if rlr.device_count() == 0:
         raise SystemExit("bench.py needs a GPU: librlr_gpu.so has no CPU path")
+    if os.environ.get("RLR_BENCH_SHARE_GPU") == "1":
+        local_rank = 0  # rehearsal of the N > 1 code path on a one-GPU box (with RLR_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("RLR_BENCH_FORCE_DIST") == "1"  # rehearse RCCL init + all-gather with one rank
@@ -174,7 +178,11 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RLR_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     sharded = importlib.import_module("rust-local-rag_amd.sharded")
 
     # The oracle is only the checker / reported baseline and only rank 0 of a single-GPU run uses it;
@@ -316,7 +324,7 @@ def main():
         out["roofline"]["kernel"] = "scan_image_kernel"
         out["dtype"] = "f32 rows, binary16 nomination scan over the image + f32 reference-order re-score"
         out["config"]["workload"] += "; single-query nomination over the binary16 image (opt-in, +dim*2 B/row of HBM)"
-    t = pmc_traffic(bytes_per_launch) if not batched else None
+    t = pmc_traffic(bytes_per_launch, out["roofline"]["kernel"]) if not batched else None
     if t:
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t[0], f"profiles/{t[1]} (rocprofv3 --pmc)"
     # Informational, outside the timed region above: the same workload with the opt-in nomination copies (identical
