@@ -763,9 +763,14 @@ bool batch_eligible(const rlr_index *ix, uint32_t nq, uint32_t k)
     // (~3.7 TB/s over the row-major matrix, ~3 TB/s of binary16 over the nomination image) plus
     // ~0.8 ms for the sample, the per-query selects and the finish kernels.
     const double row_bytes = static_cast<double>(ix->n_rows) * ix->dim * (ix->dtype == RLR_F16 ? 2.0 : 4.0);
-    const double t_single = 60e-6 + row_bytes / 6.5e12;
+    // the single-query scan streams the 8-bit copy / the binary16 image when those are switched on
+    const double scan_bytes = static_cast<double>(ix->n_rows) * ix->dim *
+                              (scan_over_q8(ix) ? 1.0 : (scan_over_image(ix) || ix->dtype == RLR_F16) ? 2.0 : 4.0);
+    const double t_single = 60e-6 + scan_bytes / 6.2e12;
     const bool image = ix->image_enabled && ix->d_image;
-    const double pass = image ? static_cast<double>(ix->n_rows) * ix->dim * 2.0 / 3.0e12 : row_bytes / 3.7e12;
+    // (over the image, batches of <= 128 queries take the resident-query kernel: ~5 TB/s of binary16)
+    const double pass = image ? static_cast<double>(ix->n_rows) * ix->dim * 2.0 / (nq <= 128 ? 5.0e12 : 3.0e12)
+                              : row_bytes / 3.7e12;
     const double t_batch = 0.8e-3 + pass * ((nq + 255) / 256);
     return nq * t_single > t_batch;
 }
