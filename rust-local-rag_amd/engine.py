@@ -123,8 +123,16 @@ class SearchRequest:  # mcp_server.rs:17-31
 class RagEngine:
     """Search half of the reference's RagEngine with the embeddings resident on one GPU."""
 
-    def __init__(self, dim: int, dtype: str = "f32", device: int = 0):
+    def __init__(self, dim: int, dtype: str = "f32", device: int = 0, accelerate: Optional[str] = None):
+        """accelerate: None | "image" | "q8" -- keep an optional nomination copy of the rows so the scan streams
+        a half / a quarter of the bytes (GpuIndex.enable_batch_image); results are unchanged"""
         self.index = GpuIndex(dim, dtype, device)
+        if accelerate == "image":
+            self.index.enable_batch_image(True, single_query=True)
+        elif accelerate == "q8":
+            self.index.enable_batch_image(False, q8=True)
+        elif accelerate is not None:
+            raise ValueError("accelerate must be None, 'image' or 'q8'")
         self.lexical = LexicalIndex(device)          # BM25 postings in HBM (rag_engine.rs:112)
         self.dim = dim
         self._chunks: List[DocumentChunk] = []       # row -> chunk

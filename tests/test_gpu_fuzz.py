@@ -82,7 +82,7 @@ def fuzz_engine(budget: float, seed0: int):
     n_cases = 0
     while time.time() < t_end:
         dim = int(rng.choice([64, 256, 384, 768]))
-        eng = rlr.RagEngine(dim)
+        eng = rlr.RagEngine(dim, accelerate=[None, None, "image", "q8"][int(rng.integers(0, 4))])
         texts_of, n_docs = {}, int(rng.integers(1, 6))
         for d in range(n_docs):
             m = int(rng.choice([1, 7, 60, 400]))
