@@ -752,6 +752,12 @@ int32_t big_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint3
 // ---- batched (matrix-core) pipeline ---------------------------------------------------
 constexpr uint32_t kBatchMaxQueries = 1024; // queries per batched pipeline run (bounds the workspace)
 
+bool env_is_one(const char *name)
+{
+    const char *v = getenv(name);
+    return v && v[0] == '1';
+}
+
 bool batch_eligible(const rlr_index *ix, uint32_t nq, uint32_t k)
 {
     if (nq < 2 || ix->dim % 128 != 0 || ix->n_rows < 4096 || k * 8 > batch_finish_capacity())
@@ -771,6 +777,10 @@ bool batch_eligible(const rlr_index *ix, uint32_t nq, uint32_t k)
     // (over the image, batches of <= 128 queries take the resident-query kernel: ~5 TB/s of binary16)
     const double pass = image ? static_cast<double>(ix->n_rows) * ix->dim * 2.0 / (nq <= 128 ? 5.0e12 : 3.0e12)
                               : row_bytes / 3.7e12;
+    const bool multi = nq <= 8 && ix->dtype == RLR_F32 && ix->pitch16 % 64 == 0 && ix->pitch16 / 64 <= 4 &&
+                       ix->pitch16 * 4 == ix->dim && !image;
+    if (multi) // one VALU pass for all of them + the per-query selects over the materialised scores
+        return nq * t_single > 0.3e-3 + row_bytes / 5.5e12 + nq * (static_cast<double>(ix->n_rows) * 12.0 / 3.0e12);
     const double t_batch = 0.8e-3 + pass * ((nq + 255) / 256);
     return nq * t_single > t_batch;
 }
@@ -785,14 +795,18 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     const uint32_t n = static_cast<uint32_t>(ix->n_rows);
     const uint32_t fin_cap = batch_finish_capacity();
     const uint32_t n_qblocks = (nq + 255) / 256;
-    const float eps_nom = nomination_eps(ix->dim, ix->dtype);
+    // 2..8 queries over f32 rows: one VALU pass over the rows for all of them (scan_multi_kernel) instead of the
+    // matrix-core pipeline -- about the cost of a single scan, scores in wavefront order (the tight f32 band)
+    const bool use_multi = nq <= 8 && ix->dtype == RLR_F32 && ix->pitch16 % 64 == 0 && ix->pitch16 / 64 <= 4 &&
+                           ix->pitch16 * 4 == ix->dim && !(ix->image_enabled && ix->d_image) && !env_is_one("RLR_NO_MULTI_SCAN");
+    const float eps_nom = use_multi ? 0.5f * p.two_eps : nomination_eps(ix->dim, ix->dtype);
     const float two_eps = 2.0f * eps_nom;
     // sample rows [0, S): large enough that the expected number of later rows above the sample's
     // k-th score (k * N / S) stays well inside the per-query candidate capacity.
     uint64_t S = (static_cast<uint64_t>(p.k) * n * 5 / 2 + fin_cap - 1) / fin_cap;
     S = std::max<uint64_t>(S, std::min<uint64_t>(n, 65536));
     S = (S + 255) / 256 * 256;
-    if (S * 2 >= n)
+    if (S * 2 >= n || use_multi)
         S = n;
     // Bootstrap: materialising and radix-selecting S rows per query costs 4 passes over nq x S floats
     // (2.4 GB for 1024 queries x 587 k rows).  When S is large, only a quarter of it (S1) goes that way;
@@ -849,10 +863,28 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     const bool use_image = ix->image_enabled && ix->d_image && (ix->dim / 64) % 4 == 0;
     const void *image = use_image ? ix->d_image : nullptr;
     // the image stores k in natural order (like binary16 rows); only the direct f32-row loads permute it
-    RLR_HIP(launch_prep_queries(dq, nq, ix->q_pitch, ix->dim, use_image ? static_cast<int>(RLR_F16) : ix->dtype, c->d_qfrag, s));
-    // 1. nominated scores of the sample rows, materialised
-    RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, 0, static_cast<uint32_t>(S), c->d_qfrag, nq,
-                                 nullptr, nullptr, 0, nullptr, c->d_sample, s_stride, image, s));
+    if (use_multi) {
+        ScanArgs sa;
+        sa.rows = ix->d_rows;
+        sa.query = dq;
+        sa.scores = c->d_sample;
+        sa.hist = nullptr;
+        sa.n_rows = n;
+        sa.dim = ix->dim;
+        sa.pitch16 = ix->pitch16;
+        sa.dtype = ix->dtype;
+        sa.n_cu = ix->n_cu;
+        sa.variant = ix->scan_variant;
+        hipError_t e = hipSuccess;
+        if (!launch_scan_multi(sa, ix->q_pitch, nq, s_stride, s, &e))
+            return fail(RLR_E_INTERNAL, "multi-query scan refused a shape its gate accepted");
+        RLR_HIP(e);
+    } else {
+        RLR_HIP(launch_prep_queries(dq, nq, ix->q_pitch, ix->dim, use_image ? static_cast<int>(RLR_F16) : ix->dtype, c->d_qfrag, s));
+        // 1. nominated scores of the sample rows, materialised
+        RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, 0, static_cast<uint32_t>(S), c->d_qfrag, nq,
+                                     nullptr, nullptr, 0, nullptr, c->d_sample, s_stride, image, s));
+    }
     if (timed) RLR_HIP(hipEventRecord(c->bev[1], s));
     // 2. per-query k-th score of the sample -> threshold; the sample's own candidates
     RLR_HIP(launch_batch_select(c->d_sample, static_cast<uint32_t>(S), s_stride, nq, c->d_bhist, c->d_bstate, two_eps,

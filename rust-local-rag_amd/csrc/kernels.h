@@ -24,6 +24,10 @@ struct ScanArgs {
     int variant;          // tuning knob, 0 = default
 };
 hipError_t launch_scan(const ScanArgs &a, hipStream_t stream);
+// one pass over the rows for 2..8 queries (a.query = n_queries x q_pitch floats, a.scores = n_queries x score_stride);
+// false when the shape is not served (then nothing was launched)
+bool launch_scan_multi(const ScanArgs &a, uint32_t q_pitch, uint32_t n_queries, size_t score_stride, hipStream_t s,
+                       hipError_t *err);
 
 // ---- select.hip : radix select / collect / sort -------------------------
 // Selection state kept on the device between the stages of one query.

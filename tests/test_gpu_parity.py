@@ -583,6 +583,31 @@ def test_single_query_nomination_over_the_8bit_copy_is_exact(rlr, oracle, dim):
         ix.close()
 
 
+@pytest.mark.parametrize("dim,nq", [(768, 2), (768, 8), (1024, 3), (256, 5), (512, 7)])
+def test_small_batches_share_one_scan(rlr, oracle, monkeypatch, dim, nq):
+    """2..8 queries over f32 rows: scan_multi_kernel reads the rows once for all of them, the batched select and
+    finish follow; rows with duplicates / zeros / NaN included"""
+    monkeypatch.setenv("RLR_BATCH_MIN", "2")          # take the batched pipeline whatever the cost model says
+    n, k = 30_011, 40
+    rows = oracle.synth_rows(n, dim, seed=3300 + dim + nq, n_clusters=9)
+    rows[5] = rows[3]
+    rows[n - 1] = rows[3]
+    rows[7] = 0
+    rows[9, 0] = np.nan
+    ix = make_index(rlr, rows)
+    qs = np.stack([oracle.normalize(oracle.synth_query(dim, seed=3350 + i)) for i in range(nq)])
+    qs[0] = oracle.normalize(rows[3].copy())
+    ix.profile_read(reset=True)
+    r, c = ix.search_topk(qs, k)
+    prof = ix.profile_read()
+    assert prof.n_batches == 1 and prof.n_batch_fallbacks == 0
+    for i in range(nq):
+        wr, wc = oracle_topk(oracle, rows, qs[i], k)
+        assert np.array_equal(r[i], wr), (dim, nq, i)
+        assert np.array_equal(bits(c[i]), bits(wc)), (dim, nq, i)
+    ix.close()
+
+
 def test_merge_topk_kernel_matches_torch_merge_and_global_oracle(rlr, oracle):
     """Four shards searched one after the other on the one GPU, their packed results laid out as an
     all-gather would deliver them, merged by rlr_merge_topk: must equal the global oracle and the
