@@ -474,9 +474,11 @@ def test_batched_mfma_sample_then_filter(rlr, oracle):
     ix.fill_synthetic(n, seed=112)
     prof = _check_batch(rlr, oracle, ix, rows, qs, 100)
     assert prof.n_batches == 1 and prof.n_batch_fallbacks == 0
-    # cost model: at 200 k rows four single scans are cheaper than one GEMM pass, eight are not
-    assert _check_batch(rlr, oracle, ix, rows, qs[:4], 100).n_batches == 0
-    assert _check_batch(rlr, oracle, ix, rows, qs[:8], 100).n_batches == 1
+    # cost model at 200 k rows: two single scans are cheaper than any batched pipeline; four share one scan
+    # (scan_multi_kernel); nine are past the shared scan's eight and worth a GEMM pass
+    assert _check_batch(rlr, oracle, ix, rows, qs[:2], 100).n_batches == 0
+    assert _check_batch(rlr, oracle, ix, rows, qs[:4], 100).n_batches == 1
+    assert _check_batch(rlr, oracle, ix, rows, qs[:9], 100).n_batches == 1
     ix.close()
 
 
