@@ -224,9 +224,15 @@ def main():
     # kernel launches) into a process, which stalls that one call for 30-40 ms (measured with
     # scratch/step_jitter.py: call 206 at every corpus size, never again afterwards).
     t_settle, n_settle = time.perf_counter(), 0
-    while args.settle_ms > 0 and ((time.perf_counter() - t_settle) * 1e3 < args.settle_ms or n_settle < 256):
-        step(0)
-        n_settle += 1
+    if dist:
+        # every step holds a collective: all ranks must run the SAME number of settle steps, so the count cannot
+        # depend on a local clock
+        for _ in range(768 if args.settle_ms > 0 else 0):
+            step(0)
+    else:
+        while args.settle_ms > 0 and ((time.perf_counter() - t_settle) * 1e3 < args.settle_ms or n_settle < 256):
+            step(0)
+            n_settle += 1
     for i in range(args.warmup):
         step(i)
 
