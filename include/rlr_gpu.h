@@ -124,9 +124,10 @@ int32_t rlr_index_enable_batch_image(rlr_index *idx, int32_t enable);
  * nominates candidates (everything within the guard band of the k-th score); the
  * nominated rows are re-scored on the GPU in strict reference order before the final
  * ordering, so the band never leaks into the result.
- * Batches on dims that are a multiple of 128 take the matrix-core path when a cost model of the two
- * pipelines says one GEMM pass is cheaper than n_queries single scans (from 2 queries at 10 M rows,
- * from ~13 at a few thousand rows; RLR_BATCH_MIN=n forces a threshold): Q x Corpus^T by v_mfma_f32_16x16x32_f16 on binary16-rounded operands nominates
+ * Batches on dims that are a multiple of 128 take a batched pipeline when a cost model says it is cheaper
+ * than n_queries single scans (from 2 queries at 10 M rows, from ~13 at a few thousand rows; RLR_BATCH_MIN=n
+ * forces a threshold).  2..8 queries over f32 rows share ONE wavefront-order pass over the rows
+ * (scan_multi_kernel); larger batches take the matrix-core path: Q x Corpus^T by v_mfma_f32_16x16x32_f16 on binary16-rounded operands nominates
  * candidates (rigorous band), the same reference-order re-score finishes; the
  * results are identical to looping single queries. */
 int32_t rlr_search_topk(rlr_index *idx, const float *queries, uint32_t n_queries, uint32_t k,
