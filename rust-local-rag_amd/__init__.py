@@ -14,8 +14,8 @@ from .engine import (DocumentChunk, QueryWeights, RagEngine, ResolvedWeights, Se
                      format_search_results, normalize, resolve_weight)
 from .index import GpuIndex, MultiGpuIndex, Profile, default_guard_eps, device_count
 from .lexical import LexicalIndex, tokenize
-from .persistence import (LoadReport, get_index_path, get_legacy_path, load_from_disk, sanitize_model_name,
-                          save_to_disk)
+from .persistence import (LoadReport, get_index_path, get_legacy_path, get_sidecar_path, load_from_disk,
+                          sanitize_model_name, save_sidecar, save_to_disk)
 
 lib()  # fail loudly at import time when librlr_gpu.so is missing
 
@@ -23,6 +23,6 @@ __all__ = [
     "DEFAULT_DIVERSITY", "DEFAULT_TOP_K", "MAX_TOP_K", "RLR_F16", "RLR_F32", "RlrError", "SO_PATH", "lib",
     "DocumentChunk", "QueryWeights", "RagEngine", "ResolvedWeights", "SearchRequest", "SearchResult",
     "format_search_results", "normalize", "resolve_weight", "GpuIndex", "MultiGpuIndex", "Profile", "default_guard_eps",
-    "device_count", "LexicalIndex", "tokenize", "LoadReport", "get_index_path", "get_legacy_path", "load_from_disk", "sanitize_model_name",
-    "save_to_disk",
+    "device_count", "LexicalIndex", "tokenize", "LoadReport", "get_index_path", "get_legacy_path", "get_sidecar_path",
+    "load_from_disk", "sanitize_model_name", "save_sidecar", "save_to_disk",
 ]

@@ -142,10 +142,87 @@ def _apply_loaded_state(engine: RagEngine, state: dict, source: str, data_dir: s
     return rep
 
 
-def load_from_disk(engine: RagEngine, data_dir: str, model_name: str) -> LoadReport:
-    """rag_engine.rs:1520-1653"""
+# ---- binary side-car cache ("and a binary side-car cache") ---------------------------------------
+# Parsing the pretty-printed `Vec<f32>` of a large corpus dominates start-up.  After a successful load the rows the
+# device holds (i.e. AFTER the load-time re-normalisation) can be written next to the JSON as raw binary32 plus the
+# chunk metadata; the next load of the SAME file (size + mtime_ns recorded in the header) uploads them as they are
+# and never touches the embedding arrays.  Any mismatch -- other size / mtime / model / dim / version -- ignores the
+# cache.  The JSON stays the source of truth; the cache is disposable.
+SIDECAR_MAGIC = b"RLRCACHE1\n"
+
+
+def get_sidecar_path(data_dir: str, model_name: str) -> str:
+    return os.path.join(data_dir, f"chunks_{sanitize_model_name(model_name)}.rlrcache")
+
+
+def _file_identity(path: str) -> Dict[str, int]:
+    st = os.stat(path)
+    return {"size": int(st.st_size), "mtime_ns": int(st.st_mtime_ns)}
+
+
+def save_sidecar(engine: RagEngine, data_dir: str, model_name: str, report: "LoadReport") -> str:
+    """Write the cache for the state just loaded from / saved to `get_index_path(data_dir, model_name)`."""
+    src = get_index_path(data_dir, model_name)
+    n = len(engine)
+    rows = engine.index.fetch_rows(np.arange(n, dtype=np.uint64)) if n else np.zeros((0, engine.dim), np.float32)
+    header = {"model": model_name, "dim": engine.dim, "n": n, "source": _file_identity(src),
+              "needs_reindex": bool(report.needs_reindex), "document_hashes": report.document_hashes,
+              "chunks": [[ch.id, ch.document_name, ch.text, ch.chunk_index, ch.page_number, ch.section]
+                         for ch in engine._chunks]}
+    blob = json.dumps(header, ensure_ascii=False).encode("utf-8")
+    path = get_sidecar_path(data_dir, model_name)
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(SIDECAR_MAGIC)
+        f.write(len(blob).to_bytes(8, "little"))
+        f.write(blob)
+        f.write(np.ascontiguousarray(rows, dtype="<f4").tobytes())
+    os.replace(tmp, path)
+    return path
+
+
+def _load_sidecar(engine: RagEngine, data_dir: str, model_name: str) -> Optional[LoadReport]:
+    path, src = get_sidecar_path(data_dir, model_name), get_index_path(data_dir, model_name)
+    if not (os.path.exists(path) and os.path.exists(src)):
+        return None
+    try:
+        with open(path, "rb") as f:
+            if f.read(len(SIDECAR_MAGIC)) != SIDECAR_MAGIC:
+                return None
+            hlen = int.from_bytes(f.read(8), "little")
+            header = json.loads(f.read(hlen).decode("utf-8"))
+            if (header.get("model") != model_name or header.get("dim") != engine.dim
+                    or header.get("source") != _file_identity(src)):
+                return None
+            n = int(header["n"])
+            rows = np.frombuffer(f.read(n * engine.dim * 4), dtype="<f4")
+            if rows.size != n * engine.dim or len(header["chunks"]) != n:
+                return None
+    except (OSError, ValueError, KeyError):
+        return None
+    engine.index.upload(rows.reshape(n, engine.dim), normalize=False)   # already the post-load rows
+    engine._chunks = [DocumentChunk(*c) for c in header["chunks"]]
+    engine._row_of = {ch.id: r for r, ch in enumerate(engine._chunks)}
+    engine.lexical.clear()
+    for r, ch in enumerate(engine._chunks):
+        engine.lexical.add_chunk(r, ch.text)
+    return LoadReport(source=path, n_chunks=n, needs_reindex=bool(header.get("needs_reindex", False)),
+                      document_hashes=dict(header.get("document_hashes", {})))
+
+
+def load_from_disk(engine: RagEngine, data_dir: str, model_name: str, use_sidecar: bool = False) -> LoadReport:
+    """rag_engine.rs:1520-1653.  use_sidecar: take the binary cache when it matches the JSON file, and (re)write it
+    after a JSON load."""
     model_path = get_index_path(data_dir, model_name)
     legacy_path = get_legacy_path(data_dir)
+    if use_sidecar:
+        rep = _load_sidecar(engine, data_dir, model_name)
+        if rep is not None:
+            return rep
+        rep = load_from_disk(engine, data_dir, model_name, use_sidecar=False)
+        if rep.source == model_path and os.path.exists(model_path):
+            save_sidecar(engine, data_dir, model_name, rep)
+        return rep
     if os.path.exists(model_path):
         try:
             with open(model_path, encoding="utf-8") as f:

@@ -66,6 +66,43 @@ def test_load_renormalises_on_device_and_round_trips(rlr, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_sidecar_cache_gives_the_same_engine_and_detects_a_changed_file(rlr, oracle, tmp_path):
+    dim, n, model = 256, 120, "cache-model"
+    raw = (np.random.default_rng(5).standard_normal((n, dim)) * 3).astype(np.float32)
+    chunks = {f"c{i}": _chunk(f"c{i}", f"d{i % 3}.pdf", raw[i], i, page=1 + i % 7) for i in range(n)}
+    src = rlr.get_index_path(str(tmp_path), model)
+    _write(src, {"version": 2, "model": model, "chunks": chunks, "needs_reindex": False,
+                 "document_hashes": {"d0.pdf": "a", "d1.pdf": "b", "d2.pdf": "c"}})
+    a = rlr.RagEngine(dim)
+    rep_a = rlr.load_from_disk(a, str(tmp_path), model, use_sidecar=True)          # JSON load, cache written
+    cache = rlr.get_sidecar_path(str(tmp_path), model)
+    assert rep_a.source == src and os.path.exists(cache)
+    b = rlr.RagEngine(dim)
+    rep_b = rlr.load_from_disk(b, str(tmp_path), model, use_sidecar=True)          # served by the cache
+    assert rep_b.source == cache and rep_b.n_chunks == n and rep_b.document_hashes == rep_a.document_hashes
+    assert np.array_equal(bits(a.index.fetch_rows(np.arange(n))), bits(b.index.fetch_rows(np.arange(n))))
+    q = oracle.synth_query(dim, seed=3)
+    ra, rb = a.search(q, 7, query_text="text c5"), b.search(q, 7, query_text="text c5")
+    assert [(x.chunk_id, x.page_number, x.document) for x in ra] == [(x.chunk_id, x.page_number, x.document) for x in rb]
+    assert np.array_equal(bits([x.score for x in ra]), bits([x.score for x in rb]))
+    # a changed JSON (other size / mtime) invalidates the cache: the loader goes back to the file and rewrites it
+    chunks["c0"]["embedding"] = [float(x) for x in raw[1]]
+    _write(src, {"version": 2, "model": model, "chunks": chunks, "needs_reindex": False, "document_hashes": {"d0.pdf": "a"}})
+    os.utime(src, ns=(1, 1))                                                       # even with an OLDER timestamp
+    c = rlr.RagEngine(dim)
+    rep_c = rlr.load_from_disk(c, str(tmp_path), model, use_sidecar=True)
+    assert rep_c.source == src
+    assert np.array_equal(bits(c.index.fetch_rows([0])), bits(c.index.fetch_rows([1])))
+    # a truncated cache is ignored, not trusted
+    with open(cache, "r+b") as f:
+        f.truncate(100)
+    d = rlr.RagEngine(dim)
+    assert rlr.load_from_disk(d, str(tmp_path), model, use_sidecar=True).source == src
+    for e in (a, b, c, d):
+        e.close()
+
+
+@pytest.mark.gpu
 def test_load_version1_clears_and_marks_reindex(rlr, tmp_path):
     model = "m"
     _write(rlr.get_index_path(str(tmp_path), model),
