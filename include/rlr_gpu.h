@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RLR_VERSION 100 /* 0.1.0 */
+#define RLR_VERSION 120 /* 0.1.20: + lexical, sharded begin/end + MMR exchange, nomination copies, shared small-batch scan */
 
 typedef struct rlr_index rlr_index;
 
