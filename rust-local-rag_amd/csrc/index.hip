@@ -332,7 +332,7 @@ int32_t sync_q8(rlr_index *ix, uint64_t first_row)
         RLR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_q8_stats), 4 * sizeof(uint32_t)));
     if (first_row == 0)
         RLR_HIP(hipMemset(ix->d_q8_stats, 0, 4 * sizeof(uint32_t)));
-    RLR_HIP(launch_q8_build(ix->d_rows, ix->pitch16, ix->dim, static_cast<uint32_t>(first_row),
+    RLR_HIP(launch_q8_build(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, static_cast<uint32_t>(first_row),
                             static_cast<uint32_t>(ix->n_rows), ix->d_q8, ix->d_q8_scale, ix->d_q8_stats, nullptr));
     uint32_t h[4] = {0, 0, 0, 0};
     RLR_HIP(hipMemcpy(h, ix->d_q8_stats, sizeof(h), hipMemcpyDeviceToHost));
@@ -617,7 +617,7 @@ void stage_query_norms(const rlr_index *ix, Ctx *c, const float *queries, uint32
 // f32 rows with an up-to-date 8-bit copy: the nomination scan reads one byte per element
 bool scan_over_q8(const rlr_index *ix)
 {
-    return ix->q8_enabled && ix->d_q8 && !ix->q8_has_inf && ix->dtype == RLR_F32;
+    return ix->q8_enabled && ix->d_q8 && !ix->q8_has_inf;
 }
 
 // band for 8-bit-nominated scores of a query of norm q_norm (Cauchy-Schwarz on the stored row error norms)
@@ -1326,9 +1326,8 @@ int32_t rlr_index_enable_batch_image(rlr_index *ix, int32_t enable)
         ix->image_cap = 0;
     }
     if (want_q8 && !ix->q8_enabled) {
-        if (ix->dtype != RLR_F32 || ix->dim % 16 != 0 || ix->dim > 1024)
-            return fail(RLR_E_INVALID, "the 8-bit nomination copy needs f32 rows and dim %% 16 == 0, dim <= 1024 (dim = %u)",
-                        ix->dim);
+        if (ix->dim % 16 != 0 || ix->dim > 1024)
+            return fail(RLR_E_INVALID, "the 8-bit nomination copy needs dim %% 16 == 0, dim <= 1024 (dim = %u)", ix->dim);
         ix->q8_enabled = true;
         RLR_TRY(sync_q8(ix, 0));
     }

@@ -125,8 +125,8 @@ hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P,
                              const uint32_t *sizes, uint32_t n_queries, hipStream_t s);
 
 // ---- q8.hip : optional 8-bit nomination copy of f32 rows (single-query scans at a quarter of the bytes) ----
-hipError_t launch_q8_build(const void *rows, uint32_t pitch16, uint32_t dim, uint32_t row_begin, uint32_t n_rows, void *q8,
-                           float *scale, uint32_t *stats, hipStream_t s);
+hipError_t launch_q8_build(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin, uint32_t n_rows,
+                           void *q8, float *scale, uint32_t *stats, hipStream_t s);
 hipError_t launch_q8_scan(const void *q8, const float *scale, uint32_t n_rows, uint32_t dim, const float *query,
                           float *scores, uint32_t *hist, int n_cu, hipStream_t s);
 float q8_arith_eps(uint32_t dim, float scale_max, float q_norm);

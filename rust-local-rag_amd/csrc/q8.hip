@@ -1,4 +1,4 @@
-// q8.hip -- optional 8-bit nomination copy of f32 rows for single-query scans.
+// q8.hip -- optional 8-bit nomination copy of the rows (f32 or binary16) for single-query scans.
 //
 // The scan of scan.hip only NOMINATES candidates; the reference-order re-score of exact.hip makes the
 // result exact.  So the scan may read any approximation of the rows whose error is BOUNDED: here one byte per
@@ -41,7 +41,8 @@ __device__ inline float wave_add_all(float v)
 }
 
 // one wavefront per row: scale, bytes, exact quantisation error norm
-__global__ __launch_bounds__(256) void q8_build_kernel(const float *__restrict__ rows, uint32_t pitch_floats, uint32_t dim,
+template <bool F16>
+__global__ __launch_bounds__(256) void q8_build_kernel(const void *__restrict__ rows, uint32_t pitch_bytes, uint32_t dim,
                                                        uint32_t row_begin, uint32_t n_rows, uint8_t *__restrict__ q8,
                                                        float *__restrict__ scale, uint32_t *__restrict__ stats)
 {
@@ -49,11 +50,17 @@ __global__ __launch_bounds__(256) void q8_build_kernel(const float *__restrict__
     const uint32_t row = row_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows)
         return;
-    const float *x = rows + static_cast<size_t>(row) * pitch_floats;
+    const unsigned char *rowp = static_cast<const unsigned char *>(rows) + static_cast<size_t>(row) * pitch_bytes;
+    auto elem = [&](uint32_t e) -> float {
+        if constexpr (F16)
+            return h2f(reinterpret_cast<const uint16_t *>(rowp)[e]);
+        else
+            return reinterpret_cast<const float *>(rowp)[e];
+    };
     float m = 0.0f;
     bool has_nan = false, has_inf = false;
     for (uint32_t e = lane; e < dim; e += 64) {
-        const float v = x[e];
+        const float v = elem(e);
         has_nan |= v != v;
         has_inf |= __builtin_fabsf(v) > 3.4028234e38f;
         m = fmaxf(m, __builtin_fabsf(v));
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(256) void q8_build_kernel(const float *__restrict__
     float err2 = 0.0f;
     uint8_t *out = q8 + static_cast<size_t>(row) * dim;
     for (uint32_t e = lane; e < dim; e += 64) {
-        const float v = bad ? 0.0f : x[e];
+        const float v = bad ? 0.0f : elem(e);
         float k = __builtin_rintf(v / s);
         k = fminf(fmaxf(k, -127.0f), 127.0f);
         const float d = v - s * k;
@@ -187,14 +194,18 @@ __global__ __launch_bounds__(256) void q8_scan_kernel(const uint8_t *__restrict_
 
 } // namespace
 
-hipError_t launch_q8_build(const void *rows, uint32_t pitch16, uint32_t dim, uint32_t row_begin, uint32_t n_rows, void *q8,
-                           float *scale, uint32_t *stats, hipStream_t s)
+hipError_t launch_q8_build(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin, uint32_t n_rows,
+                           void *q8, float *scale, uint32_t *stats, hipStream_t s)
 {
     if (row_begin >= n_rows)
         return hipSuccess;
     const uint32_t blocks = (n_rows - row_begin + 3) / 4;
-    hipLaunchKernelGGL(q8_build_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float *>(rows), pitch16 * 4, dim,
-                       row_begin, n_rows, static_cast<uint8_t *>(q8), scale, stats);
+    if (dtype == RLR_F16)
+        hipLaunchKernelGGL(q8_build_kernel<true>, dim3(blocks), dim3(256), 0, s, rows, pitch16 * 16, dim, row_begin, n_rows,
+                           static_cast<uint8_t *>(q8), scale, stats);
+    else
+        hipLaunchKernelGGL(q8_build_kernel<false>, dim3(blocks), dim3(256), 0, s, rows, pitch16 * 16, dim, row_begin, n_rows,
+                           static_cast<uint8_t *>(q8), scale, stats);
     return hipGetLastError();
 }
 

@@ -610,6 +610,21 @@ def test_small_batches_share_one_scan(rlr, oracle, monkeypatch, dim, nq):
     ix.close()
 
 
+@pytest.mark.parametrize("dim", [1024, 768])
+def test_8bit_copy_over_binary16_rows(rlr, oracle, dim):
+    """the 8-bit nomination copy also serves f16-typed indexes (half of their scan bytes)"""
+    n, k = 9001, 60
+    rows = oracle.synth_rows(n, dim, seed=4100 + dim, n_clusters=7, f16=True)
+    ix = make_index(rlr, rows, dtype="f16")
+    ix.enable_batch_image(False, q8=True)
+    for qi in range(3):
+        qn = oracle.normalize(oracle.synth_query(dim, seed=4150 + qi))
+        r, c = ix.search_topk(qn, k)
+        wr, wc = oracle_topk(oracle, rows, qn, k)
+        assert np.array_equal(r[0], wr) and np.array_equal(bits(c[0]), bits(wc)), (dim, qi)
+    ix.close()
+
+
 def test_merge_topk_kernel_matches_torch_merge_and_global_oracle(rlr, oracle):
     """Four shards searched one after the other on the one GPU, their packed results laid out as an
     all-gather would deliver them, merged by rlr_merge_topk: must equal the global oracle and the
