@@ -341,7 +341,7 @@ def main():
         modes = [("image_scan", dict(on=True, single_query=True), 2, "scan_image_kernel",
                   "single queries nominate over the binary16 image (rlr_index_enable_batch_image(idx, 3)); "
                   "+dim*2 B/row of HBM, results identical")]
-        if args.dim <= 1024:
+        if args.dim <= 2048:
             modes.append(("q8_scan", dict(on=False, q8=True), 1, "q8_scan_kernel",
                           "single queries nominate over the 8-bit copy with per-row scales "
                           "(rlr_index_enable_batch_image(idx, 4)); +dim+4 B/row of HBM, results identical"))

@@ -104,7 +104,7 @@ int32_t rlr_index_fill_synthetic(rlr_index *idx, uint64_t n_rows, uint64_t row0,
  * enable bit 2 (value 4, alone or with the others) keeps an 8-bit copy with per-row scales for single
  * queries instead: dim + 4 bytes per row, a quarter of the scan bytes (10 M x 768: 1.4 ms per query); the
  * band comes from the exact per-row quantisation error norms kept at build time (Cauchy-Schwarz), so the
- * results are still identical.  dim % 16 == 0, dim <= 1024 (f32 or binary16 rows). */
+ * results are still identical.  dim % 16 == 0, dim <= 2048 (f32 or binary16 rows). */
 int32_t rlr_index_enable_batch_image(rlr_index *idx, int32_t enable);
 
 /* ---- the hot path ------------------------------------------------------- */

@@ -1326,8 +1326,8 @@ int32_t rlr_index_enable_batch_image(rlr_index *ix, int32_t enable)
         ix->image_cap = 0;
     }
     if (want_q8 && !ix->q8_enabled) {
-        if (ix->dim % 16 != 0 || ix->dim > 1024)
-            return fail(RLR_E_INVALID, "the 8-bit nomination copy needs dim %% 16 == 0, dim <= 1024 (dim = %u)", ix->dim);
+        if (ix->dim % 16 != 0 || ix->dim > 2048)
+            return fail(RLR_E_INVALID, "the 8-bit nomination copy needs dim %% 16 == 0, dim <= 2048 (dim = %u)", ix->dim);
         ix->q8_enabled = true;
         RLR_TRY(sync_q8(ix, 0));
     }

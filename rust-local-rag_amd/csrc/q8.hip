@@ -125,9 +125,9 @@ __device__ inline float dot16_u8(u32x4 x, const float (&q)[16], float acc)
     return acc;
 }
 
-// dim <= 1024, dim % 16 == 0: a row is one 16-byte load per lane (lanes >= dim/16 idle), the lane's 16 query
+// dim <= 2048, dim % 16 == 0: a row is one (two above 1024-d) 16-byte load per lane (lanes >= dim/16 idle), the lane's query
 // values live in registers.  R rows in flight per wave, groups of <= 64 rows, scores parked per lane as in scan.hip.
-template <int R>
+template <int R, int L>
 __global__ __launch_bounds__(256) void q8_scan_kernel(const uint8_t *__restrict__ q8, const float *__restrict__ scale,
                                                       const float *__restrict__ query, float *__restrict__ scores,
                                                       uint32_t *__restrict__ g_hist, uint32_t n_rows, uint32_t dim,
@@ -140,15 +140,19 @@ __global__ __launch_bounds__(256) void q8_scan_kernel(const uint8_t *__restrict_
     for (int i = tid; i < kHistBins; i += 256)
         s_hist[i] = 0;
     const uint32_t p16 = dim / 16;
-    const bool active = static_cast<uint32_t>(lane) < p16;
-    float qv[16];
+    bool active[L];
+    float qv[L][16];
     float qs = 0.0f;
 #pragma unroll
-    for (int b = 0; b < 16; ++b) {
-        qv[b] = active ? query[lane * 16 + b] : 0.0f;
-        qs += qv[b];
+    for (int l = 0; l < L; ++l) {
+        active[l] = static_cast<uint32_t>(lane + 64 * l) < p16;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            qv[l][b] = active[l] ? query[(lane + 64 * l) * 16 + b] : 0.0f;
+            qs += qv[l][b];
+        }
     }
-    const float bias = 128.0f * qs; // the bytes are biased by 128: subtract 128 * (this lane's query slice sum)
+    const float bias = 128.0f * qs; // the bytes are biased by 128: subtract 128 * (this lane's query slice sums)
     __syncthreads();
 
     const uint32_t n_groups = (n_rows + group_rows - 1) / group_rows;
@@ -158,18 +162,24 @@ __global__ __launch_bounds__(256) void q8_scan_kernel(const uint8_t *__restrict_
         const uint32_t nr = min(group_rows, n_rows - row0);
         float mine = 0.0f;
         for (uint32_t r = 0; r < nr; r += R) {
-            u32x4 x[R];
+            u32x4 x[R][L];
             float sc[R];
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
                 const uint32_t row = min(row0 + r + rr, row0 + nr - 1);
                 const u32x4 *p = reinterpret_cast<const u32x4 *>(q8 + static_cast<size_t>(row) * dim) + lane;
-                x[rr] = active ? __builtin_nontemporal_load(p) : u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+                    x[rr][l] = active[l] ? __builtin_nontemporal_load(p + 64 * l)
+                                         : u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
                 sc[rr] = scale[row];
             }
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
-                const float acc = dot16_u8(x[rr], qv, 0.0f) - bias;
+                float acc = -bias;
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+                    acc = dot16_u8(x[rr][l], qv[l], acc);
                 const float tot = wave_sum(acc);
                 const float v = sc[rr] * tot;
                 if (static_cast<uint32_t>(lane) == r + rr)
@@ -227,10 +237,14 @@ hipError_t launch_q8_scan(const void *q8, const float *scale, uint32_t n_rows, u
     const uint32_t n_groups = (n_rows + group - 1) / group;
     const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_groups + 3) / 4, static_cast<uint32_t>(n_cu) * bpc));
     const uint8_t *p = static_cast<const uint8_t *>(q8);
+    if (dim > 1024) { // two 16-byte loads per lane per row (dim <= 2048)
+        hipLaunchKernelGGL((q8_scan_kernel<4, 2>), dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group);
+        return hipGetLastError();
+    }
     switch (r) {
-    case 4: hipLaunchKernelGGL(q8_scan_kernel<4>, dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group); break;
-    case 16: hipLaunchKernelGGL(q8_scan_kernel<16>, dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group); break;
-    default: hipLaunchKernelGGL(q8_scan_kernel<8>, dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group); break;
+    case 4: hipLaunchKernelGGL((q8_scan_kernel<4, 1>), dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group); break;
+    case 16: hipLaunchKernelGGL((q8_scan_kernel<16, 1>), dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group); break;
+    default: hipLaunchKernelGGL((q8_scan_kernel<8, 1>), dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group); break;
     }
     return hipGetLastError();
 }

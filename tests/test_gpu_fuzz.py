@@ -44,7 +44,7 @@ def fuzz(budget: float, seed0: int):
         ix = rlr.GpuIndex(dim, dtype); ix.upload(rows)
         mode = str(rng.choice(["plain", "image", "image_scan", "q8"])) if dim % 64 == 0 else "plain"
         if mode == "q8":
-            if dim <= 1024: ix.enable_batch_image(False, q8=True)
+            if dim <= 2048 and dim % 16 == 0: ix.enable_batch_image(False, q8=True)
         elif mode != "plain": ix.enable_batch_image(True, single_query=(mode == "image_scan"))
         nq = int(rng.choice([1, 1, 2, 5, 20, 40]))
         k = int(min(rng.choice([1, 5, 10, 100, 300, 1000]), max(n, 1) + 3))
@@ -289,7 +289,7 @@ def fuzz_scale(budget: float, seed0: int):
             assert sc[~np.isin(sample, r[0])].max(initial=-2.0) <= c[0][-1], ("topk", dim, dtype, n, k)
         for mode in ("plain", "image", "image_scan", "q8"):
             if mode == "q8":
-                if dim > 1024:
+                if dim > 2048:
                     continue
                 ix.enable_batch_image(True, q8=True)
             elif mode != "plain":

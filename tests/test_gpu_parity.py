@@ -610,7 +610,7 @@ def test_small_batches_share_one_scan(rlr, oracle, monkeypatch, dim, nq):
     ix.close()
 
 
-@pytest.mark.parametrize("dim", [1024, 768])
+@pytest.mark.parametrize("dim", [1024, 768, 1536, 2048])
 def test_8bit_copy_over_binary16_rows(rlr, oracle, dim):
     """the 8-bit nomination copy also serves f16-typed indexes (half of their scan bytes)"""
     n, k = 9001, 60
