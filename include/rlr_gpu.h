@@ -20,7 +20,7 @@
  *   - thread-safety mirrors the reference's tokio RwLock (mcp_server.rs:89,
  *     worker.rs:397-399): search / score / fetch / mmr calls may run
  *     concurrently from any number of OS threads; mutators (upload, append,
- *     delete, fill, reserve, destroy) need external exclusion.
+ *     delete, fill, reserve, enable_batch_image, destroy) need external exclusion.
  *   - there is NO CPU fallback inside the library: with no usable GPU every
  *     compute entry point returns RLR_E_NO_DEVICE.
  */
