@@ -159,6 +159,26 @@ size_t row_bytes(const rlr_index *ix)
     return static_cast<size_t>(ix->pitch16) * 16;
 }
 
+} // namespace
+
+namespace rlr {
+hipError_t dev_malloc(void **p, size_t bytes)
+{
+    static const bool poison = [] {
+        const char *v = getenv("RLR_POISON_ALLOC");
+        return v && v[0] == '1';
+    }();
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && poison && bytes) {
+        e = hipMemset(*p, 0xFF, bytes);
+        if (e == hipSuccess)
+            e = hipDeviceSynchronize();
+    }
+    return e;
+}
+} // namespace rlr
+
+namespace {
 int32_t use_device(const rlr_index *ix)
 {
     RLR_HIP(hipSetDevice(ix->device));
@@ -171,9 +191,11 @@ int32_t grow(T **p, uint64_t *cap, uint64_t want, bool keep = false)
     if (*cap >= want && *p)
         return RLR_OK;
     T *n = nullptr;
-    RLR_HIP(hipMalloc(reinterpret_cast<void **>(&n), want * sizeof(T)));
-    if (keep && *p && *cap)
+    RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&n), want * sizeof(T)));
+    if (keep && *p && *cap) {
         RLR_HIP(hipMemcpy(n, *p, *cap * sizeof(T), hipMemcpyDeviceToDevice));
+        RLR_HIP(hipStreamSynchronize(nullptr)); // a device-to-device copy may return before it has run
+    }
     if (*p)
         (void)hipFree(*p);
     *p = n;
@@ -234,7 +256,8 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
             ix->free_ctx.pop_back();
             if ((*out)->hist_dirty) { // a previous call failed half way: restore the zero-histogram invariant
                 (void)hipStreamSynchronize((*out)->stream);
-                if (hipMemset((*out)->d_hist, 0, 2 * kHistBins * sizeof(uint32_t)) == hipSuccess)
+                // (on the context's own stream: the null stream does not order against a non-blocking one)
+                if (hipMemsetAsync((*out)->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), (*out)->stream) == hipSuccess)
                     (*out)->hist_dirty = false;
             }
             return RLR_OK;
@@ -249,9 +272,15 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
     for (int i = 0; i < 4 && e == hipSuccess; ++i)
         e = hipEventCreate(&c->bev[i]);
     if (e == hipSuccess)
-        e = hipMalloc(reinterpret_cast<void **>(&c->d_hist), 2 * kHistBins * sizeof(uint32_t));
+        e = rlr::dev_malloc(reinterpret_cast<void **>(&c->d_hist), 2 * kHistBins * sizeof(uint32_t));
+    // The zero-histogram invariant is established ON THE CONTEXT'S STREAM: a null-stream hipMemset of device
+    // memory may return before it has run, and a non-blocking stream is not ordered against the null stream --
+    // the first scan's histogram atomics could then land before the fill and be wiped (a rare wrong threshold
+    // on the first search of a fresh context, caught by the multi-shard fuzz with five contexts starting at once).
     if (e == hipSuccess)
-        e = hipMemset(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t));
+        e = hipMemsetAsync(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         ctx_free(c);
         return fail(RLR_E_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -293,16 +322,18 @@ int32_t ensure_rows(rlr_index *ix, uint64_t want_rows)
     uint64_t cap = std::max<uint64_t>(want_rows, ix->cap_rows + ix->cap_rows / 2);
     cap = std::max<uint64_t>(cap, 1024);
     void *n = nullptr;
-    hipError_t e = hipMalloc(&n, cap * row_bytes(ix));
+    hipError_t e = rlr::dev_malloc(&n, cap * row_bytes(ix));
     if (e != hipSuccess && cap > want_rows) {
         cap = want_rows;
-        e = hipMalloc(&n, cap * row_bytes(ix));
+        e = rlr::dev_malloc(&n, cap * row_bytes(ix));
     }
     if (e != hipSuccess)
         return fail(RLR_E_OOM, "hipMalloc of %llu rows x %zu B failed: %s",
                     static_cast<unsigned long long>(cap), row_bytes(ix), hipGetErrorString(e));
-    if (ix->d_rows && ix->n_rows)
+    if (ix->d_rows && ix->n_rows) {
         RLR_HIP(hipMemcpy(n, ix->d_rows, ix->n_rows * row_bytes(ix), hipMemcpyDeviceToDevice));
+        RLR_HIP(hipStreamSynchronize(nullptr)); // a device-to-device copy may return before it has run
+    }
     if (ix->d_rows)
         (void)hipFree(ix->d_rows);
     ix->d_rows = n;
@@ -323,13 +354,13 @@ int32_t sync_q8(rlr_index *ix, uint64_t first_row)
         ix->d_q8 = nullptr;
         ix->d_q8_scale = nullptr;
         ix->q8_cap_rows = 0;
-        RLR_HIP(hipMalloc(&ix->d_q8, std::max<uint64_t>(want, 1) * ix->dim));
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_q8_scale), std::max<uint64_t>(want, 1) * sizeof(float)));
+        RLR_HIP(rlr::dev_malloc(&ix->d_q8, std::max<uint64_t>(want, 1) * ix->dim));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&ix->d_q8_scale), std::max<uint64_t>(want, 1) * sizeof(float)));
         ix->q8_cap_rows = want;
         first_row = 0;
     }
     if (!ix->d_q8_stats)
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&ix->d_q8_stats), 4 * sizeof(uint32_t)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&ix->d_q8_stats), 4 * sizeof(uint32_t)));
     if (first_row == 0)
         RLR_HIP(hipMemset(ix->d_q8_stats, 0, 4 * sizeof(uint32_t)));
     RLR_HIP(launch_q8_build(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, static_cast<uint32_t>(first_row),
@@ -354,7 +385,7 @@ int32_t sync_image(rlr_index *ix, uint64_t first_row)
             (void)hipFree(ix->d_image);
         ix->d_image = nullptr;
         ix->image_cap = 0;
-        RLR_HIP(hipMalloc(&ix->d_image, std::max<size_t>(need, 256)));
+        RLR_HIP(rlr::dev_malloc(&ix->d_image, std::max<size_t>(need, 256)));
         ix->image_cap = std::max<size_t>(need, 256);
         first_row = 0; // fresh buffer: every tile has to be written
     }
@@ -374,8 +405,8 @@ int32_t ingest(rlr_index *ix, const float *rows, uint64_t n, uint64_t first, int
     const uint64_t chunk_rows = std::max<uint64_t>(1, (64ull << 20) / (static_cast<uint64_t>(ix->dim) * 4));
     float *d_stage = nullptr, *d_norm = nullptr;
     const uint64_t cr = std::min(chunk_rows, n);
-    RLR_HIP(hipMalloc(reinterpret_cast<void **>(&d_stage), cr * ix->dim * sizeof(float)));
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_norm), cr * sizeof(float));
+    RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&d_stage), cr * ix->dim * sizeof(float)));
+    hipError_t e = rlr::dev_malloc(reinterpret_cast<void **>(&d_norm), cr * sizeof(float));
     if (e != hipSuccess) {
         (void)hipFree(d_stage);
         return fail(RLR_E_OOM, "staging allocation failed");
@@ -414,8 +445,8 @@ int32_t ctx_prepare(rlr_index *ix, Ctx *c, uint32_t nq, const SearchPlan &p)
         c->d_query = nullptr;
         c->d_state = nullptr;
         c->q_cap = 0;
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_query), static_cast<size_t>(nq) * ix->q_pitch * sizeof(float)));
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_state), static_cast<size_t>(nq) * sizeof(SelectState)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_query), static_cast<size_t>(nq) * ix->q_pitch * sizeof(float)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_state), static_cast<size_t>(nq) * sizeof(SelectState)));
         c->q_cap = nq;
     }
     RLR_TRY(grow(&c->d_scores, &c->score_cap, std::max<uint64_t>(ix->n_rows, 4)));
@@ -425,8 +456,8 @@ int32_t ctx_prepare(rlr_index *ix, Ctx *c, uint32_t nq, const SearchPlan &p)
         c->d_cand = nullptr;
         c->d_packed = nullptr;
         c->cand_cap = 0;
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cand), static_cast<size_t>(p.cap) * sizeof(uint32_t)));
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_packed), static_cast<size_t>(p.cap) * sizeof(uint64_t)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_cand), static_cast<size_t>(p.cap) * sizeof(uint32_t)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_packed), static_cast<size_t>(p.cap) * sizeof(uint64_t)));
         c->cand_cap = p.cap;
     }
     RLR_TRY(grow(&c->d_out, &c->out_cap, static_cast<uint64_t>(nq) * p.k + nq)); // results + per-query counts
@@ -713,8 +744,8 @@ int32_t big_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint3
         c->d_cand = nullptr;
         c->d_packed = nullptr;
         c->cand_cap = 0;
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_cand), static_cast<size_t>(cap) * sizeof(uint32_t)));
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_packed), static_cast<size_t>(cap) * sizeof(uint64_t)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_cand), static_cast<size_t>(cap) * sizeof(uint32_t)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_packed), static_cast<size_t>(cap) * sizeof(uint64_t)));
         c->cand_cap = cap;
     }
     SelectState *st = c->d_state + qi;
@@ -826,7 +857,7 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
         if (c->d_qfrag) (void)hipFree(c->d_qfrag);
         c->d_qfrag = nullptr;
         c->qfrag_cap = 0;
-        RLR_HIP(hipMalloc(&c->d_qfrag, qfrag_bytes));
+        RLR_HIP(rlr::dev_malloc(&c->d_qfrag, qfrag_bytes));
         c->qfrag_cap = qfrag_bytes;
     }
     if (c->bq_cap < nq) {
@@ -839,10 +870,10 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
         c->d_bhist = nullptr;
         c->d_bstatus = nullptr;
         c->bq_cap = 0;
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_tau), static_cast<size_t>(nq) * sizeof(float)));
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_bstate), static_cast<size_t>(nq) * sizeof(SelectState)));
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_bhist), static_cast<size_t>(nq) * 2 * kHistBins * sizeof(uint32_t)));
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_bstatus), static_cast<size_t>(nq) * sizeof(uint32_t)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_tau), static_cast<size_t>(nq) * sizeof(float)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_bstate), static_cast<size_t>(nq) * sizeof(SelectState)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_bhist), static_cast<size_t>(nq) * 2 * kHistBins * sizeof(uint32_t)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_bstatus), static_cast<size_t>(nq) * sizeof(uint32_t)));
         c->bq_cap = nq;
     }
     RLR_TRY(grow(&c->d_bcand, &c->bcand_cap, static_cast<uint64_t>(nq) * fin_cap));
@@ -1094,8 +1125,8 @@ int32_t upload_list(rlr_index *ix, Ctx *c, const uint64_t *rows, uint32_t n)
         c->d_vals = nullptr;
         c->list_cap = 0;
         const uint32_t cap = std::max<uint32_t>(next_pow2(n), 1024);
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_list), static_cast<size_t>(cap) * sizeof(uint32_t)));
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_vals), static_cast<size_t>(cap) * sizeof(float)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_list), static_cast<size_t>(cap) * sizeof(uint32_t)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_vals), static_cast<size_t>(cap) * sizeof(float)));
         c->list_cap = cap;
     }
     RLR_TRY(pin_reserve(c, static_cast<size_t>(n) * 8 + 64));
@@ -1275,8 +1306,8 @@ int32_t rlr_index_delete_rows(rlr_index *ix, const uint64_t *rows, uint64_t n)
     void *d_bounce = nullptr;
     uint32_t *d_keep = nullptr;
     const uint64_t cr = std::min<uint64_t>(chunk, std::max<size_t>(keep.size(), 1));
-    RLR_HIP(hipMalloc(&d_bounce, cr * row_bytes(ix)));
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_keep), cr * sizeof(uint32_t));
+    RLR_HIP(rlr::dev_malloc(&d_bounce, cr * row_bytes(ix)));
+    hipError_t e = rlr::dev_malloc(reinterpret_cast<void **>(&d_keep), cr * sizeof(uint32_t));
     if (e != hipSuccess) {
         (void)hipFree(d_bounce);
         return fail(RLR_E_OOM, "compaction buffer allocation failed");
@@ -1355,7 +1386,7 @@ int32_t rlr_index_fill_synthetic(rlr_index *ix, uint64_t n_rows, uint64_t row0, 
     RLR_TRY(ensure_rows(ix, n_rows));
     const uint64_t chunk = 1ull << 20;
     float *d_norm = nullptr;
-    RLR_HIP(hipMalloc(reinterpret_cast<void **>(&d_norm), std::min(chunk, std::max<uint64_t>(n_rows, 1)) * sizeof(float)));
+    RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&d_norm), std::min(chunk, std::max<uint64_t>(n_rows, 1)) * sizeof(float)));
     int32_t st = RLR_OK;
     for (uint64_t r0 = 0; r0 < n_rows && st == RLR_OK; r0 += chunk) {
         const uint64_t m = std::min(chunk, n_rows - r0);
@@ -1624,8 +1655,8 @@ int32_t rlr_score_rows(rlr_index *ix, const float *query, const uint64_t *rows, 
     Ctx *c = lease.c;
     RLR_TRY(upload_list(ix, c, rows, n));
     if (c->q_cap < 1) {
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_query), static_cast<size_t>(ix->q_pitch) * sizeof(float)));
-        RLR_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_state), sizeof(SelectState)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_query), static_cast<size_t>(ix->q_pitch) * sizeof(float)));
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_state), sizeof(SelectState)));
         c->q_cap = 1;
     }
     RLR_HIP(hipMemcpyAsync(c->d_query, query, ix->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));

@@ -7,6 +7,12 @@
 
 namespace rlr {
 
+// Every device allocation of the library goes through here.  RLR_POISON_ALLOC=1 (a test switch) fills each new
+// buffer with 0xFF bytes -- NaN as f32 / binary16, huge as a counter -- so that a kernel reading memory nobody
+// has written shows up as a wrong answer in the parity tests instead of hiding behind the zero pages a fresh
+// process usually gets (tests/test_gpu_fuzz.py::test_poisoned_allocations).
+hipError_t dev_malloc(void **p, size_t bytes);
+
 // index.hip: sets the thread-local rlr_last_error() message, returns `code`
 int32_t set_error(int32_t code, const char *fmt, ...);
 

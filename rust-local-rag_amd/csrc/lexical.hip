@@ -274,9 +274,11 @@ int32_t dev_grow(T **p, uint64_t *cap, uint64_t need, bool zero = false)
     *p = nullptr;
     *cap = 0;
     const uint64_t n = std::max<uint64_t>(need, 1024);
-    LEX_HIP(hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
-    if (zero)
+    LEX_HIP(rlr::dev_malloc(reinterpret_cast<void **>(p), n * sizeof(T)));
+    if (zero) { // null stream, then wait: the scoring stream is non-blocking and not ordered against it
         LEX_HIP(hipMemset(*p, 0, n * sizeof(T)));
+        LEX_HIP(hipStreamSynchronize(nullptr));
+    }
     *cap = n;
     return RLR_OK;
 }
@@ -410,13 +412,13 @@ int32_t rlr_lexical_create(int32_t device_id, rlr_lexical **out)
         e = hipStreamCreateWithFlags(&lx->stream, hipStreamNonBlocking);
     }
     if (e == hipSuccess)
-        e = hipMalloc(reinterpret_cast<void **>(&lx->d_ctl), sizeof(LexControl));
+        e = rlr::dev_malloc(reinterpret_cast<void **>(&lx->d_ctl), sizeof(LexControl));
     if (e == hipSuccess)
-        e = hipMemset(lx->d_ctl, 0, sizeof(LexControl));
+        e = hipMemsetAsync(lx->d_ctl, 0, sizeof(LexControl), lx->stream); // ordered before every scoring call
     if (e == hipSuccess)
-        e = hipMalloc(reinterpret_cast<void **>(&lx->d_sel), kMaxLimit * sizeof(uint64_t));
+        e = rlr::dev_malloc(reinterpret_cast<void **>(&lx->d_sel), kMaxLimit * sizeof(uint64_t));
     if (e == hipSuccess)
-        e = hipMalloc(reinterpret_cast<void **>(&lx->d_out), (kMaxLimit + 1) * sizeof(uint64_t));
+        e = rlr::dev_malloc(reinterpret_cast<void **>(&lx->d_out), (kMaxLimit + 1) * sizeof(uint64_t));
     if (e == hipSuccess)
         e = hipHostMalloc(reinterpret_cast<void **>(&lx->h_out), (kMaxLimit + 1) * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -593,8 +595,8 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     if (lx->workspace_dirty) { // restore the all-zero invariant a failed call may have broken
         LEX_HIP(hipStreamSynchronize(lx->stream));
         if (lx->d_scores)
-            LEX_HIP(hipMemset(lx->d_scores, 0, lx->scores_cap * sizeof(float)));
-        LEX_HIP(hipMemset(lx->d_ctl, 0, sizeof(LexControl)));
+            LEX_HIP(hipMemsetAsync(lx->d_scores, 0, lx->scores_cap * sizeof(float), lx->stream));
+        LEX_HIP(hipMemsetAsync(lx->d_ctl, 0, sizeof(LexControl), lx->stream));
         lx->workspace_dirty = false;
     }
 

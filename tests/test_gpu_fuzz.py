@@ -184,6 +184,11 @@ def fuzz_multi(budget: float, seed0: int):
         r1, c1 = one.search_topk(qs, k)
         rm, cm = mi.search_topk(qs, k)
         ctx = dict(dim=dim, dtype=dtype, n=n, shards=shards, nq=nq, k=k, seed0=seed0, case=n_cases)
+        for i in range(nq):                                         # both against the oracle: a failure names the culprit
+            sc_all = O.scan(rows, qs[i])
+            order = np.argsort(-sc_all, kind="stable")[:k]
+            for name, (rr, cc) in (("single", (r1, c1)), ("multi", (rm, cm))):
+                assert np.array_equal(rr[i], order.astype(np.uint64)) and np.array_equal(bits(cc[i]), bits(sc_all[order])), (name, i, ctx)
         assert np.array_equal(r1, rm) and np.array_equal(bits(c1), bits(cm)), ctx
         pick = rng.choice(n, size=min(n, 9), replace=False).astype(np.uint64)
         assert np.array_equal(bits(one.score_rows(qs[0], pick)), bits(mi.score_rows(qs[0], pick))), ctx
@@ -314,6 +319,21 @@ def test_fuzz_against_the_oracle():
     assert n_cases > 100 and n_q > 500
 
 
+def test_poisoned_allocations():
+    """the same differential tests in a child process whose every device allocation starts out as 0xFF bytes
+    (RLR_POISON_ALLOC=1: NaN rows, huge counters) -- a kernel that reads memory nobody wrote cannot hide behind the
+    zero pages of a fresh process"""
+    import os
+    import subprocess
+
+    env = dict(os.environ, RLR_POISON_ALLOC="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-u", os.path.abspath(__file__), "12", "9"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "multi-shard fuzz ok" in out.stdout
+
+
 def test_mmr_logged_value_keeps_the_sign_of_zero(rlr, oracle):
     """lambda = 1: (1 - lambda) * rel is -0.0 for a negative relevance and the reference logs -0.0 - 0.0 = -0.0"""
     rows = oracle.synth_rows(17, 1152, seed=470119562, f16=True)
@@ -335,6 +355,9 @@ if __name__ == "__main__":
     sys.path.insert(0, ".")
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "multi":
+        print("multi-shard fuzz ok: %d corpora" % fuzz_multi(secs, seed))
+        sys.exit(0)
     print("fuzz ok: %d corpora, %d queries" % fuzz(secs, seed))
     print("engine fuzz ok: %d engines" % fuzz_engine(secs / 2, seed))
     print("lexical fuzz ok: %d indexes" % fuzz_lexical(secs / 2, seed))
