@@ -169,6 +169,8 @@ hipError_t dev_malloc(void **p, size_t bytes)
         return v && v[0] == '1';
     }();
     hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess)
+        (void)hipGetLastError(); // reported through the return value; do not leave it for a later launch check to find
     if (e == hipSuccess && poison && bytes) {
         e = hipMemset(*p, 0xFF, bytes);
         if (e == hipSuccess)

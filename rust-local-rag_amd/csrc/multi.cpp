@@ -6,8 +6,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
+
+namespace rlr {
+int32_t set_error(int32_t code, const char *fmt, ...); // index.hip: the calling thread's rlr_last_error() text
+}
 
 struct rlr_multi {
     uint32_t dim = 0;
@@ -39,7 +44,8 @@ void set_bases(rlr_multi *m, uint64_t n_rows)
     m->n_rows = n_rows;
 }
 
-// run f(g) for every shard on its own thread; returns the first failing status
+// run f(g) for every shard on its own thread; returns the first failing status.  rlr_last_error() is per thread,
+// so a worker's message is carried back to the calling thread (prefixed with the shard it came from).
 template <typename F>
 int32_t for_each_shard(const rlr_multi *m, F f)
 {
@@ -47,17 +53,22 @@ int32_t for_each_shard(const rlr_multi *m, F f)
     std::vector<int32_t> st(G, RLR_OK);
     if (G == 1) {
         st[0] = f(0);
-    } else {
-        std::vector<std::thread> th;
-        th.reserve(G);
-        for (size_t g = 0; g < G; ++g)
-            th.emplace_back([&, g] { st[g] = f(static_cast<uint32_t>(g)); });
-        for (auto &t : th)
-            t.join();
+        return st[0];
     }
-    for (int32_t s : st)
-        if (s != RLR_OK)
-            return s;
+    std::vector<std::string> why(G);
+    std::vector<std::thread> th;
+    th.reserve(G);
+    for (size_t g = 0; g < G; ++g)
+        th.emplace_back([&, g] {
+            st[g] = f(static_cast<uint32_t>(g));
+            if (st[g] != RLR_OK)
+                why[g] = rlr_last_error();
+        });
+    for (auto &t : th)
+        t.join();
+    for (size_t g = 0; g < G; ++g)
+        if (st[g] != RLR_OK)
+            return rlr::set_error(st[g], "shard %zu: %s", g, why[g].c_str());
     return RLR_OK;
 }
 

@@ -789,6 +789,28 @@ def test_multi_index_three_shards_on_one_gpu(rlr, oracle):
     mi.close()
 
 
+def test_multi_index_reports_a_shard_failure_with_its_message(rlr):
+    """a failure inside a shard's worker thread reaches the caller with the worker's message (rlr_last_error is
+    per thread): 2 x 100 M rows of 8 KiB cannot be allocated, and the index stays usable afterwards"""
+    mi = rlr.MultiGpuIndex(2048, [0, 0])
+    with pytest.raises(rlr.RlrError) as err:
+        mi.fill_synthetic(200_000_000, seed=1)
+    assert "shard 0:" in str(err.value) and "failed" in str(err.value), str(err.value)
+    mi.fill_synthetic(2000, seed=1)
+    r, c = mi.search_topk(np.ones(2048, np.float32) / np.float32(np.sqrt(2048.0)), 5)
+    assert r.shape == (1, 5) and np.all(np.diff(c[0]) <= 0)
+    mi.close()
+    # same on the calling thread: the failed allocation must not linger as a stale HIP error for the next launch check
+    one = rlr.GpuIndex(2048)
+    with pytest.raises(rlr.RlrError) as err:
+        one.fill_synthetic(100_000_000, seed=1)
+    assert err.value.status == rlr._native.RLR_E_OOM
+    one.fill_synthetic(2000, seed=1)
+    r1, c1 = one.search_topk(np.ones(2048, np.float32) / np.float32(np.sqrt(2048.0)), 5)
+    assert np.array_equal(r1[:, :5], r) and np.array_equal(bits(c1), bits(c))
+    one.close()
+
+
 # ---------------------------------------------------------------- rarely taken paths
 def test_multi_query_band_overflow_rescans(rlr, oracle):
     """fewer than 16 queries (looped single-query pipeline) where one query's band overflows:
