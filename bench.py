@@ -64,6 +64,12 @@ def queries_without_oracle(rlr, dim, n, seed):
     return np.stack([rlr.normalize(rng.standard_normal(dim).astype(np.float32)) for _ in range(n)])
 
 
+def q8_kernel_name(dim):
+    """which 8-bit scan kernel csrc/q8.hip launches for this row width (launch_q8_scan)"""
+    packed = os.environ.get("RLR_Q8_PACKED", "1")[:1] != "0" and dim in (384, 768, 1536)
+    return "q8_scan_packed_kernel" if packed else "q8_scan_kernel"
+
+
 def pmc_traffic(bytes_per_launch, kernel):
     """HBM bytes per launch of the scan kernel from the committed rocprofv3 --pmc passes of
     this same command (profiles/rNN_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
@@ -323,7 +329,7 @@ def main():
         out["band_retries"] = prof.n_batch_fallbacks
         out["dtype"] = f"{args.dtype} rows, f16 MFMA nomination + f32 reference-order re-score"
     if q8_scan and not batched:
-        out["roofline"]["kernel"] = "q8_scan_kernel"
+        out["roofline"]["kernel"] = q8_kernel_name(args.dim)
         out["dtype"] = "f32 rows, 8-bit nomination scan + f32 reference-order re-score"
         out["config"]["workload"] += "; single-query nomination over the 8-bit copy (opt-in, +dim+4 B/row of HBM)"
     elif image_scan and not batched:
@@ -342,7 +348,7 @@ def main():
                   "single queries nominate over the binary16 image (rlr_index_enable_batch_image(idx, 3)); "
                   "+dim*2 B/row of HBM, results identical")]
         if args.dim <= 2048:
-            modes.append(("q8_scan", dict(on=False, q8=True), 1, "q8_scan_kernel",
+            modes.append(("q8_scan", dict(on=False, q8=True), 1, q8_kernel_name(args.dim),
                           "single queries nominate over the 8-bit copy with per-row scales "
                           "(rlr_index_enable_batch_image(idx, 4)); +dim+4 B/row of HBM, results identical"))
         for name, kw, eb, kern, what in modes:

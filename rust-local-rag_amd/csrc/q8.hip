@@ -202,6 +202,104 @@ __global__ __launch_bounds__(256) void q8_scan_kernel(const uint8_t *__restrict_
     }
 }
 
+// Lane-packed variant, the default at 768 / 384 / 1536-d (RLR_Q8_PACKED=0 goes back to the kernel above; measured
+// 1.263 ms against 1.365 ms at 10 M x 768 on the same box, identical candidates and results):
+// when dim/16 does not divide 64 the kernel above leaves lanes idle on every row load (768-d: 48 of 64 carry
+// data).  Here G consecutive rows form one block of G * dim bytes = NL full wave loads (768-d: 4 rows = 3 loads;
+// 384-d: 8 rows = 3 loads; 1536-d: 2 rows = 3 loads), lane l of load j holds 16-byte unit u = 64 j + l of the
+// block, i.e. row u / p16, segment u % p16 -- a quarter fewer loads, converts and FMAs at 768-d.  The G row sums
+// come out of G wave reductions over the lanes' parts selected by row.  Same bound as above (q8_arith_eps): 16
+// chained FMAs from the bias, at most NL - 1 extra adds, 6 reduction levels, the scale.
+template <int G, int NL>
+__global__ __launch_bounds__(256) void q8_scan_packed_kernel(const uint8_t *__restrict__ q8, const float *__restrict__ scale,
+                                                             const float *__restrict__ query, float *__restrict__ scores,
+                                                             uint32_t *__restrict__ g_hist, uint32_t n_rows, uint32_t dim,
+                                                             uint32_t group_rows)
+{
+    constexpr int NB = 8 / G; // blocks in flight: 8 rows per iteration like the kernel above
+    static_assert(G * NB == 8, "G must divide 8");
+    __shared__ uint32_t s_hist[kHistBins];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < kHistBins; i += 256)
+        s_hist[i] = 0;
+    const uint32_t p16 = dim / 16; // host guarantees G * p16 == NL * 64
+    uint32_t rib[NL], off[NL];
+    float qv[NL][16], nbias[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const uint32_t u = static_cast<uint32_t>(j * 64 + lane);
+        rib[j] = u / p16;
+        const uint32_t seg = u - rib[j] * p16;
+        off[j] = seg * 16;
+        float qs = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            qv[j][b] = query[seg * 16 + b];
+            qs += qv[j][b];
+        }
+        nbias[j] = -128.0f * qs; // the bytes are biased by 128
+    }
+    __syncthreads();
+
+    const uint32_t n_groups = (n_rows + group_rows - 1) / group_rows;
+    const uint32_t n_waves = gridDim.x * 4;
+    for (uint32_t g = blockIdx.x * 4 + wave; g < n_groups; g += n_waves) {
+        const uint32_t row0 = g * group_rows;
+        const uint32_t nr = min(group_rows, n_rows - row0);
+        const uint32_t last = row0 + nr - 1;
+        float mine = 0.0f;
+        for (uint32_t r = 0; r < nr; r += 8) {
+            u32x4 x[NB][NL];
+            float sc[8];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    // rows past the group end are clamped to its last row (a valid address; the lane that would
+                    // receive the result is never stored)
+                    const uint32_t row = min(row0 + r + bb * G + rib[j], last);
+                    x[bb][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(q8 + static_cast<size_t>(row) * dim + off[j]));
+                }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+                sc[rr] = scale[min(row0 + r + rr, last)];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                float acc[NL];
+#pragma unroll
+                for (int j = 0; j < NL; ++j)
+                    acc[j] = dot16_u8(x[bb][j], qv[j], nbias[j]);
+#pragma unroll
+                for (int rb = 0; rb < G; ++rb) {
+                    float part = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NL; ++j)
+                        part += rib[j] == static_cast<uint32_t>(rb) ? acc[j] : 0.0f;
+                    const float tot = wave_sum(part);
+                    const float v = sc[bb * G + rb] * tot;
+                    if (static_cast<uint32_t>(lane) == r + bb * G + rb)
+                        mine = v;
+                }
+            }
+        }
+        if (static_cast<uint32_t>(lane) < nr) {
+            scores[row0 + lane] = mine;
+            if (g_hist)
+                atomicAdd(&s_hist[score_key(mine) >> 21], 1u);
+        }
+    }
+    if (g_hist) {
+        __syncthreads();
+        for (int i = tid; i < kHistBins; i += 256) {
+            const uint32_t c = s_hist[i];
+            if (c)
+                atomicAdd(&g_hist[i], c);
+        }
+    }
+}
+
 } // namespace
 
 hipError_t launch_q8_build(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin, uint32_t n_rows,
@@ -237,6 +335,30 @@ hipError_t launch_q8_scan(const void *q8, const float *scale, uint32_t n_rows, u
     const uint32_t n_groups = (n_rows + group - 1) / group;
     const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_groups + 3) / 4, static_cast<uint32_t>(n_cu) * bpc));
     const uint8_t *p = static_cast<const uint8_t *>(q8);
+    static const bool packed = [] {
+        const char *v = getenv("RLR_Q8_PACKED");
+        return !(v && v[0] == '0');
+    }();
+    if (packed) {
+        const uint32_t p16 = dim / 16;
+        const uint32_t pg = std::max<uint32_t>(8, group / 8 * 8); // whole 8-row iterations
+        const uint32_t pgroups = (n_rows + pg - 1) / pg;
+        // 91 VGPRs at 768-d (5 workgroups per CU could be resident): 4 / 5 / 10 per CU measured 1.263 / 1.275 / 1.276 ms
+        const uint32_t pbpc = ((tune >> 8) & 0xFF) ? ((tune >> 8) & 0xFF) : 4;
+        const uint32_t pblocks = std::max<uint32_t>(1, std::min<uint32_t>((pgroups + 3) / 4, static_cast<uint32_t>(n_cu) * pbpc));
+        if (p16 * 4 == 3 * 64) { // 768-d
+            hipLaunchKernelGGL((q8_scan_packed_kernel<4, 3>), dim3(pblocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, pg);
+            return hipGetLastError();
+        }
+        if (p16 * 8 == 3 * 64) { // 384-d
+            hipLaunchKernelGGL((q8_scan_packed_kernel<8, 3>), dim3(pblocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, pg);
+            return hipGetLastError();
+        }
+        if (p16 * 2 == 3 * 64) { // 1536-d
+            hipLaunchKernelGGL((q8_scan_packed_kernel<2, 3>), dim3(pblocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, pg);
+            return hipGetLastError();
+        }
+    }
     if (dim > 1024) { // two 16-byte loads per lane per row (dim <= 2048)
         hipLaunchKernelGGL((q8_scan_kernel<4, 2>), dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group);
         return hipGetLastError();

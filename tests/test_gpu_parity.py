@@ -546,7 +546,7 @@ def test_single_query_nomination_over_the_image_is_exact(rlr, oracle, dim):
         ix.close()
 
 
-@pytest.mark.parametrize("dim", [768, 1024, 64, 400])
+@pytest.mark.parametrize("dim", [768, 1024, 64, 400, 384, 1536])
 def test_single_query_nomination_over_the_8bit_copy_is_exact(rlr, oracle, dim):
     """enable_batch_image(q8=True): one byte per element + a per-row scale; the band comes from the stored row error
     norms (Cauchy-Schwarz), the re-score from the f32 rows -- rows and scores identical to the oracle, including
@@ -623,6 +623,32 @@ def test_8bit_copy_over_binary16_rows(rlr, oracle, dim):
         wr, wc = oracle_topk(oracle, rows, qn, k)
         assert np.array_equal(r[0], wr) and np.array_equal(bits(c[0]), bits(wc)), (dim, qi)
     ix.close()
+
+
+def test_8bit_scan_kernels_agree(rlr, oracle):
+    """the lane-packed 8-bit scan (default at 768 / 384 / 1536-d) and the one-row-per-load kernel (RLR_Q8_PACKED=0, read
+    once per process, so in a child) both end in the oracle's answer on a corpus with ragged group tails"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import importlib, numpy as np, sys; sys.path.insert(0, '.')\n"
+        "rlr = importlib.import_module('rust-local-rag_amd'); from oracle import oracle as O\n"
+        "for dim in (768, 384, 1536):\n"
+        "    for n in (1, 7, 33, 4099):\n"
+        "        rows = O.synth_rows(n, dim, seed=77 + n + dim, n_clusters=3)\n"
+        "        ix = rlr.GpuIndex(dim); ix.upload(rows); ix.enable_batch_image(False, q8=True)\n"
+        "        q = O.normalize(O.synth_query(dim, seed=5 + n))\n"
+        "        r, c = ix.search_topk(q, 10)\n"
+        "        s = O.scan(rows, q); o = np.argsort(-s, kind='stable')[:10]\n"
+        "        assert np.array_equal(r[0], o.astype(np.uint64)) and np.array_equal(c[0].view(np.uint32), s[o].view(np.uint32)), (dim, n)\n"
+        "        ix.close()\n"
+        "print('agree')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for packed in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RLR_Q8_PACKED=packed),
+                             capture_output=True, text=True, timeout=240)
+        assert out.returncode == 0 and "agree" in out.stdout, (packed, out.stdout[-1000:], out.stderr[-3000:])
 
 
 def test_merge_topk_kernel_matches_torch_merge_and_global_oracle(rlr, oracle):
