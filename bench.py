@@ -66,7 +66,7 @@ def queries_without_oracle(rlr, dim, n, seed):
 
 def q8_kernel_name(dim):
     """which 8-bit scan kernel csrc/q8.hip launches for this row width (launch_q8_scan)"""
-    packed = os.environ.get("RLR_Q8_PACKED", "1")[:1] != "0" and dim in (384, 768, 1536)
+    packed = os.environ.get("RLR_Q8_PACKED", "1")[:1] != "0" and dim in (128, 256, 384, 512, 768, 1536)
     return "q8_scan_packed_kernel" if packed else "q8_scan_kernel"
 
 

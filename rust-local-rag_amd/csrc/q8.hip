@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void q8_scan_kernel(const uint8_t *__restrict_
     }
 }
 
-// Lane-packed variant, the default at 768 / 384 / 1536-d (RLR_Q8_PACKED=0 goes back to the kernel above; measured
+// Lane-packed variant, the default at 768 / 384 / 1536 / 512 / 256 / 128-d (RLR_Q8_PACKED=0 goes back to the kernel above; measured
 // 1.263 ms against 1.365 ms at 10 M x 768 on the same box, identical candidates and results):
 // when dim/16 does not divide 64 the kernel above leaves lanes idle on every row load (768-d: 48 of 64 carry
 // data).  Here G consecutive rows form one block of G * dim bytes = NL full wave loads (768-d: 4 rows = 3 loads;
@@ -210,21 +210,21 @@ __global__ __launch_bounds__(256) void q8_scan_kernel(const uint8_t *__restrict_
 // block, i.e. row u / p16, segment u % p16 -- a quarter fewer loads, converts and FMAs at 768-d.  The G row sums
 // come out of G wave reductions over the lanes' parts selected by row.  Same bound as above (q8_arith_eps): 16
 // chained FMAs from the bias, at most NL - 1 extra adds, 6 reduction levels, the scale.
-template <int G, int NL>
+template <int G, int NL, int NB>
 __global__ __launch_bounds__(256) void q8_scan_packed_kernel(const uint8_t *__restrict__ q8, const float *__restrict__ scale,
                                                              const float *__restrict__ query, float *__restrict__ scores,
                                                              uint32_t *__restrict__ g_hist, uint32_t n_rows, uint32_t dim,
                                                              uint32_t group_rows)
 {
-    constexpr int NB = 8 / G; // blocks in flight: 8 rows per iteration like the kernel above
-    static_assert(G * NB == 8, "G must divide 8");
+    constexpr int RI = G * NB; // rows per iteration (NB blocks = NB * NL loads in flight per wave)
+    static_assert(RI <= 64, "a group parks one score per lane");
     __shared__ uint32_t s_hist[kHistBins];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < kHistBins; i += 256)
         s_hist[i] = 0;
-    const uint32_t p16 = dim / 16; // host guarantees G * p16 == NL * 64
+    const uint32_t p16 = dim / 16; // host guarantees G * p16 == NL * 64 and group_rows % RI == 0, group_rows <= 64
     uint32_t rib[NL], off[NL];
     float qv[NL][16], nbias[NL];
 #pragma unroll
@@ -249,10 +249,11 @@ __global__ __launch_bounds__(256) void q8_scan_packed_kernel(const uint8_t *__re
         const uint32_t row0 = g * group_rows;
         const uint32_t nr = min(group_rows, n_rows - row0);
         const uint32_t last = row0 + nr - 1;
+        // the row scales of the whole group in one load (lane i: row row0 + i), applied when the scores are stored
+        const float my_scale = scale[min(row0 + static_cast<uint32_t>(lane), last)];
         float mine = 0.0f;
-        for (uint32_t r = 0; r < nr; r += 8) {
+        for (uint32_t r = 0; r < nr; r += RI) {
             u32x4 x[NB][NL];
-            float sc[8];
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb)
 #pragma unroll
@@ -262,9 +263,6 @@ __global__ __launch_bounds__(256) void q8_scan_packed_kernel(const uint8_t *__re
                     const uint32_t row = min(row0 + r + bb * G + rib[j], last);
                     x[bb][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(q8 + static_cast<size_t>(row) * dim + off[j]));
                 }
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr)
-                sc[rr] = scale[min(row0 + r + rr, last)];
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) {
                 float acc[NL];
@@ -278,16 +276,16 @@ __global__ __launch_bounds__(256) void q8_scan_packed_kernel(const uint8_t *__re
                     for (int j = 0; j < NL; ++j)
                         part += rib[j] == static_cast<uint32_t>(rb) ? acc[j] : 0.0f;
                     const float tot = wave_sum(part);
-                    const float v = sc[bb * G + rb] * tot;
                     if (static_cast<uint32_t>(lane) == r + bb * G + rb)
-                        mine = v;
+                        mine = tot;
                 }
             }
         }
         if (static_cast<uint32_t>(lane) < nr) {
-            scores[row0 + lane] = mine;
+            const float v = my_scale * mine; // NaN scale -> NaN score -> ordered last, like the reference dot of a NaN row
+            scores[row0 + lane] = v;
             if (g_hist)
-                atomicAdd(&s_hist[score_key(mine) >> 21], 1u);
+                atomicAdd(&s_hist[score_key(v) >> 21], 1u);
         }
     }
     if (g_hist) {
@@ -341,23 +339,26 @@ hipError_t launch_q8_scan(const void *q8, const float *scale, uint32_t n_rows, u
     }();
     if (packed) {
         const uint32_t p16 = dim / 16;
-        const uint32_t pg = std::max<uint32_t>(8, group / 8 * 8); // whole 8-row iterations
-        const uint32_t pgroups = (n_rows + pg - 1) / pg;
-        // 91 VGPRs at 768-d (5 workgroups per CU could be resident): 4 / 5 / 10 per CU measured 1.263 / 1.275 / 1.276 ms
-        const uint32_t pbpc = ((tune >> 8) & 0xFF) ? ((tune >> 8) & 0xFF) : 4;
-        const uint32_t pblocks = std::max<uint32_t>(1, std::min<uint32_t>((pgroups + 3) / 4, static_cast<uint32_t>(n_cu) * pbpc));
-        if (p16 * 4 == 3 * 64) { // 768-d
-            hipLaunchKernelGGL((q8_scan_packed_kernel<4, 3>), dim3(pblocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, pg);
-            return hipGetLastError();
-        }
-        if (p16 * 8 == 3 * 64) { // 384-d
-            hipLaunchKernelGGL((q8_scan_packed_kernel<8, 3>), dim3(pblocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, pg);
-            return hipGetLastError();
-        }
-        if (p16 * 2 == 3 * 64) { // 1536-d
-            hipLaunchKernelGGL((q8_scan_packed_kernel<2, 3>), dim3(pblocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, pg);
-            return hipGetLastError();
-        }
+        // G rows per block, NL loads per block, NB blocks per iteration, rows per group, workgroups per CU (when
+        // RLR_Q8_VARIANT does not say).  768-d: 91 VGPRs, 4 / 5 / 10 workgroups per CU measured 1.263 / 1.275 / 1.276 ms.
+        // The NL = 1 widths keep 8 loads in flight per wave like the kernel above, with every lane carrying data.
+#define RLR_Q8_PACKED_CASE(G_, NL_, NB_, GROUP_, BPC_)                                                                \
+    if (p16 * G_ == NL_ * 64) {                                                                                      \
+        const uint32_t pg = GROUP_;                                                                                  \
+        const uint32_t pgroups = (n_rows + pg - 1) / pg;                                                             \
+        const uint32_t pbpc = ((tune >> 8) & 0xFF) ? ((tune >> 8) & 0xFF) : BPC_;                                    \
+        const uint32_t pblocks = std::max<uint32_t>(1, std::min<uint32_t>((pgroups + 3) / 4, static_cast<uint32_t>(n_cu) * pbpc)); \
+        hipLaunchKernelGGL((q8_scan_packed_kernel<G_, NL_, NB_>), dim3(pblocks), dim3(256), 0, s, p, scale, query, scores, \
+                           hist, n_rows, dim, pg);                                                                   \
+        return hipGetLastError();                                                                                    \
+    }
+        RLR_Q8_PACKED_CASE(4, 3, 2, 32, 4) // 768-d: 4 rows = 3 loads, 8 rows per iteration
+        RLR_Q8_PACKED_CASE(8, 3, 1, 32, 4) // 384-d: 8 rows = 3 loads
+        RLR_Q8_PACKED_CASE(2, 3, 4, 32, 4) // 1536-d: 2 rows = 3 loads
+        RLR_Q8_PACKED_CASE(2, 1, 8, 32, 8) // 512-d: 2 rows per load, 16 rows per iteration
+        RLR_Q8_PACKED_CASE(4, 1, 8, 32, 8) // 256-d: 4 rows per load, 32 rows per iteration
+        RLR_Q8_PACKED_CASE(8, 1, 8, 64, 8) // 128-d: 8 rows per load, 64 rows per iteration
+#undef RLR_Q8_PACKED_CASE
     }
     if (dim > 1024) { // two 16-byte loads per lane per row (dim <= 2048)
         hipLaunchKernelGGL((q8_scan_kernel<4, 2>), dim3(blocks), dim3(256), 0, s, p, scale, query, scores, hist, n_rows, dim, group);

@@ -546,7 +546,7 @@ def test_single_query_nomination_over_the_image_is_exact(rlr, oracle, dim):
         ix.close()
 
 
-@pytest.mark.parametrize("dim", [768, 1024, 64, 400, 384, 1536])
+@pytest.mark.parametrize("dim", [768, 1024, 64, 400, 384, 1536, 512, 1280])
 def test_single_query_nomination_over_the_8bit_copy_is_exact(rlr, oracle, dim):
     """enable_batch_image(q8=True): one byte per element + a per-row scale; the band comes from the stored row error
     norms (Cauchy-Schwarz), the re-score from the f32 rows -- rows and scores identical to the oracle, including
@@ -626,7 +626,7 @@ def test_8bit_copy_over_binary16_rows(rlr, oracle, dim):
 
 
 def test_8bit_scan_kernels_agree(rlr, oracle):
-    """the lane-packed 8-bit scan (default at 768 / 384 / 1536-d) and the one-row-per-load kernel (RLR_Q8_PACKED=0, read
+    """the lane-packed 8-bit scan (default where dim/16 times 2, 4 or 8 is a multiple of 64) and the one-row-per-load kernel (RLR_Q8_PACKED=0, read
     once per process, so in a child) both end in the oracle's answer on a corpus with ragged group tails"""
     import os
     import subprocess
@@ -634,7 +634,7 @@ def test_8bit_scan_kernels_agree(rlr, oracle):
     code = (
         "import importlib, numpy as np, sys; sys.path.insert(0, '.')\n"
         "rlr = importlib.import_module('rust-local-rag_amd'); from oracle import oracle as O\n"
-        "for dim in (768, 384, 1536):\n"
+        "for dim in (768, 384, 1536, 512, 256, 128, 640, 1280):\n"
         "    for n in (1, 7, 33, 4099):\n"
         "        rows = O.synth_rows(n, dim, seed=77 + n + dim, n_clusters=3)\n"
         "        ix = rlr.GpuIndex(dim); ix.upload(rows); ix.enable_batch_image(False, q8=True)\n"
