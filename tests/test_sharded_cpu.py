@@ -52,10 +52,11 @@ def _worker(rank, world, port, n_total, dim, k, seed, ret):
         dist.destroy_process_group()
 
 
-def test_world2_gloo_allgather_merge_matches_global_oracle(oracle):
+@pytest.mark.parametrize("n_total,world,k", [(1001, 2, 20), (50, 3, 20)])   # the second: shards shorter than k
+def test_world2_gloo_allgather_merge_matches_global_oracle(oracle, n_total, world, k):
     import torch.multiprocessing as mp
 
-    n_total, dim, k, seed, world = 1001, 64, 20, 77, 2
+    dim, seed = 64, 77
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
