@@ -17,12 +17,15 @@
 // quadrant (A0,B0), (A0,B1), (A1,B1), (A1,B0); `s_waitcnt vmcnt(6)` once per K-tile (phase 3, after that phase's
 // DMAs were issued) retires everything the next K-tile reads and leaves three half-tiles in flight.
 #include <hip/hip_runtime.h>
+#include "../../rust-local-rag_amd/csrc/common.h"
 #include "../../rust-local-rag_amd/csrc/kernels.h"
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -42,11 +45,16 @@ constexpr int kHalfBytes = 16384;
 // LDS half-tile images: A [row block 8][k-step 2][lane] (a linear copy), B [k-step 2][col block 8][lane].
 // wave (wm, wn) multiplies row blocks wm*4..+3 of each A half with col blocks wn*2..+1 of each B half.
 
-template <bool MATERIALISE>
+// MODE 0: count scores above tau (timing); 1: materialise C[q][row]; 2: filter -- append (score, row) >= tau_q[q] to
+// cand[q] exactly as the library's gemm_epilogue does (per-lane atomic slot, pack_result)
+template <int MODE>
 __global__ __launch_bounds__(512) void gemm8_kernel(const char *__restrict__ A, const char *__restrict__ B, uint32_t n_tiles,
                                                     uint32_t T, float tau, float *__restrict__ C, uint32_t ldc,
-                                                    unsigned *__restrict__ count)
+                                                    unsigned *__restrict__ count, const float *__restrict__ tau_q,
+                                                    uint64_t *__restrict__ cand, uint32_t cand_stride,
+                                                    rlr::SelectState *__restrict__ st, uint32_t n_rows)
 {
+    constexpr bool MATERIALISE = MODE == 1;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,6 +97,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const char *__restrict__ A, 
                     acc[h][q][rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     half8 a[2][4], b[2][2][2];
     unsigned passed = 0;
+    // filter mode: this lane's four query columns' thresholds, loaded and waited for BEFORE the first DMA (an
+    // ordinary load result used while DMAs are in flight would make hipcc wait vmcnt(0) in the loop)
+    float tq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                tq[q][cb] = tau_q[q * 128 + wn * 32 + cb * 16 + (lane & 15)];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                asm volatile("" : "+v"(tq[q][cb]));
+    }
 
     // prologue: half-tiles 0..6 in flight, then K-tile 0 (0..3) retired
 #pragma unroll
@@ -159,6 +183,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const char *__restrict__ A, 
                                     const uint32_t row = tile * 256 + h * 128 + wm * 64 + rb * 16 + 4 * (lane >> 4) + j;
                                     const uint32_t qi = q * 128 + wn * 32 + cb * 16 + (lane & 15);
                                     C[static_cast<size_t>(qi) * ldc + row] = v;
+                                } else if constexpr (MODE == 2) {
+                                    const uint32_t row = tile * 256 + h * 128 + wm * 64 + rb * 16 + 4 * (lane >> 4) + j;
+                                    if (v >= tq[q][cb] && row < n_rows) { // rare: the atomic's return drains the DMAs
+                                        const uint32_t qi = q * 128 + wn * 32 + cb * 16 + (lane & 15);
+                                        const uint32_t slot = atomicAdd(&st[qi].n_cand, 1u);
+                                        if (slot < st[qi].cap)
+                                            cand[static_cast<size_t>(qi) * cand_stride + slot] = rlr::pack_result(v, row);
+                                    }
                                 } else {
                                     passed += v > tau;
                                 }
@@ -168,7 +200,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const char *__restrict__ A, 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the tail's dummy DMAs must land before the LDS is handed back
-    if (!MATERIALISE && passed)
+    if (MODE == 0 && passed)
         atomicAdd(count, passed);
 }
 
@@ -187,8 +219,9 @@ int main(int argc, char **argv)
 {
     using namespace rlr;
     const uint32_t K = 768, T = K / 64, NQ = 256, pitch16 = K * 2 / 16;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kHalfBytes));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kHalfBytes));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kHalfBytes));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kHalfBytes));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm8_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kHalfBytes));
     std::vector<float> hq(static_cast<size_t>(NQ) * K);
     srand(11);
     for (auto &v : hq) v = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
@@ -214,8 +247,9 @@ int main(int argc, char **argv)
         int bad_total = 0;
         for (int rep = 0; rep < 10; ++rep) {
             CK(hipMemset(dC, 0xFF, c.size() * 4));
-            hipLaunchKernelGGL(gemm8_kernel<true>, dim3(2), dim3(512), 8 * kHalfBytes, 0, static_cast<const char *>(dImg),
-                               static_cast<const char *>(dQfrag), tiles, T, 0.0f, dC, ldc, nullptr);
+            hipLaunchKernelGGL(gemm8_kernel<1>, dim3(2), dim3(512), 8 * kHalfBytes, 0, static_cast<const char *>(dImg),
+                               static_cast<const char *>(dQfrag), tiles, T, 0.0f, dC, ldc, nullptr, nullptr, nullptr, 0u,
+                               nullptr, n);
             CK(hipGetLastError());
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost));
@@ -230,6 +264,52 @@ int main(int argc, char **argv)
             bad_total += bad;
         }
         printf("check against launch_gemm_nominate: %s\n", bad_total ? "FAILED" : "ok (10 runs)");
+        // filter mode: thresholds midway between each query's 20th and 21st best reference score -> both kernels must
+        // collect the same 20 rows per query (order within a list is arbitrary: compare as sets)
+        {
+            std::vector<float> tau(NQ);
+            for (uint32_t q = 0; q < NQ; ++q) {
+                std::vector<float> v(ref.begin() + static_cast<size_t>(q) * ldc, ref.begin() + static_cast<size_t>(q) * ldc + n);
+                std::sort(v.begin(), v.end(), std::greater<float>());
+                tau[q] = 0.5f * (v[19] + v[20]);
+            }
+            const uint32_t cap = 64;
+            float *dTau; uint64_t *dCand[2]; SelectState *dSt[2];
+            CK(hipMalloc(&dTau, NQ * 4)); CK(hipMemcpy(dTau, tau.data(), NQ * 4, hipMemcpyHostToDevice));
+            std::vector<SelectState> st(NQ);
+            memset(st.data(), 0, st.size() * sizeof(SelectState));
+            for (auto &x : st) x.cap = cap;
+            for (int w = 0; w < 2; ++w) {
+                CK(hipMalloc(&dCand[w], static_cast<size_t>(NQ) * cap * 8)); CK(hipMemset(dCand[w], 0, static_cast<size_t>(NQ) * cap * 8));
+                CK(hipMalloc(&dSt[w], NQ * sizeof(SelectState)));
+                CK(hipMemcpy(dSt[w], st.data(), NQ * sizeof(SelectState), hipMemcpyHostToDevice));
+            }
+            CK(launch_gemm_nominate(dRows, pitch16, K, 1, 0, n, dQfrag, NQ, dTau, dCand[0], cap, dSt[0], nullptr, 0, dImg, nullptr));
+            hipLaunchKernelGGL(gemm8_kernel<2>, dim3(2), dim3(512), 8 * kHalfBytes, 0, static_cast<const char *>(dImg),
+                               static_cast<const char *>(dQfrag), tiles, T, 0.0f, nullptr, 0u, nullptr, dTau, dCand[1], cap, dSt[1], n);
+            CK(hipGetLastError());
+            CK(hipDeviceSynchronize());
+            std::vector<uint64_t> hc[2]; std::vector<SelectState> hs[2];
+            for (int w = 0; w < 2; ++w) {
+                hc[w].resize(static_cast<size_t>(NQ) * cap); hs[w].resize(NQ);
+                CK(hipMemcpy(hc[w].data(), dCand[w], hc[w].size() * 8, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hs[w].data(), dSt[w], NQ * sizeof(SelectState), hipMemcpyDeviceToHost));
+            }
+            int badf = 0;
+            for (uint32_t q = 0; q < NQ; ++q) {
+                std::vector<uint32_t> rows[2];
+                for (int w = 0; w < 2; ++w) {
+                    for (uint32_t i = 0; i < std::min(hs[w][q].n_cand, cap); ++i) {
+                        float sc; uint32_t r; unpack_result(hc[w][static_cast<size_t>(q) * cap + i], &sc, &r);
+                        rows[w].push_back(r);
+                    }
+                    std::sort(rows[w].begin(), rows[w].end());
+                }
+                if (rows[0] != rows[1] || rows[0].size() != 20) { if (badf < 3) printf("  filter q %u: library %zu rows, 8-phase %zu rows\n", q, rows[0].size(), rows[1].size()); ++badf; }
+            }
+            printf("filter-mode candidate sets: %s\n", badf ? "FAILED" : "identical (20 rows per query)");
+            bad_total += badf;
+        }
         (void)hipFree(dRows); (void)hipFree(dImg); (void)hipFree(dC); (void)hipFree(dRef);
         if (bad_total) return 1;
     }
@@ -259,8 +339,9 @@ int main(int argc, char **argv)
         for (int rep = 0; rep < 8; ++rep) {
             float ms8 = 0, msl = 0;
             CK(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL(gemm8_kernel<false>, dim3(grid), dim3(512), 8 * kHalfBytes, 0, static_cast<const char *>(dImg),
-                               static_cast<const char *>(dQfrag), tiles, T, 1e30f, nullptr, 0, dCount);
+            hipLaunchKernelGGL(gemm8_kernel<0>, dim3(grid), dim3(512), 8 * kHalfBytes, 0, static_cast<const char *>(dImg),
+                               static_cast<const char *>(dQfrag), tiles, T, 1e30f, nullptr, 0, dCount, nullptr, nullptr, 0u,
+                               nullptr, n);
             CK(hipGetLastError());
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms8, e0, e1));
             CK(hipEventRecord(e0, 0));
