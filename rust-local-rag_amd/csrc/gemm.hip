@@ -499,6 +499,325 @@ __global__ __launch_bounds__(512) void gemm_image_kernel(const GemmArgs a, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// The batched main kernel: 8-phase LDS-DMA GEMM over the image (the guide's 256 x 256 x 64 structure).
+//
+// Workgroup = 8 waves as 2 (rows) x 4 (queries); tile = 256 rows x 256 queries; a wave owns 128 x 64 = 32 accumulator
+// tiles of v_mfma_f32_16x16x32_f16.  BOTH operands reach LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR hop): a
+// K-tile (64 k) is four 16 KiB half-tiles consumed in the order A0, B0, B1, A1 (A half h = rows h*128..+127 of the
+// tile, B half = queries hq*128..+127); half-tile s of the workgroup's stream lives in slot s & 7 and is staged 7
+// phases ahead by two DMAs per thread.  Phase p of a K-tile multiplies quadrant (A0,B0), (A0,B1), (A1,B1), (A1,B0):
+// 16 MFMAs per wave between two raw s_barriers.  `s_waitcnt vmcnt(6)` once per K-tile (phase 3, after that phase's
+// DMAs were issued) retires everything the next K-tile reads and leaves three half-tiles in flight -- never
+// __syncthreads() in the loop, its fence would drain the DMAs with vmcnt(0).  Both layouts are already fragment-major
+// (image: [tile][K-chunk][row block 16][k-step 2][lane]; queries: [qblock][k-step][col block 16][lane]), so every DMA
+// destination and every ds_read_b128 is lane-linear: no swizzle, no bank conflicts.
+//   RAW: a slot is read one phase after the vmcnt + barrier that retires it.  WAR: a slot is restaged >= 1 phase after
+//   its last ds_read, behind the reading phase's lgkmcnt(0) and closing barrier.  Extra vector-memory operations in the
+//   stream (threshold DMA, candidate stores, atomics) are OLDER than the three half-tiles a wait leaves in flight, so
+//   they only make a wait longer, never shorter.
+// Persistent: the grid is one workgroup per CU; a workgroup walks "units" = (row tile, query block of 256).  The units
+// of one row tile (n_queries > 256) are consecutive entries of ONE XCD's work list and run on adjacent workgroups of
+// that XCD at the same time, so the tile's second..fourth read hits that XCD's L2 (speed only, never correctness).
+// Epilogue (filter mode): thresholds of the unit arrive by a 4-byte LDS-DMA at its first phase; an accumulator that
+// passes is appended to a workgroup-local LDS list (ds_add_rtn: no global atomic, no vmcnt drain, in the loop); the
+// list is flushed to the per-query candidate lists -- one returning global atomic per entry, all lanes at once --
+// when it is half full and at the end.  Measured (scratch/gemm_next/gemm8_abl.hip, 256 queries x 10 M x 768): the
+// loop is POWER-bound, not issue- or HBM-bound: MFMA alone 2.35 ms at 1.89 GHz, MFMA + LDS reads 3.0 ms at 1.72 GHz,
+// with the DMA stream 3.5-3.7 ms at 1.5-1.6 GHz on every schedule variant tried (staggered wave halves, s_setprio,
+// role-split rings with 10 phases of HBM lookahead, nt loads): time = energy / power cap.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHalfBytes = 16384;                 // one half-tile: 128 rows (or queries) x 64 k x 2 B
+constexpr uint32_t kG8ListCap = 2048;             // workgroup-local candidate list (entries)
+constexpr int kG8OffPack = 8 * kHalfBytes;        // u64[kG8ListCap]
+constexpr int kG8OffQid = kG8OffPack + kG8ListCap * 8;   // u32[kG8ListCap]
+constexpr int kG8OffTau = kG8OffQid + kG8ListCap * 4;    // f32[2][256]
+constexpr int kG8OffCnt = kG8OffTau + 2 * 256 * 4;       // u32
+constexpr int kG8LdsBytes = kG8OffCnt + 64;
+
+#define RLR_GLDS16(src, dst)                                                                               \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),                \
+                                     (__attribute__((address_space(3))) void *)(dst), 16, 0, 0)
+#define RLR_FENCE() asm volatile("" ::: "memory")
+
+// LDS writes of the epilogue as inline asm: hipcc orders every LDS *store* it can see behind the LDS-DMAs in flight
+// with s_waitcnt vmcnt(0) (they might write the same bytes; these never do), which would drain the staging pipeline
+// once per unit.  Addresses are byte offsets into LDS.
+__device__ __forceinline__ uint32_t lds_add_rtn_u32(uint32_t addr, uint32_t v)
+{
+    uint32_t r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr), "v"(v) : "memory");
+    return r;
+}
+__device__ __forceinline__ uint32_t lds_read_b32(uint32_t addr)
+{
+    uint32_t r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_write_b64(uint32_t addr, uint64_t v)
+{
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write_b32(uint32_t addr, uint32_t v)
+{
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+template <bool MATERIALISE>
+__global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char *__restrict__ image, uint32_t n_tiles)
+{
+    __shared__ __attribute__((aligned(1024))) char lds[kG8LdsBytes];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const uint32_t T = a.n_ksteps / 2; // K-tiles of 64 (even: dim % 128 == 0)
+    const uint32_t nqb = a.n_qblocks;
+
+    // this workgroup's units: entry s = j + it * J of XCD group (blockIdx % 8)'s list, s -> (tile = (s / nqb) * 8 + xcd, s % nqb)
+    const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3, J = gridDim.x >> 3;
+    const uint32_t n_tl = n_tiles > xcd ? (n_tiles - xcd + 7) / 8 : 0;
+    const uint32_t n_units = n_tl * nqb;
+    const uint32_t n_it = n_units > j ? (n_units - j + J - 1) / J : 0;
+    if (n_it == 0)
+        return;
+    const uint32_t n_phase = n_it * 4 * T; // = half-tiles of this workgroup
+    const uint32_t tile_img0 = a.row_begin / kBM;
+    const size_t qb_bytes = static_cast<size_t>(a.n_ksteps) * kNB * 1024; // one query block's fragments
+    const char *qfrag = reinterpret_cast<const char *>(a.qfrag);
+
+    // staging cursor (wave-uniform): half-tile (s_it, s_t, s_i) of the stream, source bases of unit s_it
+    uint32_t s_it = 0, s_t = 0, s_i = 0, s_slot = 0;
+    const char *s_abase = nullptr, *s_bbase = nullptr;
+    auto set_stage_unit = [&](uint32_t it) {
+        const uint32_t s = j + it * J;
+        const uint32_t tile = (s / nqb) * 8 + xcd;
+        s_abase = image + static_cast<size_t>(tile_img0 + tile) * T * (2 * kHalfBytes);
+        s_bbase = qfrag + static_cast<size_t>(s % nqb) * qb_bytes;
+    };
+    set_stage_unit(0);
+    auto stage = [&]() {
+        const bool is_a = s_i == 0 || s_i == 3;
+        char *dst = lds + s_slot * kHalfBytes + wave * 1024;
+        // A half: 16 KiB contiguous; B half: k-steps 2t and 2t+1 of col blocks hq*8..+7 = two 8 KiB pieces 16 KiB apart
+        const char *src = is_a ? s_abase + (static_cast<size_t>(s_t) * 2 + (s_i == 3)) * kHalfBytes
+                               : s_bbase + (static_cast<size_t>(s_t) * 2 * 16 + (s_i == 2) * 8) * 1024;
+        const uint32_t second = is_a ? 8192u : 16384u;
+        RLR_GLDS16(src + tid * 16, dst);
+        RLR_GLDS16(src + second + tid * 16, dst + 8192);
+        s_slot = (s_slot + 1) & 7;
+        if (++s_i == 4) {
+            s_i = 0;
+            if (++s_t == T) {
+                s_t = 0;
+                if (++s_it < n_it) // past the end: the last unit again, into slots nobody reads any more
+                    set_stage_unit(s_it);
+            }
+        }
+    };
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    acc[h][q][rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    half8 fa[2][4], fb[2][2][2];
+
+    uint32_t *l_cnt = reinterpret_cast<uint32_t *>(lds + kG8OffCnt);
+    uint64_t *l_pack = reinterpret_cast<uint64_t *>(lds + kG8OffPack);
+    uint32_t *l_qid = reinterpret_cast<uint32_t *>(lds + kG8OffQid);
+    const float *l_tau = reinterpret_cast<const float *>(lds + kG8OffTau);
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) char *)lds));
+    if (tid == 0)
+        *l_cnt = 0;
+
+    // thresholds of unit `it` -> l_tau[it & 1] (4 bytes per lane; waves 4-7 repeat waves 0-3, so every wave issues the
+    // same number of vector-memory operations)
+    auto tau_dma = [&](uint32_t it, uint32_t ln) {
+        if constexpr (!MATERIALISE) {
+            const uint32_t s = j + it * J;
+            const uint32_t q = min((s % nqb) * kQB + (wave & 3) * 64 + ln, a.n_queries - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.tau + q),
+                                             (__attribute__((address_space(3))) void *)(lds + kG8OffTau + (it & 1) * 1024 +
+                                                                                       (wave & 3) * 256),
+                                             4, 0, 0);
+        }
+    };
+
+    // prologue: half-tiles 0..6 in flight, then K-tile 0 (0..3) retired
+    tau_dma(0, lane);
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+        stage();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    RLR_FENCE();
+
+    const half8 *L = reinterpret_cast<const half8 *>(lds);
+    constexpr int kSlotH8 = kHalfBytes / 16; // half8 entries per slot
+    uint32_t kt = 0, it = 0;                 // K-tile / unit being consumed
+
+#define RLR_READ_A(SLOT)                                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)         \
+        fa[ks][rb] = L[(SLOT) * kSlotH8 + ((wm * 4 + rb) * 2 + ks) * 64 + lane];
+#define RLR_READ_B(SLOT, HQ)                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)         \
+        fb[HQ][ks][cb] = L[(SLOT) * kSlotH8 + (ks * 8 + wn * 2 + cb) * 64 + lane];
+#define RLR_COMPUTE(H, HQ)                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)         \
+        _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                      \
+            acc[H][HQ][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][rb], fb[HQ][ks][cb], acc[H][HQ][rb][cb], 0, 0, 0);
+#define RLR_PHASE_HEAD(WAIT)                                                                                 \
+    stage();                                                                                                 \
+    if (WAIT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                              \
+    RLR_FENCE();                                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define RLR_PHASE_TAIL()                                                                                     \
+    RLR_FENCE();                                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    RLR_FENCE();
+#define RLR_KTILE(KP)                                                                                        \
+    RLR_READ_B((KP) * 4 + 1, 0)                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    RLR_READ_A((KP) * 4 + 0)                                                                                 \
+    RLR_PHASE_HEAD(false) RLR_COMPUTE(0, 0) RLR_PHASE_TAIL()                                                 \
+    RLR_READ_B((KP) * 4 + 2, 1)                                                                              \
+    RLR_PHASE_HEAD(false) RLR_COMPUTE(0, 1) RLR_PHASE_TAIL()                                                 \
+    RLR_READ_A((KP) * 4 + 3)                                                                                 \
+    RLR_PHASE_HEAD(false) RLR_COMPUTE(1, 1) RLR_PHASE_TAIL()                                                 \
+    RLR_PHASE_HEAD(true) RLR_COMPUTE(1, 0) RLR_PHASE_TAIL()
+
+    // candidate -> the query's global list (slow path: list overflow, and the flush)
+    auto append_global = [&](uint32_t q, uint64_t pk) {
+        const uint32_t slot = atomicAdd(&a.st[q].n_cand, 1u);
+        if (slot < a.st[q].cap)
+            a.cand[static_cast<size_t>(q) * a.cand_stride + slot] = pk;
+    };
+
+#pragma unroll 1
+    for (uint32_t g = 0; g < n_phase; g += 8) {
+        RLR_KTILE(0)
+        RLR_KTILE(1)
+        kt += 2;
+        if (kt == T) { // a unit is complete: consume the accumulators, start the next one
+            kt = 0;
+            const uint32_t s = j + it * J;
+            const uint32_t tile = (s / nqb) * 8 + xcd, qb = s % nqb;
+            // everything the epilogue derives from the lane id is recomputed here, once per unit, from an opaque copy:
+            // hoisted out of the loop (hipcc does that) those values stay live across the main loop, whose 192
+            // accumulator and fragment registers leave no room for them (256 VGPRs + a spill otherwise)
+            uint32_t lane_e = static_cast<uint32_t>(lane);
+            asm volatile("" : "+v"(lane_e));
+            const uint32_t row0 = a.row_begin + tile * kBM + wm * 64 + 4 * (lane_e >> 4);
+            const uint32_t last_row = a.row_end - 1;
+            const uint32_t q0 = qb * kQB + wn * 32 + (lane_e & 15);
+            if constexpr (MATERIALISE) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                            for (int cb = 0; cb < 2; ++cb) {
+                                const f32x4 v = acc[h][q][rb][cb];
+                                const uint32_t r = row0 + h * 128 + rb * 16;
+                                const uint32_t qi = q0 + q * 128 + cb * 16;
+                                if (qi < a.n_queries && r <= last_row) {
+                                    float *dst = a.scores + static_cast<size_t>(qi) * a.score_stride + (r - a.row_begin);
+                                    if (r + 3 <= last_row) {
+                                        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                                    } else {
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i)
+                                            if (r + i <= last_row)
+                                                dst[i] = v[i];
+                                    }
+                                }
+                                acc[h][q][rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
+            } else {
+                float tq[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        const uint32_t ql = q * 128 + wn * 32 + cb * 16 + (lane_e & 15);
+                        const float t = l_tau[(it & 1) * 256 + ql];
+                        tq[q][cb] = qb * kQB + ql < a.n_queries ? t : __builtin_inff();
+                    }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                            for (int cb = 0; cb < 2; ++cb) {
+                                const f32x4 v = acc[h][q][rb][cb];
+                                const float t = tq[q][cb];
+                                if (v[0] >= t || v[1] >= t || v[2] >= t || v[3] >= t) {
+                                    const uint32_t r = row0 + h * 128 + rb * 16;
+                                    const uint32_t qi = q0 + q * 128 + cb * 16;
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) {
+                                        if (v[i] >= t && r + i <= last_row) {
+                                            const uint64_t pk = pack_result(v[i], r + i);
+                                            const uint32_t slot = lds_add_rtn_u32(lds_base + kG8OffCnt, 1u);
+                                            if (slot < kG8ListCap) {
+                                                lds_write_b64(lds_base + kG8OffPack + slot * 8, pk);
+                                                lds_write_b32(lds_base + kG8OffQid + slot * 4, qi);
+                                            } else {
+                                                // list full (> 1024 hits of one unit: a threshold gone wrong): the query is
+                                                // marked overflowed and goes back to the single-query pipeline (no-return
+                                                // atomic: nothing to wait for)
+                                                atomicOr(&a.st[qi].n_cand, 0x80000000u);
+                                            }
+                                        }
+                                    }
+                                }
+                                acc[h][q][rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
+                // flush the workgroup's list when it is half full, and after the last unit
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RLR_FENCE();
+                __builtin_amdgcn_s_barrier();
+                RLR_FENCE();
+                const uint32_t cnt = lds_read_b32(lds_base + kG8OffCnt);
+                if (cnt >= kG8ListCap / 2 || (it + 1 == n_it && cnt > 0)) {
+                    const uint32_t n_list = min(cnt, kG8ListCap);
+                    for (uint32_t i = tid; i < n_list; i += 512)
+                        append_global(l_qid[i], l_pack[i]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    RLR_FENCE();
+                    __builtin_amdgcn_s_barrier();
+                    RLR_FENCE();
+                    if (tid == 0)
+                        lds_write_b32(lds_base + kG8OffCnt, 0u);
+                }
+            }
+            ++it;
+            if (it < n_it)
+                tau_dma(it, lane_e);
+        }
+    }
+#undef RLR_KTILE
+#undef RLR_PHASE_TAIL
+#undef RLR_PHASE_HEAD
+#undef RLR_COMPUTE
+#undef RLR_READ_B
+#undef RLR_READ_A
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the tail's dummy DMAs must land before the LDS is handed back
+}
+
+// ---------------------------------------------------------------------------------------------
 // Single-query scan over the image: the HBM-bound scan of scan.hip at half the bytes.  The image is a
 // binary16 copy of the rows, so a query that only needs NOMINATED scores (the exact re-score reads the
 // f32 rows of the few candidates) can stream 2 B per element instead of 4.  A wave owns one (tile, wave)
@@ -920,6 +1239,40 @@ hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pi
     return hipGetLastError();
 }
 
+static bool use_gemm8()
+{
+    static const bool on = [] {
+        const char *v = getenv("RLR_GEMM8"); // A/B switch: 0 = the round-1 register-staged image kernel
+        return !(v && v[0] == '0');
+    }();
+    return on;
+}
+
+// can a batch over `dim`-wide rows run over the nomination image?  (the caller prepares the query fragments in the
+// image's natural k order only then)
+bool gemm_image_usable(uint32_t dim)
+{
+    if (dim % 64 != 0)
+        return false;
+    return use_gemm8() ? (dim / 64) % 2 == 0 : (dim / 64) % 4 == 0;
+}
+
+// one workgroup per CU of the current device, rounded down to a multiple of 8 (the XCD round-robin of the unit lists)
+static uint32_t persistent_grid()
+{
+    static uint32_t cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+            n = 256;
+        cus[dev] = static_cast<uint32_t>(n) / 8 * 8;
+    }
+    return cus[dev];
+}
+
 hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin,
                                 uint32_t row_end, const void *qfrag, uint32_t n_queries, const float *tau,
                                 uint64_t *cand, uint32_t cand_stride, SelectState *st, float *scores,
@@ -959,6 +1312,16 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
             hipLaunchKernelGGL((gemm_resident_kernel<true>), dim3(rgrid), dim3(512), 0, s, a, img, n_qg);
         else
             hipLaunchKernelGGL((gemm_resident_kernel<false>), dim3(rgrid), dim3(512), 0, s, a, img, n_qg);
+        return hipGetLastError();
+    }
+    if (use_gemm8() && image && row_begin % kBM == 0 && a.n_ksteps % 4 == 0) {
+        const uint32_t n_units = n_rt * a.n_qblocks;
+        const uint32_t g8 = std::max<uint32_t>(8, std::min<uint32_t>(persistent_grid(), (n_units + 7) / 8 * 8));
+        const char *img = static_cast<const char *>(image);
+        if (mat)
+            hipLaunchKernelGGL((gemm8_kernel<true>), dim3(g8), dim3(512), 0, s, a, img, n_rt);
+        else
+            hipLaunchKernelGGL((gemm8_kernel<false>), dim3(g8), dim3(512), 0, s, a, img, n_rt);
         return hipGetLastError();
     }
     if (image && row_begin % kBM == 0 && (a.n_ksteps / kKsChunk) % 4 == 0) {

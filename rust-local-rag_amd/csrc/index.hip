@@ -893,7 +893,7 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     RLR_HIP(hipMemsetAsync(c->d_bhist, 0, static_cast<size_t>(nq) * 2 * kHistBins * sizeof(uint32_t), s));
     RLR_HIP(hipMemsetAsync(c->d_bstatus, 0xFF, static_cast<size_t>(nq) * sizeof(uint32_t), s));
     if (timed) RLR_HIP(hipEventRecord(c->bev[0], s));
-    const bool use_image = ix->image_enabled && ix->d_image && (ix->dim / 64) % 4 == 0;
+    const bool use_image = ix->image_enabled && ix->d_image && gemm_image_usable(ix->dim);
     const void *image = use_image ? ix->d_image : nullptr;
     // the image stores k in natural order (like binary16 rows); only the direct f32-row loads permute it
     if (use_multi) {

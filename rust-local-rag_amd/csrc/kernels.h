@@ -74,6 +74,8 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
                                 size_t score_stride, const void *image, hipStream_t s);
 // optional binary16 nomination image of the corpus in GEMM-fragment order (see gemm.hip)
 size_t image_bytes(uint32_t dim, uint64_t n_rows);
+// whether launch_gemm_nominate serves rows of this width from the image (else it reads the row-major matrix)
+bool gemm_image_usable(uint32_t dim);
 // single-query nomination scan over the image (binary16, half the bytes of the f32 rows); dim % 64 == 0,
 // query = dim floats on the device; same outputs as launch_scan; error bound nomination_eps(dim, dtype)
 hipError_t launch_scan_image(const void *image, uint32_t n_rows, uint32_t dim, const float *query, float *scores,

@@ -780,6 +780,59 @@ def test_batch_image_same_results_and_tracks_mutation(rlr, oracle, dim, dtype):
     ix.close()
 
 
+@pytest.mark.parametrize("dim,dtype,n,nq,k", [
+    (768, "f32", 70_001, 130, 100),    # one query block, partly filled; ragged last row tile
+    (768, "f32", 300_000, 256, 100),   # sample + bootstrap + filtered main pass, every workgroup several units
+    (1024, "f16", 45_300, 300, 20),    # two query blocks (the second ragged): units of one tile on neighbouring workgroups
+    (384, "f32", 33_000, 520, 10),     # three query blocks; dim / 64 = 6 (not a multiple of 4: 8-phase kernel only)
+    (768, "f32", 5_000, 140, 100),     # fewer row tiles than workgroups
+])
+def test_batch_image_8phase_kernel(rlr, oracle, dim, dtype, n, nq, k):
+    """More than 128 queries over the nomination image take the persistent 8-phase LDS-DMA GEMM (gemm8_kernel):
+    rows and score bits equal to the oracle on a sample of the queries and to the single-query path on all."""
+    f16 = dtype == "f16"
+    rows = oracle.synth_rows(n, dim, seed=640, f16=f16)
+    qs = np.stack([oracle.normalize(oracle.synth_query(dim, seed=1500 + i)) for i in range(nq)])
+    ix = rlr.GpuIndex(dim, dtype)
+    ix.fill_synthetic(n, seed=640)
+    assert np.array_equal(ix.fetch_rows(np.arange(0, n, 997)).view(np.uint32), rows[::997].view(np.uint32))
+    ix.enable_batch_image(True)
+    ix.profile_read(reset=True)
+    r, c = ix.search_topk(qs, k)
+    prof = ix.profile_read()
+    assert prof.n_batches == 1 and prof.n_batch_queries == nq and prof.n_batch_fallbacks == 0
+    for i in list(range(0, nq, max(1, nq // 12))) + [nq - 1]:
+        wr, wc = oracle_topk(oracle, rows, qs[i], k)
+        assert np.array_equal(r[i], wr), f"query {i}: rows differ"
+        assert np.array_equal(bits(c[i]), bits(wc)), f"query {i}: scores differ"
+    ix.enable_batch_image(False)
+    for i in range(nq):
+        r1, c1 = ix.search_topk(qs[i], k)
+        assert np.array_equal(r1[0], r[i]) and np.array_equal(bits(c1[0]), bits(c[i])), i
+    ix.close()
+
+
+def test_batch_image_8phase_kernel_survives_a_candidate_flood(rlr, oracle):
+    """9000 copies of one chunk right at the top of one query's scores: its candidate list (and the workgroup-local
+    LDS list of the tiles holding the copies) overflow; that query goes back to the single-query pipeline, the other
+    queries of the batch are unaffected -- results still identical to the oracle."""
+    base = oracle.synth_rows(30_000, 768, seed=641)
+    q0 = oracle.synth_query(768, seed=642)
+    dup = oracle.normalize(q0 + np.float32(0.01) * base[0])
+    rows = np.concatenate([base[:20_000], np.repeat(dup[None, :], 9000, axis=0), base[20_000:]])
+    qs = np.stack([oracle.normalize(q0)] + [oracle.normalize(oracle.synth_query(768, seed=1700 + i)) for i in range(149)])
+    ix = make_index(rlr, rows)
+    ix.enable_batch_image(True)
+    ix.profile_read(reset=True)
+    r, c = ix.search_topk(qs, 10)
+    prof = ix.profile_read()
+    assert prof.n_batches == 1 and prof.n_batch_fallbacks >= 1
+    for i in [0, 1, 2, 77, 149]:
+        wr, wc = oracle_topk(oracle, rows, qs[i], 10)
+        assert np.array_equal(r[i], wr) and np.array_equal(bits(c[i]), bits(wc)), i
+    ix.close()
+
+
 # ---------------------------------------------------------------- one process, several shards
 def test_multi_index_three_shards_on_one_gpu(rlr, oracle):
     """rlr_multi_* with three shards that all live on GPU 0: concurrent per-shard searches from
