@@ -563,7 +563,9 @@ __device__ __forceinline__ void lds_write_b32(uint32_t addr, uint32_t v)
     asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-template <bool MATERIALISE>
+// VAR (tuning A/B inside one build, RLR_GEMM8_VARIANT): bit 0 = s_setprio pair around each MFMA cluster, bit 1 = no
+// sched_barrier behind the phase's lgkmcnt(0), bit 2 = non-temporal DMA for the once-read row half-tiles
+template <bool MATERIALISE, int VAR>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char *__restrict__ image, uint32_t n_tiles)
 {
     __shared__ __attribute__((aligned(1024))) char lds[kG8LdsBytes];
@@ -602,8 +604,15 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char
         const char *src = is_a ? s_abase + (static_cast<size_t>(s_t) * 2 + (s_i == 3)) * kHalfBytes
                                : s_bbase + (static_cast<size_t>(s_t) * 2 * 16 + (s_i == 2) * 8) * 1024;
         const uint32_t second = is_a ? 8192u : 16384u;
-        RLR_GLDS16(src + tid * 16, dst);
-        RLR_GLDS16(src + second + tid * 16, dst + 8192);
+        if ((VAR & 4) && is_a) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + tid * 16),
+                                             (__attribute__((address_space(3))) void *)(dst), 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + second + tid * 16),
+                                             (__attribute__((address_space(3))) void *)(dst + 8192), 16, 0, 2);
+        } else {
+            RLR_GLDS16(src + tid * 16, dst);
+            RLR_GLDS16(src + second + tid * 16, dst + 8192);
+        }
         s_slot = (s_slot + 1) & 7;
         if (++s_i == 4) {
             s_i = 0;
@@ -678,8 +687,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char
     RLR_FENCE();                                                                                             \
     __builtin_amdgcn_s_barrier();                                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-    __builtin_amdgcn_sched_barrier(0);
+    if (!(VAR & 2)) __builtin_amdgcn_sched_barrier(0);                                                       \
+    if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #define RLR_PHASE_TAIL()                                                                                     \
+    if (VAR & 1) __builtin_amdgcn_s_setprio(0);                                                              \
     RLR_FENCE();                                                                                             \
     __builtin_amdgcn_s_barrier();                                                                            \
     RLR_FENCE();
@@ -1318,10 +1329,23 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
         const uint32_t n_units = n_rt * a.n_qblocks;
         const uint32_t g8 = std::max<uint32_t>(8, std::min<uint32_t>(persistent_grid(), (n_units + 7) / 8 * 8));
         const char *img = static_cast<const char *>(image);
-        if (mat)
-            hipLaunchKernelGGL((gemm8_kernel<true>), dim3(g8), dim3(512), 0, s, a, img, n_rt);
-        else
-            hipLaunchKernelGGL((gemm8_kernel<false>), dim3(g8), dim3(512), 0, s, a, img, n_rt);
+        static const int var = [] {
+            const char *v = getenv("RLR_GEMM8_VARIANT");
+            return v ? static_cast<int>(strtol(v, nullptr, 0)) : 6; // same-box A/B: 6 is 2-4 % faster than 0, 1 is slower
+        }();
+#define RLR_G8(VAR)                                                                                           \
+    if (mat)                                                                                                  \
+        hipLaunchKernelGGL((gemm8_kernel<true, VAR>), dim3(g8), dim3(512), 0, s, a, img, n_rt);               \
+    else                                                                                                      \
+        hipLaunchKernelGGL((gemm8_kernel<false, VAR>), dim3(g8), dim3(512), 0, s, a, img, n_rt)
+        switch (var) {
+        case 1: RLR_G8(1); break;
+        case 2: RLR_G8(2); break;
+        case 4: RLR_G8(4); break;
+        case 0: RLR_G8(0); break;
+        default: RLR_G8(6); break;
+        }
+#undef RLR_G8
         return hipGetLastError();
     }
     if (image && row_begin % kBM == 0 && (a.n_ksteps / kKsChunk) % 4 == 0) {
