@@ -11,11 +11,14 @@ every input resident in HBM.  With N > 1 (launched by torch.distributed.run, one
 per GPU) the same 10M rows are sharded N ways and every step adds the RCCL all-gather of
 the per-shard partial top-k and the merge -- total work is fixed => "scaling": "strong".
 
-Rank 0 prints ONE JSON line (metric/value/unit/... + "roofline" + "cpu_baseline").
+Rank 0 prints ONE JSON line: metric/value/unit/... + "roofline" + "cpu_baseline" + (N = 1 only,
+measured outside the headline's timed region) "configs": BASELINE configs C2 / C3 / C5-share,
+each with its own roofline object.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -27,7 +30,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense binary16 / bf16 MFMA peak (same guide; never the 2:1-sparsity figure)
 
 
 def parse():
@@ -49,7 +53,8 @@ def parse():
                     help="keep the binary16 nomination image for the batched path (rlr_index_enable_batch_image)")
     ap.add_argument("--settle-ms", type=float, default=500.0,
                     help="untimed clock/power settle phase before the warmup steps (0 disables)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the informational optional-mode measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the informational measurements outside the timed region (optional_modes, configs)")
     ap.add_argument("--image-scan", action="store_true",
                     help="single queries nominate over the binary16 image too (half the scan bytes; same results)")
     ap.add_argument("--q8-scan", action="store_true",
@@ -70,8 +75,19 @@ def q8_kernel_name(dim):
     return "q8_scan_packed_kernel" if packed else "q8_scan_kernel"
 
 
+def batch_kernel_name(dim, nq, image):
+    """which GEMM csrc/gemm.hip launches for a batch (launch_gemm_nominate's dispatch)"""
+    if not image:
+        return "gemm_nominate_kernel"
+    if nq <= int(os.environ.get("RLR_GEMM_RESIDENT_MAX", "128")) and dim % 256 == 0 and dim <= 1152:
+        return "gemm_resident_kernel"
+    if os.environ.get("RLR_GEMM8", "1")[:1] != "0" and dim % 128 == 0:
+        return "gemm8_kernel"
+    return "gemm_image_kernel" if dim % 256 == 0 else "gemm_nominate_kernel"
+
+
 def pmc_traffic(bytes_per_launch, kernel):
-    """HBM bytes per launch of the scan kernel from the committed rocprofv3 --pmc passes of
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of
     this same command (profiles/rNN_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
     separate passes).  PMC counters cannot be read from inside the process, so the figure is
     quoted from the newest summary of the SAME kernel whose byte count matches this run's shape
@@ -91,11 +107,44 @@ def pmc_traffic(bytes_per_launch, kernel):
     return best
 
 
+def batched_roofline(prof, dim, nq, image):
+    """roofline object of the dominant launch of a batch (the filtered main GEMM pass), from the library's HIP
+    events on its own stream.  `bound` is the roof with the larger ideal time for this launch: the operand bytes
+    once at the HBM peak against 2*Q*rows*dim flops at the dense binary16 MFMA peak (both reported)."""
+    n = max(prof.n_batches, 1)
+    ms, b, fl = prof.batch_main_ms / n, prof.batch_main_bytes / n, prof.batch_main_flops / n
+    if ms <= 0:
+        return None
+    gbps, tflops = b / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
+    t_hbm, t_mfma = b / (HBM_PEAK_GBPS * 1e9), fl / (MFMA_F16_PEAK_TFLOPS * 1e12)
+    hbm = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS}
+    mfma = {"achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F16_PEAK_TFLOPS}
+    main = dict(mfma if t_mfma >= t_hbm else hbm)
+    main.update({"bound": "mfma" if t_mfma >= t_hbm else "hbm", "traffic": None,
+                 "kernel": batch_kernel_name(dim, nq, image) + " (the filtered main pass of a batch)",
+                 "kernel_ms": ms, "bytes_per_launch": b, "flops_per_launch": fl,
+                 "hbm": hbm, "mfma": mfma,
+                 "all_gemm_launches_ms": prof.batch_gemm_ms / n,
+                 "note": "binary16 MFMA nominates; emitted rows and scores are re-scored in f32 reference order"})
+    return main
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, rlr):
     """Times the oracle (CPU port of the reference loops) on a bounded sample of the same
     corpus: rows [0, cpu_rows) of the synthetic stream, full search (scan + stable sort +
-    take), 1 thread -- the reference's actual behaviour -- then the same arithmetic with
-    rows split over all host cores.  Extrapolated linearly to the full row count."""
+    take), 1 thread -- the reference's actual behaviour -- the scan alone (=> the sort's share), the same
+    arithmetic with rows split over all host cores, and the literal O(k^2 P) mmr_diversify loop on one
+    pool of 300 (rag_engine.rs:788-835).  Search figures are extrapolated linearly to the full row count."""
     from oracle import oracle as O  # checker / reported baseline only
 
     n = min(args.cpu_rows, args.rows)
@@ -112,37 +161,168 @@ def cpu_baseline(args, rlr):
     qn = O.normalize(q)
     t0 = time.perf_counter()
     for _ in range(reps):
+        O.scan(rows, qn, threads=1)
+    ts = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
         O.scan(rows, qn, threads=cores)
     tm = (time.perf_counter() - t0) / reps
+    # literal MMR loop: pool = the 300 best of the sample, k = 100, lambda = 0.3 (config C2's shape)
+    pool = O.search(rows, q, 300)
+    emb = np.ascontiguousarray(rows[np.asarray(pool[0], dtype=np.int64)])
+    t0 = time.perf_counter()
+    O.mmr(emb, np.asarray(pool[1], dtype=np.float32), 100, 0.3)
+    t_mmr = time.perf_counter() - t0
     scale = args.rows / n
     return {
         "value": 1.0 / (t1 * scale),
         "unit": "queries/s",
         "cores": 1,
         "kind": "port",
+        "cpu_model": cpu_model(),
         "sample": (f"oracle search (scan + stable sort + take) of 1 query over rows [0,{n}) of the same synthetic "
                    f"corpus, {t1 * 1e3:.0f} ms/query on 1 thread, extrapolated x{scale:.0f} to {args.rows} rows; "
                    f"contiguous matrix, no per-candidate clone (both favour the reference)"),
+        "scan_only_ms_on_sample": ts * 1e3,
+        "sort_and_take_ms_on_sample": max(t1 - ts, 0.0) * 1e3,
+        "sort_note": "full stable sort of all scored chunks as rag_engine.rs:543 does; = search - scan on the sample",
+        "mmr_1_thread": {"ms": t_mmr * 1e3, "pool": 300, "top_k": 100, "lambda": 0.3,
+                         "note": "literal mmr_diversify loop (rag_engine.rs:788-835), 1 156 650 dot products"},
         "all_cores": {"value": 1.0 / (tm * scale), "cores": cores,
                       "note": "scan only, rows split over threads; not something the reference does"},
         "sample_gen_s": round(gen_s, 2),
     }, rows, r1
 
 
+def source_sha16():
+    """sha256 over the sources librlr_gpu.so is built from (csrc/ + include/), first 16 hex digits"""
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "rust-local-rag_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            p = os.path.join(d, f)
+            if os.path.isfile(p):
+                h.update(f.encode())
+                h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def ensure_built():
-    """librlr_gpu.so normally travels with the tree; if it does not, compile it once (hipcc is a child
-    process, nothing here touches the GPU) -- one rank builds, the others wait on the lock."""
-    so = os.path.join(ROOT, "rust-local-rag_amd", "librlr_gpu.so")
-    if os.path.exists(so):
-        return
+    """Bring librlr_gpu.so up to date with csrc/ and include/ (build.py recompiles only what is stale: a no-op
+    when the shipped binary is fresh; hipcc is a child process, nothing here touches the GPU) -- one rank
+    builds, the others wait on the lock."""
     import fcntl
+
+    import __graft_entry__
 
     with open(os.path.join(ROOT, "rust-local-rag_amd", ".build.lock"), "w") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
-        if not os.path.exists(so):
-            import __graft_entry__
+        __graft_entry__._load_build_module().build()
 
-            __graft_entry__._load_build_module().build()
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE configs measured beside the headline (N = 1, outside its timed region)
+# ------------------------------------------------------------------------------------------------------
+def config_c3(rlr, ix, args, torch):
+    """C3: 10 M x 768 f32, 256 batched queries, top-100, over the nomination image (same index as the headline)."""
+    nq, steps = 256, 12
+    pool = queries_without_oracle(rlr, args.dim, nq + steps + 3, args.seed + 3)
+    ix.enable_batch_image(True)
+    try:
+        for i in range(3):
+            ix.search_topk(pool[i:i + nq], args.k)
+        ix.profile_read(reset=True)
+        ix.profile_enable(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ix.search_topk(pool[3 + i:3 + i + nq], args.k)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ix.profile_enable(False)
+        p = ix.profile_read()
+    finally:
+        ix.enable_batch_image(False)
+    return {"workload": f"C3: {len(ix)} chunks x {args.dim}-d f32, {nq} batched queries/step, top_k={args.k}, "
+                        f"nomination image (+dim*2 B/row)",
+            "value": steps * nq / el, "unit": "queries/s", "ms_per_batch": el / steps * 1e3,
+            "stages_ms": {"gemm_all_launches": p.batch_gemm_ms / max(p.n_batches, 1),
+                          "select_and_finish": p.batch_other_ms / max(p.n_batches, 1)},
+            "fallback_queries": p.n_batch_fallbacks, "roofline": batched_roofline(p, args.dim, nq, True)}
+
+
+def config_c2(rlr, torch):
+    """C2: 100 k x 768 f32, single query, top-100, MMR lambda 0.3: RagEngine.search_with_diversity."""
+    n, dim, k, lam, steps = 100_000, 768, 100, 0.3, 60
+    eng = rlr.RagEngine(dim)
+    try:
+        eng.index.fill_synthetic(n, seed=0x5EED0002, n_clusters=200)
+        eng._chunks = [rlr.DocumentChunk(str(i), "synthetic", "", i) for i in range(n)]
+        qs = queries_without_oracle(rlr, dim, steps + 5, 0x5EED0002)
+        for i in range(5):
+            eng.search_with_diversity(qs[i], k, lam)
+        eng.index.profile_read(reset=True)
+        eng.index.profile_enable(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            res = eng.search_with_diversity(qs[5 + i], k, lam)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        eng.index.profile_enable(False)
+        p = eng.index.profile_read()
+    finally:
+        eng.close()
+    ns = max(p.n_scan_launches, 1)
+    scan_ms = p.scan_ms / ns
+    kern = {"scan": scan_ms, "select": p.select_ms / ns, "rescore_sort": p.rescore_ms / ns,
+            "mmr_gather_gram_greedy": p.mmr_ms / max(p.n_mmr, 1)}
+    b = n * dim * 4
+    gbps = b / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    return {"workload": f"C2: {n} chunks x {dim}-d f32, 1 query/step, top_k={k}, MMR lambda={lam} "
+                        f"(pool 300 -> {k}); search_with_diversity through the engine ABI",
+            "value": steps / el, "unit": "queries/s", "ms_per_query": el / steps * 1e3,
+            "kernels_ms": kern, "kernel_sum_ms": sum(kern.values()), "results_per_query": len(res),
+            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": gbps / HBM_PEAK_GBPS, "traffic": None, "kernel": "scan_fixed_kernel",
+                         "kernel_ms": scan_ms, "bytes_per_launch": b,
+                         "note": "307 MB per launch: launch-latency-limited, not bandwidth-limited (SURVEY 8(d))"}}
+
+
+def config_c5_share(rlr, torch):
+    """One GPU's share of C5: 6.25 M x 1024 binary16 rows (50 M / 8), 1024 batched queries, top-100, MMR 0.7."""
+    n, dim, nq, k, lam = 6_250_000, 1024, 1024, 100, 0.7
+    eng = rlr.RagEngine(dim, "f16")
+    try:
+        eng.index.fill_synthetic(n, seed=0x5EED0005, n_clusters=500)
+        eng._chunks = [None] * n
+        eng.index.enable_batch_image(True)
+        qs = queries_without_oracle(rlr, dim, nq, 0x5EED0005)
+        ix = eng.index
+        pool = max(3 * k, k + 10)
+        ix.search_topk(qs[:256], pool + 8)
+        ix.profile_read(reset=True)
+        ix.profile_enable(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r, c = ix.search_topk(qs, pool + 8)                       # what search_with_diversity_batch fetches
+        torch.cuda.synchronize()
+        t_search = time.perf_counter() - t0
+        sc = (np.float32(0.7) * c[:, :pool]).astype(np.float32)
+        t0 = time.perf_counter()
+        ix.mmr_select_batch(np.ascontiguousarray(r[:, :pool]), sc, np.full(nq, pool, np.uint32), k, lam)
+        torch.cuda.synchronize()
+        t_mmr = time.perf_counter() - t0
+        ix.profile_enable(False)
+        p = ix.profile_read()
+    finally:
+        eng.close()
+    return {"workload": f"C5 per-GPU share: {n} chunks x {dim}-d binary16, {nq} batched queries, top_k={k}, "
+                        f"MMR lambda={lam} (pool {pool}); nomination image",
+            "value": nq / (t_search + t_mmr), "unit": "queries/s",
+            "stages_ms": {"batched_search_pool308": t_search * 1e3, "batched_mmr": t_mmr * 1e3,
+                          "gemm_all_launches": p.batch_gemm_ms, "select_and_finish": p.batch_other_ms,
+                          "mmr_kernels": p.mmr_ms},
+            "fallback_queries": p.n_batch_fallbacks, "roofline": batched_roofline(p, dim, nq, True)}
 
 
 def main():
@@ -218,9 +398,10 @@ def main():
         ix.enable_batch_image(args.image or args.image_scan, single_query=args.image_scan, q8=args.q8_scan)
 
     force_sharded = os.environ.get("RLR_BENCH_FORCE_SHARDED") == "1" or force_dist  # rehearse the N>1 code path on one GPU
+    use_sharded = world > 1 or force_sharded
 
     def step(i):
-        if world == 1 and not force_sharded:
+        if not use_sharded:
             return ix.search_topk(qs[i], args.k)
         return sh.search_topk(qs[i], args.k)
 
@@ -244,6 +425,7 @@ def main():
 
     ix.profile_read(reset=True)
     ix.profile_enable(not args.no_profile)  # HIP events around each stage, on the stream the kernels run on
+    sh.time_exchange(use_sharded and not args.no_profile)  # torch events around all-gather + merge, on torch's stream
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -257,6 +439,8 @@ def main():
     elapsed = time.perf_counter() - t0
     ix.profile_enable(False)
     prof = ix.profile_read()
+    exchange_ms = sh.exchange_ms_per_step()
+    sh.time_exchange(False)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -312,20 +496,16 @@ def main():
         "candidates_per_query": prof.n_candidates / max(prof.n_searches, 1),
         "band_retries": prof.n_retries,
         "fill_s": round(fill_s, 2),
+        "build_source_sha16": source_sha16(),
     }
+    if use_sharded:
+        # the exchange step of SURVEY 8(e): all-gather of world x k packed results + merge kernel, per step
+        out["stages_ms"]["allgather_merge"] = exchange_ms
     if batched and prof.n_batches:
-        gemm_ms = prof.batch_gemm_ms / prof.n_batches
-        passes = (args.batch + 255) // 256
-        b_bytes = passes * bytes_per_launch
-        out["roofline"] = {
-            "bound": "hbm", "achieved": b_bytes / (gemm_ms * 1e-3) / 1e9 if gemm_ms > 0 else 0.0, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": (b_bytes / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if gemm_ms > 0 else 0.0,
-            "traffic": None, "kernel": "gemm_nominate_kernel (both launches of a batch: sample + filter)",
-            "bytes_per_launch": b_bytes, "kernel_ms": gemm_ms,
-            "mfma": {"achieved_tflops": prof.batch_gemm_flops / prof.n_batches / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
-                     "peak_tflops_f16_dense": 2500.0, "note": "f16 MFMA nominates; results re-scored in f32 reference order"},
-        }
-        out["stages_ms"] = {"gemm": gemm_ms, "select_and_finish": prof.batch_other_ms / prof.n_batches}
+        out["roofline"] = batched_roofline(prof, args.dim, args.batch, args.image) or out["roofline"]
+        out["stages_ms"] = {"gemm_all_launches": prof.batch_gemm_ms / prof.n_batches,
+                            "gemm_main_pass": prof.batch_main_ms / prof.n_batches,
+                            "select_and_finish": prof.batch_other_ms / prof.n_batches}
         out["band_retries"] = prof.n_batch_fallbacks
         out["dtype"] = f"{args.dtype} rows, f16 MFMA nomination + f32 reference-order re-score"
     if q8_scan and not batched:
@@ -339,10 +519,10 @@ def main():
     t = pmc_traffic(bytes_per_launch, out["roofline"]["kernel"]) if not batched else None
     if t:
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t[0], f"profiles/{t[1]} (rocprofv3 --pmc)"
+    extras = world == 1 and not batched and not args.image_scan and not args.q8_scan and not args.no_extras
     # Informational, outside the timed region above: the same workload with the opt-in nomination copies (identical
     # results, the scan streams a half / a quarter of the bytes).  Never the headline `value`.
-    if (world == 1 and not batched and not args.image_scan and not args.q8_scan and not args.no_extras
-            and args.dtype == "f32" and args.dim % 64 == 0 and n_local * args.dim * 3 < 100e9):
+    if extras and args.dtype == "f32" and args.dim % 64 == 0 and n_local * args.dim * 3 < 100e9:
         out["optional_modes"] = {}
         modes = [("image_scan", dict(on=True, single_query=True), 2, "scan_image_kernel",
                   "single queries nominate over the binary16 image (rlr_index_enable_batch_image(idx, 3)); "
@@ -378,6 +558,15 @@ def main():
             except Exception as e:  # never let the extra measurement take the headline line down
                 out["optional_modes"][name] = {"error": str(e)}
             ix.enable_batch_image(False)
+    # BASELINE's other single-GPU configurations, each with its own roofline, outside the timed region too
+    if extras and args.dtype == "f32" and args.dim == 768 and args.rows == 10_000_000:
+        out["configs"] = {}
+        for name, fn in (("C3_256_batched_queries", lambda: config_c3(rlr, ix, args, torch)),
+                         ("C2_100k_mmr", lambda: config_c2(rlr, torch))):
+            try:
+                out["configs"][name] = fn()
+            except Exception as e:
+                out["configs"][name] = {"error": str(e)}
     if world == 1 and not args.no_cpu and O is not None:
         base, sample_rows, want = cpu_baseline(args, rlr)
         out["cpu_baseline"] = base
@@ -389,8 +578,16 @@ def main():
                 ok = bool(np.array_equal(r[0], want[0]) and
                           np.array_equal(c[0].view(np.uint32), want[2].view(np.uint32)))
             out["parity_check"] = {"rows": int(sample_rows.shape[0]), "top_k_identical_and_scores_bit_equal": ok}
+        del sample_rows
     else:
         out["cpu_baseline"] = None
+    if "configs" in out:
+        # the C5 share needs 12.8 GB of rows + 12.8 GB of image: after the headline corpus is gone
+        sh.index.close()
+        try:
+            out["configs"]["C5_per_gpu_share"] = config_c5_share(rlr, torch)
+        except Exception as e:
+            out["configs"]["C5_per_gpu_share"] = {"error": str(e)}
     print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -253,9 +253,18 @@ typedef struct rlr_profile {
     uint64_t n_batch_queries;  /* queries they carried */
     double batch_gemm_ms;      /* sum of HIP-event durations of the GEMM nomination launches */
     double batch_other_ms;     /* query prep + sample select + per-query finish */
-    uint64_t batch_gemm_bytes; /* algorithmic bytes: rows * dim * elem per batch of <= 256 queries */
+    uint64_t batch_gemm_bytes; /* algorithmic bytes: the operand the GEMM streams (rows * dim * 2 B over the
+                                * nomination image or binary16 rows, * 4 B over f32 rows), ONCE per batch: the
+                                * query blocks of one row tile share it through the XCD's L2 */
     double batch_gemm_flops;   /* 2 * queries * rows * dim */
     uint64_t n_batch_fallbacks;/* queries re-run through the single-query pipeline */
+    /* the dominant launch of a batch alone: the filtered main pass over rows [sample end, n) */
+    double batch_main_ms;      /* sum of its HIP-event durations */
+    uint64_t batch_main_bytes; /* rows it covered * dim * operand bytes */
+    double batch_main_flops;   /* 2 * queries * rows it covered * dim */
+    /* MMR (rlr_mmr_select*, rlr_engine_search_with_diversity*) */
+    uint64_t n_mmr;            /* queries diversified */
+    double mmr_ms;             /* gather + Gram + greedy kernels, HIP events on their stream, summed per call */
 } rlr_profile;
 /* enable != 0: record HIP events around each stage on the stream it is launched on
  * (adds one event pair per stage).  Disabled by default. */

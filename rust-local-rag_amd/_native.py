@@ -55,7 +55,9 @@ class ProfileC(C.Structure):
                 ("n_retries", C.c_uint64),
                 ("n_batches", C.c_uint64), ("n_batch_queries", C.c_uint64), ("batch_gemm_ms", C.c_double),
                 ("batch_other_ms", C.c_double), ("batch_gemm_bytes", C.c_uint64), ("batch_gemm_flops", C.c_double),
-                ("n_batch_fallbacks", C.c_uint64)]
+                ("n_batch_fallbacks", C.c_uint64),
+                ("batch_main_ms", C.c_double), ("batch_main_bytes", C.c_uint64), ("batch_main_flops", C.c_double),
+                ("n_mmr", C.c_uint64), ("mmr_ms", C.c_double)]
 
 
 # every symbol include/*.h declares: (name, restype, argtypes)

@@ -106,7 +106,7 @@ struct Ctx {
     uint64_t bcand_cap = 0;         // entries
     float *d_sample = nullptr;      // q x S nominated scores of the sample rows
     uint64_t sample_cap = 0;        // floats
-    hipEvent_t bev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t bev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // pinned host
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
@@ -271,7 +271,7 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; ++i)
         e = hipEventCreate(&c->ev[i]);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+    for (int i = 0; i < 5 && e == hipSuccess; ++i)
         e = hipEventCreate(&c->bev[i]);
     if (e == hipSuccess)
         e = rlr::dev_malloc(reinterpret_cast<void **>(&c->d_hist), 2 * kHistBins * sizeof(uint32_t));
@@ -933,6 +933,7 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
         rest_begin = static_cast<uint32_t>(S2);
     }
     // 3. the rest of the corpus, filtered in the GEMM epilogue
+    if (timed) RLR_HIP(hipEventRecord(c->bev[4], s));
     RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, rest_begin, n, c->d_qfrag, nq,
                                  c->d_tau, c->d_bcand, fin_cap, c->d_bstate, nullptr, 0, image, s));
     if (timed) RLR_HIP(hipEventRecord(c->bev[3], s));
@@ -959,8 +960,16 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
             (void)hipEventElapsedTime(&fin, c->bev[3], c->ev[3]);
             ix->prof.batch_gemm_ms += prep + g2; // prep is ~us; both GEMM launches are in here
             ix->prof.batch_other_ms += sel + fin;
-            ix->prof.batch_gemm_bytes += static_cast<uint64_t>(n_qblocks) * n * ix->dim * ((ix->dtype == RLR_F16 || use_image) ? 2 : 4);
+            const uint64_t opb = (ix->dtype == RLR_F16 || use_image) ? 2 : 4;
+            ix->prof.batch_gemm_bytes += static_cast<uint64_t>(n) * ix->dim * opb;
             ix->prof.batch_gemm_flops += 2.0 * nq * static_cast<double>(n) * ix->dim;
+            if (!use_multi && rest_begin < n) {
+                float mainp = 0;
+                (void)hipEventElapsedTime(&mainp, c->bev[4], c->bev[3]);
+                ix->prof.batch_main_ms += mainp;
+                ix->prof.batch_main_bytes += static_cast<uint64_t>(n - rest_begin) * ix->dim * opb;
+                ix->prof.batch_main_flops += 2.0 * nq * static_cast<double>(n - rest_begin) * ix->dim;
+            }
         }
     }
     return RLR_OK;
@@ -1689,6 +1698,16 @@ int32_t rlr_fetch_rows(rlr_index *ix, const uint64_t *rows, uint32_t n, float *o
     return RLR_OK;
 }
 
+// profile bookkeeping of an MMR call: c->ev[0] .. c->ev[1] bracket gather + Gram + greedy on the context's stream
+static void note_mmr(rlr_index *ix, Ctx *c, uint32_t n_queries)
+{
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->prof.n_mmr += n_queries;
+    ix->prof.mmr_ms += ms;
+}
+
 int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *pool_scores, uint32_t P, uint32_t k,
                        float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out)
 {
@@ -1717,14 +1736,19 @@ int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *po
     uint32_t *d_order = reinterpret_cast<uint32_t *>(d_sc + P);
     float *d_mmr = d_sc + 2ull * P;
     uint32_t *d_n = reinterpret_cast<uint32_t *>(d_sc + 3ull * P);
+    const bool timed = ix->profiling;
     RLR_HIP(hipMemcpyAsync(d_sc, pool_scores, static_cast<size_t>(P) * sizeof(float), hipMemcpyHostToDevice, s));
+    if (timed) RLR_HIP(hipEventRecord(c->ev[0], s));
     RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_pool, s));
     RLR_HIP(launch_gram(d_pool, P, ix->dim, d_gram, 1, s));
     RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, nullptr, 1, s));
+    if (timed) RLR_HIP(hipEventRecord(c->ev[1], s));
     // one D2H: order | mmr | n are contiguous
     RLR_TRY(pin_reserve(c, (2ull * P + 4) * 4));
     RLR_HIP(hipMemcpyAsync(c->h_pin, d_order, (2ull * P + 1) * 4, hipMemcpyDeviceToHost, s));
     RLR_HIP(hipStreamSynchronize(s));
+    if (timed)
+        note_mmr(ix, c, 1);
     const uint32_t *h_order = static_cast<const uint32_t *>(c->h_pin);
     const float *h_mmr = reinterpret_cast<const float *>(h_order + P);
     const uint32_t n_sel = h_order[2 * P];
@@ -1801,16 +1825,21 @@ static int32_t mmr_batch_impl(rlr_index *ix, const uint64_t *pool_rows, const fl
         RLR_HIP(hipMemcpyAsync(d_sc, h_sc, static_cast<size_t>(n_list) * sizeof(float), hipMemcpyHostToDevice, s));
         RLR_HIP(hipMemcpyAsync(d_sizes, h_sizes, m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         const float *d_rows_f32 = d_pool;
+        const bool timed = ix->profiling;
+        if (timed) RLR_HIP(hipEventRecord(c->ev[0], s));
         if (pool_rows)
             RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, n_list, d_pool, s));
         else
             d_rows_f32 = d_values + static_cast<size_t>(q0) * P * ix->dim;
         RLR_HIP(launch_gram(d_rows_f32, P, ix->dim, d_gram, m, s));
         RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, d_sizes, m, s));
+        if (timed) RLR_HIP(hipEventRecord(c->ev[1], s));
         // results: order | mmr | n are contiguous
         uint32_t *h_res = reinterpret_cast<uint32_t *>(h_sizes + m + 4);
         RLR_HIP(hipMemcpyAsync(h_res, d_order, (2ull * n_list + m) * 4, hipMemcpyDeviceToHost, s));
         RLR_HIP(hipStreamSynchronize(s));
+        if (timed)
+            note_mmr(ix, c, m);
         const float *h_mmr = reinterpret_cast<const float *>(h_res + n_list);
         const uint32_t *h_n = h_res + 2ull * n_list;
         for (uint32_t q = 0; q < m; ++q) {

@@ -43,6 +43,11 @@ class Profile:
     batch_gemm_bytes: int = 0
     batch_gemm_flops: float = 0.0
     n_batch_fallbacks: int = 0
+    batch_main_ms: float = 0.0
+    batch_main_bytes: int = 0
+    batch_main_flops: float = 0.0
+    n_mmr: int = 0
+    mmr_ms: float = 0.0
 
 
 class GpuIndex:

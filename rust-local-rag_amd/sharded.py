@@ -106,6 +106,22 @@ class ShardedIndex:
         self._bases_h = np.array([shard_range(n_total, r, self.world)[0] for r in range(self.world)], dtype=np.uint64)
         self._local = None
         self._gath = None
+        self._time_exchange = False
+        self._exchange_ms = 0.0
+        self._exchange_n = 0
+        self._ev = None
+
+    def time_exchange(self, on: bool) -> None:
+        """Record torch events around the exchange step (all-gather + merge kernel) on torch's current stream,
+        the stream that step is enqueued on; read the mean with exchange_ms_per_step()."""
+        self._time_exchange = bool(on)
+        if on:
+            self._exchange_ms, self._exchange_n = 0.0, 0
+            if self._ev is None:
+                self._ev = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
+
+    def exchange_ms_per_step(self):
+        return self._exchange_ms / self._exchange_n if self._exchange_n else None
 
     def fill_synthetic(self, seed: int, n_clusters: int = 0) -> None:
         self.index.fill_synthetic(self.hi - self.lo, seed, row0=self.lo, n_clusters=n_clusters)
@@ -131,19 +147,31 @@ class ShardedIndex:
         else:
             # the collective and the merge are queued behind the scan: no host round trip in between
             ticket = self.index.search_topk_device_begin(q, k, self._local.data_ptr(), stream)
-        if self.world > 1 or (self.dist is not None and os.environ.get("RLR_BENCH_FORCE_DIST") == "1"):
-            # the exchange step: world x k x 8 B per query over xGMI (RCCL all-gather)
-            self.dist.all_gather_into_tensor(self._gath.view(self.world * nq, k), self._local, group=self.group)
-            gathered = self._gath
-        else:
-            gathered = self._local
-        # merge on the GPU in one launch (rlr_merge_topk), results land in pinned host memory
         rows_h, cos_h, n_h = self._rows_h, self._cos_h, self._n_h
-        N.check(N.lib().rlr_merge_topk(self.dev.index, C.c_void_p(gathered.data_ptr()), self.world, nq, k,
-                                       self._bases_h.ctypes.data_as(N.u64p), rows_h.ctypes.data_as(N.u64p),
-                                       cos_h.ctypes.data_as(N.f32p), n_h.ctypes.data_as(N.u32p), C.c_void_p(stream)))
-        if ticket is not None:
-            self.index.search_topk_device_end(ticket)
+        try:
+            if self._time_exchange:
+                self._ev[0].record()
+            if self.world > 1 or (self.dist is not None and os.environ.get("RLR_BENCH_FORCE_DIST") == "1"):
+                # the exchange step: world x k x 8 B per query over xGMI (RCCL all-gather)
+                self.dist.all_gather_into_tensor(self._gath.view(self.world * nq, k), self._local, group=self.group)
+                gathered = self._gath
+            else:
+                gathered = self._local
+            # merge on the GPU in one launch (rlr_merge_topk), results land in pinned host memory
+            N.check(N.lib().rlr_merge_topk(self.dev.index, C.c_void_p(gathered.data_ptr()), self.world, nq, k,
+                                           self._bases_h.ctypes.data_as(N.u64p), rows_h.ctypes.data_as(N.u64p),
+                                           cos_h.ctypes.data_as(N.f32p), n_h.ctypes.data_as(N.u32p), C.c_void_p(stream)))
+            if self._time_exchange:
+                self._ev[1].record()
+        finally:
+            # the ticket holds a search context (pinned + device buffers): always hand it back, also when the
+            # collective or the merge raised
+            if ticket is not None:
+                self.index.search_topk_device_end(ticket)
+        if self._time_exchange:
+            self._ev[1].synchronize()
+            self._exchange_ms += self._ev[0].elapsed_time(self._ev[1])
+            self._exchange_n += 1
         # A shard whose guard band overflowed (massive exact ties) marks its slot; the marker travels through the
         # all-gather, so every rank sees it in the merged counts and takes the same branch: redo the step on
         # the synchronous path, which handles the overflow.
