@@ -205,7 +205,7 @@ class RagEngine:
         cap = max(3 * max(top_k, 1), 1)
         hits = (N.SearchHitC * cap)()
         n = C.c_uint32()
-        lr, ls, nl = self._lex(lexical, query_text, 5 * top_k)
+        lr, ls, nl = self._lex(lexical, query_text, 5 * max(top_k, 1))   # top_k.max(1) then saturating_mul(5) :490, :505
         wc = weights.to_c() if weights is not None else None
         N.check(N.lib().rlr_engine_search(self.index.handle, q.ctypes.data_as(N.f32p), q.size, top_k,
                                           C.byref(wc) if wc is not None else None, lr.ctypes.data_as(N.u64p),
@@ -223,7 +223,7 @@ class RagEngine:
         n = C.c_uint32()
         lam = min(max(float(diversity_factor), 0.0), 1.0)
         k_eff = top_k if lam == 0.0 else max(3 * top_k, top_k + 10)  # the top_k `search` sees (:728-735)
-        lr, ls, nl = self._lex(lexical, query_text, 5 * k_eff)
+        lr, ls, nl = self._lex(lexical, query_text, 5 * max(k_eff, 1))    # search() treats 0 as 1 (:490) before * 5 (:505)
         wc = weights.to_c() if weights is not None else None
         N.check(N.lib().rlr_engine_search_with_diversity(
             self.index.handle, q.ctypes.data_as(N.f32p), q.size, top_k, float(diversity_factor),

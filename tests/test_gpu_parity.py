@@ -268,6 +268,28 @@ def test_engine_search_with_diversity_matches_oracle(rlr, oracle, n, dim, k, lam
     eng.close()
 
 
+def test_config2_search_with_diversity_at_100k_matches_oracle(rlr, oracle):
+    """BASELINE config 2 at its stated size: 100 000 x 768 f32, single query, top_k = 100, MMR lambda = 0.3
+    (pool 300 -> 100), through the engine ABI, rows / scores / cosines bit-equal to rlr_o_search_with_diversity."""
+    n, dim, k, lam = 100_000, 768, 100, 0.3
+    rows = oracle.synth_rows(n, dim, seed=0x5EED0002, n_clusters=200)
+    eng = rlr.RagEngine(dim)
+    eng.index.fill_synthetic(n, seed=0x5EED0002, n_clusters=200)
+    eng._chunks = [rlr.DocumentChunk(str(i), "synthetic", "", i) for i in range(n)]
+    assert np.array_equal(eng.index.fetch_rows(np.arange(0, n, 911)).view(np.uint32), rows[::911].view(np.uint32))
+    for s in (1, 2):
+        q = oracle.synth_query(dim, seed=0x5EED0002 + s)
+        got = eng.search_with_diversity(q, k, lam)
+        wr, wc, we, wl = oracle.search_with_diversity(rows, q, k, lam)
+        assert len(got) == k and [g.row for g in got] == list(wr)
+        assert np.array_equal(bits([g.score for g in got]), bits(wc))
+        assert np.array_equal(bits([g.embedding_score for g in got]), bits(we))
+        plain = eng.search(q, k)                                   # and the no-MMR ordering at the same size
+        pr, pc, _, _ = oracle.search(rows, q, k)
+        assert [g.row for g in plain] == list(pr) and np.array_equal(bits([g.score for g in plain]), bits(pc))
+    eng.close()
+
+
 def test_mmr_select_values_bit_exact(rlr, oracle):
     rows = oracle.synth_rows(2000, 768, seed=91, n_clusters=12)
     ix = make_index(rlr, rows)

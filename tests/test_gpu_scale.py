@@ -99,6 +99,38 @@ def test_config5_shard_batched_search_and_mmr(rlr):
     ix.close()
 
 
+def test_config4_shard_single_query_12_5m_rows(rlr):
+    """BASELINE config 4's per-GPU share: 12.5 M x 768 f32 rows (100 M / 8 GPUs = 38.4 GB), single queries, as rank 3 of
+    8 holds it (row0 = 3 x 12.5 M of the same synthetic stream).  The same size-independent properties as at 10 M rows,
+    plus: the shard's answer is what a merge needs -- reference-order scores, (score desc, row asc) order."""
+    n, row0 = 12_500_000, 3 * 12_500_000
+    ix = rlr.GpuIndex(DIM)
+    ix.fill_synthetic(n, seed=0x5EED0004, row0=row0)
+    rng = np.random.default_rng(44)
+    qs = _queries(rlr, 2, seed=44)
+    for q in qs:
+        r, c = ix.search_topk(q, K)
+        r, c = r[0], c[0]
+        assert len(r) == K and len(set(r.tolist())) == K and r.max() < n
+        key = list(zip((-c).tolist(), r.tolist()))
+        assert key == sorted(key)
+        assert np.array_equal(bits(c), bits(ix.score_rows(q, r)))
+        sample = rng.choice(n, size=200_000, replace=False).astype(np.uint64)
+        s = ix.score_rows(q, sample)
+        assert s[~np.isin(sample, r)].max() <= c[-1]
+        r2, c2 = ix.search_topk(q, K)
+        assert np.array_equal(r2[0], r) and np.array_equal(bits(c2[0]), bits(c))
+    # the opt-in nomination copies give the same answer at this size too
+    base = [ix.search_topk(q, K) for q in qs]
+    for kw in (dict(on=True, single_query=True), dict(on=False, q8=True)):
+        ix.enable_batch_image(**kw)
+        for q, (rb, cb) in zip(qs, base):
+            r, c = ix.search_topk(q, K)
+            assert np.array_equal(r, rb) and np.array_equal(bits(c), bits(cb)), kw
+        ix.enable_batch_image(False)
+    ix.close()
+
+
 def test_delete_round_trip(rlr):
     n = 1_000_000
     ix = rlr.GpuIndex(DIM)
