@@ -165,6 +165,26 @@ int32_t rlr_mmr_select_batch(rlr_index *idx, const uint64_t *pool_rows, const fl
                              const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k,
                              float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out);
 
+/* search -> pool -> MMR in ONE enqueue on one stream with ONE host synchronisation: the path of
+ * RagEngine::search_with_diversity (rag_engine.rs:717-759) for a query without lexical candidates --
+ * `search(pool)` :735 with combined = w_e*cos + w_l*0 (:531-532), candidate order (combined desc, row asc)
+ * :543, cut to `pool` :544/:734, then `mmr_diversify` :756 -- with the pool never leaving the device
+ * (scan -> select -> re-score -> pool order -> gather -> Gram -> greedy -> results in pinned memory).
+ *   query        normalised, dim floats (as for rlr_search_topk)
+ *   pool         candidates `search` keeps (the reference's max(3*top_k, top_k+10)), <= 1024
+ *   k, lambda    as rlr_mmr_select
+ *   w_embedding, w_lexical   the resolved weights (w_embedding > 0)
+ *   rows_out / cos_out / score_out   min(max(k,1), pool) entries each, in pick order; score = the combined
+ *                (relevance) score the reference reports, cos = embedding_score
+ *   *fallback    != 0: nothing was written; take rlr_search_topk + rlr_mmr_select instead.  Set when the
+ *                guard band overflowed (massive exact ties), when distinct cosines round to one combined score
+ *                in a chain that reaches the last fetched row (the boundary rule of rag_engine.rs:543 needs a
+ *                wider fetch), or for arguments outside the fused kernels (pool > 1024, w_embedding <= 0).
+ * Results are identical to the two-call path (tests/test_gpu_parity.py::test_search_diverse_*). */
+int32_t rlr_search_diverse(rlr_index *idx, const float *query, uint32_t pool, uint32_t k, float lambda,
+                           float w_embedding, float w_lexical, float guard_eps, uint64_t *rows_out,
+                           float *cos_out, float *score_out, uint32_t *n_out, int32_t *fallback);
+
 /* ---- device-resident variant (multi-GPU sharding) ------- */
 /* Same search, but the per-query result stays in device memory so the caller can hand it
  * to an RCCL all-gather without a host round trip.

@@ -93,6 +93,8 @@ PROTOTYPES = [
     ("rlr_mmr_select", C.c_int32, [_H, u64p, f32p, C.c_uint32, C.c_uint32, C.c_float, u32p, f32p, u32p]),
     ("rlr_mmr_select_batch", C.c_int32, [_H, u64p, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, u32p, f32p,
                                          u32p]),
+    ("rlr_search_diverse", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, u64p,
+                                       f32p, f32p, u32p, i32p]),
     ("rlr_multi_create", C.c_int32, [C.c_uint32, C.c_int32, C.c_int32, i32p, C.POINTER(_H)]),
     ("rlr_multi_destroy", C.c_int32, [_H]),
     ("rlr_multi_info", C.c_int32, [_H, u64p, u32p]),

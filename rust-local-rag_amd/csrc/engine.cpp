@@ -287,6 +287,36 @@ int32_t rlr_engine_search_with_diversity(rlr_index *idx, const float *query_raw,
     }
     const uint64_t p3 = static_cast<uint64_t>(top_k) * 3, p10 = static_cast<uint64_t>(top_k) + 10;
     const uint32_t pool_size = static_cast<uint32_t>(std::min<uint64_t>(std::max(p3, p10), 0xFFFFFFFFull)); // :734
+    if (n_lex == 0 && w.embedding > 0.0f && pool_size <= 1024) {
+        // no lexical candidates: search(pool) -> mmr_diversify entirely on the device, one synchronisation
+        // (rlr_search_diverse); it hands the query back when its fetch cannot decide the pool order
+        uint64_t N = 0;
+        uint32_t dim = 0;
+        int32_t st0 = rlr_index_info(idx, &N, &dim, nullptr, nullptr);
+        if (st0 != RLR_OK)
+            return st0;
+        if (N == 0)
+            return RLR_OK;
+        const std::vector<float> q = prepare_query(query_raw, dq, dim);
+        const uint32_t kk = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(top_k, 1u), pool_size));
+        std::vector<uint64_t> rows(kk);
+        std::vector<float> cosv(kk), sc(kk);
+        uint32_t n_sel = 0;
+        int32_t fb = 0;
+        st0 = rlr_search_diverse(idx, q.data(), pool_size, top_k, diversity_factor, w.embedding, w.lexical, -1.0f, rows.data(),
+                                 cosv.data(), sc.data(), &n_sel, &fb);
+        if (st0 != RLR_OK)
+            return st0;
+        if (!fb) {
+            if (n_sel && !out)
+                return RLR_E_INVALID;
+            std::vector<Cand> picked(n_sel);
+            for (uint32_t i = 0; i < n_sel; ++i)
+                picked[i] = {rows[i], sc[i], cosv[i], 0.0f};
+            emit(picked, out, cap, n_out);
+            return RLR_OK;
+        }
+    }
     int32_t st = search_impl(idx, query_raw, dq, pool_size, w, lex_rows, lex_scores, n_lex, 0, pool); // :735
     if (st != RLR_OK)
         return st;

@@ -622,6 +622,106 @@ __global__ void emit_kernel(const uint64_t *__restrict__ packed, uint32_t n, uin
     if (i < k)
         out[i] = i < n ? packed[i] : 0ull;
 }
+
+// ---- search -> MMR without a host round trip (rlr_search_diverse) -----------------------------------------
+// The device twin of the host code between `search` and `mmr_diversify` for a query without lexical candidates
+// (csrc/engine.cpp: search_impl's candidate list + rlr_engine_search_with_diversity): the `fetch` best rows by
+// cosine (sorted, packed) become candidates with combined = w_e * cos + w_l * 0 (rag_engine.rs:531-532: two
+// rounded products, one add), ordered (combined desc, NaN last, row asc) -- distinct cosines can round to one
+// combined score, so this is NOT always the cosine order -- cut to the first `need` (:544, :734).  If such a
+// rounding tie chain reaches the last fetched row while rows remain unfetched the order cannot be decided from
+// this fetch: info[1] = 2 and the host takes the widening two-call path, exactly as search_impl does.
+//   info[0] = pool size, info[1] = status (0 ok, 1 guard-band overflow upstream, 2 boundary tie)
+constexpr uint32_t kPoolMax = 1024, kPoolFetchMax = kPoolMax + 8;
+
+__global__ __launch_bounds__(1024) void pool_prepare_kernel(const uint64_t *__restrict__ packed, uint32_t fetch, uint32_t need,
+                                                            uint32_t n_rows, float w_e, float w_l,
+                                                            uint32_t *__restrict__ list, float *__restrict__ comb,
+                                                            float *__restrict__ cosv, uint32_t *__restrict__ info)
+{
+    __shared__ uint64_t s_key[kPoolFetchMax];
+    __shared__ float s_c[kPoolFetchMax], s_e[kPoolFetchMax];
+    __shared__ uint32_t s_got;
+    __shared__ float s_cneed;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) {
+        s_got = 0;
+        s_cneed = 0.0f;
+    }
+    __syncthreads();
+    const bool overflow = packed[0] == ~0ull;
+    for (uint32_t i = t; i < fetch; i += 1024) {
+        const uint64_t p = overflow ? 0ull : packed[i];
+        uint64_t key = 0;
+        if (p != 0) { // valid entries are a prefix: (score desc, row asc), padding zeros behind
+            const float e = key_score(static_cast<uint32_t>(p >> 32));
+            const float t0 = w_e * e;
+            const float t1 = w_l * 0.0f;
+            const float c = t0 + t1;
+            s_c[i] = c;
+            s_e[i] = e;
+            key = (static_cast<uint64_t>(score_key(c)) << 32) | (p & 0xFFFFFFFFull);
+            atomicAdd(&s_got, 1u);
+        }
+        s_key[i] = key;
+    }
+    __syncthreads();
+    const uint32_t got = s_got;
+    // rank sort: keys are unique (the row is part of the key)
+    for (uint32_t i = t; i < got; i += 1024) {
+        const uint64_t mine = s_key[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < got; ++j)
+            rank += s_key[j] > mine;
+        if (rank < need) {
+            list[rank] = 0xFFFFFFFFu - static_cast<uint32_t>(mine & 0xFFFFFFFFull);
+            comb[rank] = s_c[i];
+            cosv[rank] = s_e[i];
+            if (rank == need - 1)
+                s_cneed = s_c[i];
+        }
+    }
+    const uint32_t n_pool = min(got, need);
+    for (uint32_t i = n_pool + t; i < need; i += 1024) { // unused slots: a valid row, never read by the greedy kernel
+        list[i] = 0;
+        comb[i] = 0.0f;
+        cosv[i] = 0.0f;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t status = overflow ? 1u : 0u;
+        if (!overflow && got < n_rows && got > 0) {
+            // bound on every unfetched row: the combined score of the last fetched cosine
+            const float t0 = w_e * s_e[got - 1];
+            const float t1 = w_l * 0.0f;
+            const float c_tail = t0 + t1;
+            const bool ok = got >= need && (c_tail != c_tail || s_cneed > c_tail);
+            if (!ok)
+                status = 2u;
+        }
+        info[0] = status ? 0u : n_pool;
+        info[1] = status;
+    }
+}
+
+// picks -> pinned host memory: [row u32 | cos f32 | combined f32] x k, then n_picks, status
+__global__ __launch_bounds__(256) void diverse_emit_kernel(const uint32_t *__restrict__ list, const float *__restrict__ comb,
+                                                           const float *__restrict__ cosv, const uint32_t *__restrict__ order,
+                                                           const uint32_t *__restrict__ n_sel, const uint32_t *__restrict__ info,
+                                                           uint32_t k_cap, uint32_t *__restrict__ h_out)
+{
+    const uint32_t n = info[1] ? 0u : min(*n_sel, k_cap);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t o = order[i];
+        h_out[i] = list[o];
+        h_out[k_cap + i] = __builtin_bit_cast(uint32_t, cosv[o]);
+        h_out[2 * k_cap + i] = __builtin_bit_cast(uint32_t, comb[o]);
+    }
+    if (threadIdx.x == 0) {
+        h_out[3 * k_cap] = n;
+        h_out[3 * k_cap + 1] = info[1];
+    }
+}
 } // namespace rlr
 
 namespace {
@@ -1756,6 +1856,114 @@ int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *po
         order_out[i] = h_order[i];
         if (mmr_out)
             mmr_out[i] = h_mmr[i];
+    }
+    *n_out = n_sel;
+    return RLR_OK;
+}
+
+int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uint32_t k, float lambda, float w_embedding,
+                           float w_lexical, float guard_eps, uint64_t *rows_out, float *cos_out, float *score_out,
+                           uint32_t *n_out, int32_t *fallback)
+{
+    RLR_TRY(check_handle(ix));
+    if (!n_out || !fallback)
+        return fail(RLR_E_INVALID, "n_out / fallback is null");
+    *n_out = 0;
+    *fallback = 0;
+    if (ix->n_rows == 0 || pool == 0)
+        return RLR_OK;
+    if (!query || !rows_out || !cos_out || !score_out)
+        return fail(RLR_E_INVALID, "null argument");
+    const uint32_t n = static_cast<uint32_t>(ix->n_rows);
+    const uint32_t need = std::min<uint32_t>(n, pool);
+    const uint32_t fetch = static_cast<uint32_t>(std::min<uint64_t>(n, static_cast<uint64_t>(need) + 8));
+    if (need > rlr::kPoolMax || !(w_embedding > 0.0f) || !(w_lexical >= 0.0f) || !std::isfinite(w_lexical)) {
+        *fallback = 1; // outside what the fused kernels cover: the caller's two-call path handles it
+        return RLR_OK;
+    }
+    RLR_TRY(use_device(ix));
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    hipStream_t s = c->stream;
+    SearchPlan p;
+    p.k = fetch;
+    const float eps = guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim);
+    p.two_eps = 2.0f * eps;
+    p.two_eps_img = image_two_eps(ix, eps);
+    p.cap = kLdsSortCap;
+    RLR_TRY(ctx_prepare(ix, c, 1, p));
+    const uint32_t P = need;
+    const uint32_t k_cap = std::max<uint32_t>(std::min<uint32_t>(std::max<uint32_t>(k, 1u), P), 1u);
+    // workspace: pool P x dim | gram P x P | combined P | cos P | order P | mmr P | n_sel, info[2]
+    const uint64_t floats = static_cast<uint64_t>(P) * ix->dim + static_cast<uint64_t>(P) * P + 4ull * P + 8;
+    RLR_TRY(grow(&c->d_pool, &c->pool_cap, floats));
+    if (c->list_cap < P || !c->d_list) {
+        const uint64_t zero = 0;
+        RLR_TRY(upload_list(ix, c, &zero, 1)); // (allocates the list for >= 1024 rows)
+    }
+    float *d_pool = c->d_pool;
+    float *d_gram = d_pool + static_cast<uint64_t>(P) * ix->dim;
+    float *d_comb = d_gram + static_cast<uint64_t>(P) * P;
+    float *d_cos = d_comb + P;
+    uint32_t *d_order = reinterpret_cast<uint32_t *>(d_cos + P);
+    float *d_mmr = d_cos + 2ull * P;
+    uint32_t *d_nsel = reinterpret_cast<uint32_t *>(d_cos + 3ull * P);
+    uint32_t *d_info = d_nsel + 1;
+    const size_t q_bytes = static_cast<size_t>(ix->q_pitch) * sizeof(float);
+    const size_t out_words = 3ull * k_cap + 2;
+    RLR_TRY(pin_reserve(c, q_bytes + out_words * 4 + 64));
+    float *h_q = static_cast<float *>(c->h_pin);
+    uint32_t *h_out = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + q_bytes);
+    std::memset(h_q, 0, q_bytes);
+    std::memcpy(h_q, query, ix->dim * sizeof(float));
+    stage_query_norms(ix, c, query, 1);
+    c->hist_dirty = true;
+    const bool timed = ix->profiling;
+    RLR_HIP(hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s));
+    uint64_t *d_meta = c->d_out + fetch;
+    RLR_HIP(enqueue_query(ix, c, 0, p, c->d_out, d_meta, timed));
+    if (timed) RLR_HIP(hipEventRecord(c->bev[0], s));
+    hipLaunchKernelGGL(rlr::pool_prepare_kernel, dim3(1), dim3(1024), 0, s, c->d_out, fetch, need, n, w_embedding, w_lexical,
+                       c->d_list, d_comb, d_cos, d_info);
+    RLR_HIP(hipGetLastError());
+    RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_pool, s));
+    RLR_HIP(launch_gram(d_pool, P, ix->dim, d_gram, 1, s));
+    RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, k, lambda, d_order, d_mmr, d_nsel, d_info, 1, s));
+    hipLaunchKernelGGL(rlr::diverse_emit_kernel, dim3(1), dim3(256), 0, s, c->d_list, d_comb, d_cos, d_order, d_nsel, d_info,
+                       k_cap, h_out);
+    RLR_HIP(hipGetLastError());
+    if (timed) RLR_HIP(hipEventRecord(c->bev[1], s));
+    RLR_HIP(hipStreamSynchronize(s));
+    c->hist_dirty = false;
+    const uint32_t n_sel = h_out[3 * k_cap], status = h_out[3 * k_cap + 1];
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        ix->prof.n_searches += 1;
+        if (timed) {
+            float a = 0, b = 0, d = 0, m = 0;
+            (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+            (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+            (void)hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
+            (void)hipEventElapsedTime(&m, c->bev[0], c->bev[1]);
+            ix->prof.n_scan_launches += 1;
+            ix->prof.scan_ms += a;
+            ix->prof.select_ms += b;
+            ix->prof.rescore_ms += d;
+            ix->prof.total_ms += a + b + d + m;
+            ix->prof.scan_bytes += ix->n_rows * ix->dim * (scan_over_q8(ix) ? 1 : (ix->dtype == RLR_F16 || scan_over_image(ix)) ? 2 : 4);
+            ix->prof.n_mmr += 1;
+            ix->prof.mmr_ms += m;
+        }
+    }
+    if (status != 0) {
+        *fallback = static_cast<int32_t>(status);
+        return RLR_OK;
+    }
+    for (uint32_t i = 0; i < n_sel; ++i) {
+        rows_out[i] = h_out[i];
+        cos_out[i] = __builtin_bit_cast(float, h_out[k_cap + i]);
+        score_out[i] = __builtin_bit_cast(float, h_out[2 * k_cap + i]);
     }
     *n_out = n_sel;
     return RLR_OK;

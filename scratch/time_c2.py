@@ -2,7 +2,7 @@
 of RagEngine.search_with_diversity (pool 300 search + GPU MMR) and a parity check vs the oracle."""
 import importlib, sys, time, json
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 rlr = importlib.import_module("rust-local-rag_amd")
 from oracle import oracle as O
 n, dim, k, lam = 100_000, 768, 100, 0.3

@@ -2,7 +2,7 @@
 top_k=100, MMR lambda=0.7 -- batched search (pool 300) + batched MMR through the engine API."""
 import importlib, sys, time, json
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 rlr = importlib.import_module("rust-local-rag_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 6_250_000
 dim, nq, k, lam = 1024, 1024, 100, 0.7

@@ -290,6 +290,74 @@ def test_config2_search_with_diversity_at_100k_matches_oracle(rlr, oracle):
     eng.close()
 
 
+def _search_diverse(rlr, ix, qn, pool, k, lam, w_e=0.7, w_l=0.3):
+    import ctypes as C
+    N = rlr._native
+    kk = max(min(max(k, 1), pool), 1)
+    rows = np.zeros(kk, np.uint64)
+    cos = np.zeros(kk, np.float32)
+    sc = np.zeros(kk, np.float32)
+    n, fb = C.c_uint32(), C.c_int32()
+    N.check(N.lib().rlr_search_diverse(ix.handle, qn.ctypes.data_as(N.f32p), pool, k, lam, w_e, w_l, -1.0,
+                                       rows.ctypes.data_as(N.u64p), cos.ctypes.data_as(N.f32p), sc.ctypes.data_as(N.f32p),
+                                       C.byref(n), C.byref(fb)))
+    return rows[:n.value], cos[:n.value], sc[:n.value], fb.value
+
+
+@pytest.mark.parametrize("n,dim,dtype,k,lam,ncl", [(20_000, 768, "f32", 100, 0.3, 40), (5_000, 1024, "f16", 100, 0.7, 25),
+                                                    (40, 768, "f32", 100, 0.5, 3), (3_000, 384, "f32", 5, 1.0, 0),
+                                                    (9, 768, "f32", 0, 0.4, 0)])
+def test_search_diverse_is_the_two_call_path_on_the_device(rlr, oracle, n, dim, dtype, k, lam, ncl):
+    """rlr_search_diverse (scan -> select -> re-score -> pool order -> gather -> Gram -> greedy, one synchronisation)
+    against rlr_o_search_with_diversity and against rlr_search_topk + rlr_mmr_select on the same index."""
+    rows = oracle.synth_rows(n, dim, seed=1200 + n, n_clusters=ncl, f16=(dtype == "f16"))
+    ix = rlr.GpuIndex(dim, dtype)
+    ix.upload(rows)
+    pool = max(3 * k, k + 10)
+    for s in range(3):
+        q = oracle.synth_query(dim, seed=1300 + n + s)
+        qn = oracle.normalize(q)
+        r, c, sc, fb = _search_diverse(rlr, ix, qn, pool, k, lam)
+        assert fb == 0
+        wr, wc, we, _ = oracle.search_with_diversity(rows, q, k, lam)
+        assert np.array_equal(r, wr) and np.array_equal(bits(sc), bits(wc)) and np.array_equal(bits(c), bits(we))
+        pr, pc = ix.search_topk(qn, min(pool, n))                  # the two-call path, same index
+        psc = (np.float32(0.7) * pc[0]).astype(np.float32)
+        order, _ = ix.mmr_select(pr[0], psc, k, lam)
+        assert np.array_equal(r, pr[0][order]) and np.array_equal(bits(sc), bits(psc[order]))
+    # other weights
+    q = oracle.synth_query(dim, seed=77)
+    r, c, sc, fb = _search_diverse(rlr, ix, oracle.normalize(q), pool, k, lam, w_e=0.2, w_l=0.9)
+    wr, wc, we, _ = oracle.search_with_diversity(rows, q, k, lam, w_e=0.2, w_l=0.9)
+    assert fb == 0 and np.array_equal(r, wr) and np.array_equal(bits(sc), bits(wc))
+    # arguments the fused kernels do not cover are handed back, not guessed at
+    assert _search_diverse(rlr, ix, oracle.normalize(q), 2000, 100, lam)[3] != 0 or n <= 1024
+    assert _search_diverse(rlr, ix, oracle.normalize(q), pool, k, lam, w_e=0.0)[3] != 0
+    ix.close()
+
+
+def test_engine_diversity_when_distinct_cosines_round_to_one_score(rlr, oracle):
+    """embedding weight 1e-40: w_e * cos underflows to a handful of subnormal values, so long chains of DISTINCT
+    cosines share one combined score and the candidate order (combined desc, row asc -- rag_engine.rs:543 with the
+    build's tie rule) is no longer the cosine order.  The fused path must either order such chains itself or hand the
+    query back when a chain reaches its last fetched row; either way the engine's answer equals the oracle's."""
+    n, dim = 6000, 768
+    rows = oracle.synth_rows(n, dim, seed=5150, n_clusters=9)
+    eng = rlr.RagEngine(dim)
+    eng.index.upload(rows)
+    eng._chunks = [rlr.DocumentChunk(str(i), "synthetic", "", i) for i in range(n)]
+    for w_e in (1e-40, 3e-39, 1e-3):
+        w = rlr.QueryWeights(embedding=w_e)
+        for k, lam in ((5, 0.3), (100, 0.5)):
+            q = oracle.synth_query(dim, seed=5151 + k)
+            got = eng.search_with_diversity(q, k, lam, weights=w)
+            wr, wc, we, _ = oracle.search_with_diversity(rows, q, k, lam, w_e=w_e)
+            assert [g.row for g in got] == list(wr), (w_e, k)
+            assert np.array_equal(bits([g.score for g in got]), bits(wc)), (w_e, k)
+            assert np.array_equal(bits([g.embedding_score for g in got]), bits(we)), (w_e, k)
+    eng.close()
+
+
 def test_mmr_select_values_bit_exact(rlr, oracle):
     rows = oracle.synth_rows(2000, 768, seed=91, n_clusters=12)
     ix = make_index(rlr, rows)
