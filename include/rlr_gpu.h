@@ -234,8 +234,9 @@ void rlr_unpack_result(uint64_t packed, float *score, uint32_t *row);
 /* ---- one process, several GPUs ------------------------------------------------------------ */
 /* The reference is a single-process server; this handle lets such a host drive all GPUs of a node
  * without torch / one-process-per-GPU: rows are split into contiguous ranges (shard g holds rows
- * [g*ceil(N/G), ...)), every search runs on all shards concurrently (one host thread per device)
- * and the per-shard top-k lists (k x 8 bytes each) are merged on the host.  Results are identical
+ * [g*ceil(N/G), ...)), every search runs on all shards concurrently (one persistent host thread per
+ * shard, parked between calls) and the per-shard top-k lists (k x 8 bytes each) are merged on the host or, with
+ * rlr_multi_set_exchange(m, 1), all-gathered over RCCL and merged on the device.  Results are identical
  * to a single index over the same rows.  device_ids may repeat (several shards on one GPU).
  * The benchmark contract's multi-GPU path is the one-process-per-GPU / RCCL variant
  * (rlr_search_topk_device + rlr_merge_topk, rust-local-rag_amd/sharded.py). */
@@ -244,6 +245,16 @@ int32_t rlr_multi_create(uint32_t dim, int32_t dtype, int32_t n_devices, const i
                          rlr_multi **out);
 int32_t rlr_multi_destroy(rlr_multi *m);
 int32_t rlr_multi_info(const rlr_multi *m, uint64_t *n_rows, uint32_t *n_shards);
+/* How rlr_multi_search_topk exchanges the per-shard partial top-k lists:
+ *   0  host merge (default): each shard's k x (row, score) list returns to the host, k-way merge there;
+ *   1  RCCL: the lists stay in device memory (rlr_search_topk_device), one ncclAllGather of
+ *      n_queries x k x 8 bytes per shard over xGMI (group call, single process: ncclCommInitAll), then
+ *      merge_topk_kernel on the first device (rlr_merge_topk).  Needs one shard per device (RLR_E_INVALID
+ *      otherwise) and a loadable librccl.so (dlopen on first use; RLR_E_NO_DEVICE otherwise).  A call whose
+ *      shape is outside the merge kernel (more than 16 shards, shards x k > 8192) or whose guard band
+ *      overflowed on some shard is answered through the host merge instead.  Results are identical in both
+ *      modes.  Mutator-class call: not concurrent with searches. */
+int32_t rlr_multi_set_exchange(rlr_multi *m, int32_t mode);
 /* replace all rows (host memory, n_rows x dim f32), sharded by contiguous ranges */
 int32_t rlr_multi_upload(rlr_multi *m, const float *rows, uint64_t n_rows, int32_t normalize_on_device);
 int32_t rlr_multi_fill_synthetic(rlr_multi *m, uint64_t n_rows, uint64_t seed, uint32_t n_clusters);

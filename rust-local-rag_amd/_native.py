@@ -98,6 +98,7 @@ PROTOTYPES = [
     ("rlr_multi_create", C.c_int32, [C.c_uint32, C.c_int32, C.c_int32, i32p, C.POINTER(_H)]),
     ("rlr_multi_destroy", C.c_int32, [_H]),
     ("rlr_multi_info", C.c_int32, [_H, u64p, u32p]),
+    ("rlr_multi_set_exchange", C.c_int32, [_H, C.c_int32]),
     ("rlr_multi_upload", C.c_int32, [_H, f32p, C.c_uint64, C.c_int32]),
     ("rlr_multi_fill_synthetic", C.c_int32, [_H, C.c_uint64, C.c_uint64, C.c_uint32]),
     ("rlr_multi_search_topk", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, u64p, f32p, u32p]),

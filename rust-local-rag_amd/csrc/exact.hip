@@ -486,13 +486,17 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
     const uint32_t t = threadIdx.x, ty = t >> 4, tx = t & 15;
     float acc00 = 0.0f, acc01 = 0.0f, acc10 = 0.0f, acc11 = 0.0f;
     const bool vec = (dim & 3u) == 0;
-    for (uint32_t k0 = 0; k0 < dim; k0 += kGK) {
+    // the next chunk's 64 rows x 64 columns travel global -> registers while the current chunk is multiplied out of
+    // LDS (one round of load latency per chunk used to sit between the two barriers: 41 -> see DESIGN.md)
+    constexpr int kPre = 2 * kGT * (kGK / 4) / 256; // float4 per thread per chunk
+    float4 pre[kPre];
+    auto fetch = [&](uint32_t k0) {
         const uint32_t kc = min(static_cast<uint32_t>(kGK), dim - k0);
-        // stage: 64 rows x kc columns; 16 threads per row, float4 each when dim % 4 == 0
-        for (uint32_t idx = t; idx < 2 * kGT * (kGK / 4); idx += 256) {
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const uint32_t idx = t + 256 * u;
             const uint32_t r = idx / (kGK / 4), c4 = idx % (kGK / 4);
-            const bool is_b = r >= kGT;
-            const uint32_t row = (is_b ? j0 + (r - kGT) : i0 + r);
+            const uint32_t row = r >= kGT ? j0 + (r - kGT) : i0 + r;
             float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (row < P && c4 * 4 < kc) {
                 const float *src = pool + static_cast<size_t>(row) * dim + k0 + c4 * 4;
@@ -505,10 +509,26 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
                     if (c4 * 4 + 3 < kc) v.w = src[3];
                 }
             }
-            float *dst = (is_b ? sb + (r - kGT) * kGPitch : sa + r * kGPitch) + c4 * 4;
-            *reinterpret_cast<float4 *>(dst) = v;
+            pre[u] = v;
         }
-        __syncthreads();
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const uint32_t idx = t + 256 * u;
+            const uint32_t r = idx / (kGK / 4), c4 = idx % (kGK / 4);
+            float *dst = (r >= kGT ? sb + (r - kGT) * kGPitch : sa + r * kGPitch) + c4 * 4;
+            *reinterpret_cast<float4 *>(dst) = pre[u];
+        }
+    };
+    fetch(0);
+    stash();
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < dim; k0 += kGK) {
+        const uint32_t kc = min(static_cast<uint32_t>(kGK), dim - k0);
+        const bool more = k0 + kGK < dim;
+        if (more)
+            fetch(k0 + kGK);
         const float4 *a0 = reinterpret_cast<const float4 *>(sa + ty * kGPitch);
         const float4 *a1 = reinterpret_cast<const float4 *>(sa + (ty + 16) * kGPitch);
         const float4 *b0 = reinterpret_cast<const float4 *>(sb + tx * kGPitch);
@@ -536,6 +556,10 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
             p = xb * yb; acc11 = acc11 + p;
         }
         __syncthreads();
+        if (more) {
+            stash();
+            __syncthreads();
+        }
     }
     const uint32_t ri[2] = {i0 + ty, i0 + ty + 16}, cj[2] = {j0 + tx, j0 + tx + 16};
     const float v[2][2] = {{acc00, acc01}, {acc10, acc11}};

@@ -253,6 +253,11 @@ class MultiGpuIndex:
     def fill_synthetic(self, n_rows: int, seed: int, n_clusters: int = 0) -> None:
         N.check(self._L.rlr_multi_fill_synthetic(self._h, n_rows, seed, n_clusters))
 
+    def set_exchange(self, mode: str) -> None:
+        """"host": per-shard lists merged on the host (default); "rccl": ncclAllGather of the packed partial top-k
+        lists + merge kernel on the first device (one shard per device; librccl loaded on first use)"""
+        N.check(self._L.rlr_multi_set_exchange(self._h, {"host": 0, "rccl": 1}[mode]))
+
     def search_topk(self, queries, k: int, guard_eps: float = -1.0):
         q = _f32(queries).reshape(-1, self.dim)
         nq = q.shape[0]

@@ -870,6 +870,52 @@ def test_batch_image_same_results_and_tracks_mutation(rlr, oracle, dim, dtype):
     ix.close()
 
 
+def test_multi_index_rccl_exchange_world1_and_persistent_workers(rlr, oracle):
+    """rlr_multi_set_exchange(m, 1): the partial top-k lists stay on the device, ncclAllGather (single-process
+    communicator, here of one rank: the one-GPU box) + merge_topk_kernel -- same results as the host merge and as the
+    oracle; duplicate devices are refused.  Then the persistent shard workers under concurrent callers."""
+    import threading
+
+    n, dim = 30_011, 768
+    rows = oracle.synth_rows(n, dim, seed=7771, n_clusters=11)
+    qs = np.stack([oracle.normalize(oracle.synth_query(dim, seed=7800 + i)) for i in range(6)])
+    one = rlr.MultiGpuIndex(dim, [0])
+    one.upload(rows)
+    host = one.search_topk(qs, 100)
+    one.set_exchange("rccl")
+    got = one.search_topk(qs, 100)
+    assert np.array_equal(got[0], host[0]) and np.array_equal(bits(got[1]), bits(host[1]))
+    for i in range(len(qs)):
+        wr, wc = oracle_topk(oracle, rows, qs[i], 100)
+        assert np.array_equal(got[0][i], wr) and np.array_equal(bits(got[1][i]), bits(wc)), i
+    r1, c1 = one.search_topk(qs[0], 7)                      # other shapes reuse / regrow the exchange buffers
+    assert np.array_equal(r1[0], host[0][0][:7])
+    one.set_exchange("host")
+    one.close()
+    two = rlr.MultiGpuIndex(dim, [0, 0])
+    with pytest.raises(rlr.RlrError):
+        two.set_exchange("rccl")                            # RCCL wants one rank per device
+    two.close()
+    # four shards on one GPU, eight host threads searching at once: every answer still the oracle's
+    mi = rlr.MultiGpuIndex(dim, [0, 0, 0, 0])
+    mi.upload(rows)
+    want = [oracle_topk(oracle, rows, q, 20) for q in qs]
+    bad = []
+
+    def hammer(t):
+        for rep in range(12):
+            i = (t + rep) % len(qs)
+            r, c = mi.search_topk(qs[i], 20)
+            if not (np.array_equal(r[0], want[i][0]) and np.array_equal(bits(c[0]), bits(want[i][1]))):
+                bad.append((t, rep))
+
+    th = [threading.Thread(target=hammer, args=(t,)) for t in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad, bad
+    mi.close()
+
+
 @pytest.mark.parametrize("dim,dtype,n,nq,k", [
     (768, "f32", 70_001, 130, 100),    # one query block, partly filled; ragged last row tile
     (768, "f32", 300_000, 256, 100),   # sample + bootstrap + filtered main pass, every workgroup several units
