@@ -114,6 +114,32 @@ int32_t rlr_engine_embedding_candidates(rlr_index *idx, const float *query_raw, 
                                         uint32_t count, uint64_t *rows_out, float *scores_out,
                                         uint32_t *n_out);
 
+/* ---- corpus file at scale ---------------------------------------------------------
+ * `chunks_{model}.json` (PersistedState, rag_engine.rs:1478-1499; read whole with serde_json :1555-1557) read
+ * in one streaming pass over the memory-mapped file: the embedding arrays go straight into a dense row-major f32
+ * matrix (row r = the r-th chunk of the file; decimal -> binary64 correctly rounded -> binary32, serde_json's f32
+ * path; null = a non-finite value; shorter / longer arrays are zero-extended / truncated to `dim` like
+ * dot_product's zip :1778), everything else is copied verbatim into `meta_json`, the same document with every
+ * embedding array replaced by [] -- id, text, metadata, document_hashes, version, model: small enough for the
+ * host's own JSON library.  Buffers are malloc'ed; release them with rlr_json_free_corpus. */
+typedef struct rlr_json_corpus {
+    float *rows;       /* n_rows x dim */
+    uint64_t n_rows;
+    uint32_t dim;
+    char *meta_json;   /* NUL-terminated */
+    uint64_t meta_len;
+} rlr_json_corpus;
+int32_t rlr_json_load_corpus(const char *path, uint32_t dim, rlr_json_corpus *out);
+void rlr_json_free_corpus(rlr_json_corpus *c);
+/* The same, uploaded: replaces all rows of `idx` (rlr_index_upload; normalize_on_device = 1 reproduces the
+ * reference's re-normalise-on-load :1678-1680 on the GPU).  `meta_out` (nullable) receives the metadata document
+ * (rows == NULL there: they live in HBM). */
+int32_t rlr_index_load_json(rlr_index *idx, const char *path, int32_t normalize_on_device, rlr_json_corpus *meta_out);
+/* One embedding as save_to_disk writes it (:1477-1518, serde_json pretty printer): "[", one value per line at
+ * indent + 2 spaces -- the shortest decimal that reads back as the same binary32, non-finite as null -- and "]" at
+ * `indent`.  Returns the bytes needed; the text was written (no terminating NUL) only if that is <= cap. */
+uint64_t rlr_json_format_embedding(const float *v, uint32_t dim, uint32_t indent, char *out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,11 @@ class SearchHitC(C.Structure):
                 ("lexical_score", C.c_float), ("initial_score", C.c_float)]
 
 
+class JsonCorpusC(C.Structure):
+    _fields_ = [("rows", C.POINTER(C.c_float)), ("n_rows", C.c_uint64), ("dim", C.c_uint32),
+                ("meta_json", C.c_void_p), ("meta_len", C.c_uint64)]
+
+
 class ProfileC(C.Structure):
     _fields_ = [("n_searches", C.c_uint64), ("n_scan_launches", C.c_uint64),
                 ("scan_ms", C.c_double), ("select_ms", C.c_double), ("rescore_ms", C.c_double),
@@ -95,6 +100,10 @@ PROTOTYPES = [
                                          u32p]),
     ("rlr_search_diverse", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, u64p,
                                        f32p, f32p, u32p, i32p]),
+    ("rlr_json_load_corpus", C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(JsonCorpusC)]),
+    ("rlr_json_free_corpus", None, [C.POINTER(JsonCorpusC)]),
+    ("rlr_index_load_json", C.c_int32, [_H, C.c_char_p, C.c_int32, C.POINTER(JsonCorpusC)]),
+    ("rlr_json_format_embedding", C.c_uint64, [f32p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64]),
     ("rlr_multi_create", C.c_int32, [C.c_uint32, C.c_int32, C.c_int32, i32p, C.POINTER(_H)]),
     ("rlr_multi_destroy", C.c_int32, [_H]),
     ("rlr_multi_info", C.c_int32, [_H, u64p, u32p]),

@@ -18,7 +18,8 @@ OBJ = os.path.join(HERE, "_obj")
 SO = os.path.join(HERE, "librlr_gpu.so")
 ROOT = os.path.dirname(HERE)
 
-SOURCES = ["scan.hip", "select.hip", "exact.hip", "gemm.hip", "index.hip", "engine.cpp", "multi.cpp", "lexical.hip", "q8.hip"]
+SOURCES = ["scan.hip", "select.hip", "exact.hip", "gemm.hip", "index.hip", "engine.cpp", "multi.cpp", "lexical.hip", "q8.hip",
+           "jsonio.cpp"]
 HEADERS = ["common.h", "kernels.h", "exact_dot.h", os.path.join(ROOT, "include", "rlr_gpu.h"),
            os.path.join(ROOT, "include", "rlr_engine.h"), os.path.join(ROOT, "include", "rlr_lexical.h")]
 

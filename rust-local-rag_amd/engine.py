@@ -80,6 +80,7 @@ class DocumentChunk:  # rag_engine.rs:46-59 (embedding lives in HBM, not here)
     chunk_index: int
     page_number: int = 0
     section: Optional[str] = None
+    metadata: Optional[dict] = None  # ChunkMetadata (:61-70) as loaded; written back unchanged by save_to_disk
 
 
 @dataclass

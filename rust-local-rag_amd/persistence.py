@@ -20,6 +20,7 @@ JSON numbers go through binary64 and are rounded to binary32, like serde_json's 
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
 import os
 from dataclasses import dataclass, field
@@ -27,6 +28,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
+from . import _native as N
 from .engine import DocumentChunk, RagEngine
 
 
@@ -60,42 +62,101 @@ class LoadReport:
     document_hashes: Dict[str, str] = field(default_factory=dict)
 
 
-def _f32_text(x: np.float32) -> str:
-    """shortest decimal that round-trips the binary32 value (what serde_json prints for f32)"""
-    return np.format_float_positional(x, unique=True, trim="0") if np.isfinite(x) else "null"
+DEFAULT_METADATA = {"page_range": None, "sentence_range": None, "section_title": None, "token_count": 0,
+                    "overlap_with_previous": 0}
+
+
+def _embedding_text(row: np.ndarray, indent: int, buf) -> str:
+    """one embedding array as serde_json's pretty printer lays it out, every value the shortest decimal that reads
+    back as the same binary32 (rlr_json_format_embedding: std::to_chars; non-finite -> null)"""
+    row = np.ascontiguousarray(row, dtype=np.float32)
+    L = N.lib()
+    n = L.rlr_json_format_embedding(row.ctypes.data_as(N.f32p), row.size, indent, buf, len(buf))
+    if n > len(buf):
+        raise RuntimeError("embedding text buffer too small")
+    return buf.raw[:n].decode("ascii")
+
+
+def _member(key: str, value, indent: int) -> str:
+    """`"key": value` with nested containers indented like json.dumps(indent=2) at depth `indent`"""
+    text = json.dumps(value, indent=2, ensure_ascii=False)
+    if "\n" in text:
+        text = text.replace("\n", "\n" + " " * indent)
+    return " " * indent + json.dumps(key, ensure_ascii=False) + ": " + text
 
 
 def save_to_disk(engine: RagEngine, data_dir: str, model_name: str, needs_reindex: bool = False,
                  document_hashes: Optional[Dict[str, str]] = None, metadata: Optional[Dict[str, dict]] = None) -> str:
-    """rag_engine.rs:1477-1518: version 2 state, pretty-printed, written to `<final>.json.tmp` then renamed."""
+    """rag_engine.rs:1477-1518: version 2 state, pretty-printed, written to `<final>.json.tmp` then renamed.
+    One streaming pass: chunk objects are written one after the other with their embedding lines (rows fetched from
+    the GPU in blocks), so the cost is linear in the file size.  Each chunk's `metadata` is what was loaded with it
+    (DocumentChunk.metadata), or the entry of the `metadata` argument for its id, or the defaults."""
     final_path = get_index_path(data_dir, model_name)
     temp_path = final_path[: -len(".json")] + ".json.tmp"
     n = len(engine)
-    rows = engine.index.fetch_rows(np.arange(n, dtype=np.uint64)) if n else np.zeros((0, engine.dim), np.float32)
-    chunks = {}
-    for r, ch in enumerate(engine._chunks):
-        md = (metadata or {}).get(ch.id) or {"page_range": None, "sentence_range": None, "section_title": None,
-                                            "token_count": 0, "overlap_with_previous": 0}
-        chunks[ch.id] = {"id": ch.id, "document_name": ch.document_name, "text": ch.text,
-                         "embedding": f"@@EMB{r}@@", "chunk_index": ch.chunk_index,
-                         "page_number": ch.page_number, "section": ch.section, "metadata": md}
-    state = {"version": 2, "model": model_name, "chunks": chunks, "needs_reindex": bool(needs_reindex)}
-    if document_hashes:  # skip_serializing_if = "HashMap::is_empty"
-        state["document_hashes"] = dict(document_hashes)
-    text = json.dumps(state, indent=2, ensure_ascii=False)
-    # embeddings are spliced in as shortest-round-trip binary32 literals, one per line like
-    # serde_json's pretty printer (json.dumps would print the binary64 expansion of each value)
-    pad, pad_close = " " * 8, " " * 6
-    for r in range(n):
-        body = ",\n".join(pad + _f32_text(v) for v in rows[r])
-        text = text.replace(f'"@@EMB{r}@@"', "[\n" + body + "\n" + pad_close + "]" if rows.shape[1] else "[]", 1)
+    dim = engine.dim
+    buf = C.create_string_buffer(max(dim, 1) * 40 + 64)
+    block = max(1, min(n, (64 << 20) // (4 * max(dim, 1))))
     with open(temp_path, "w", encoding="utf-8") as f:
-        f.write(text)
+        f.write("{\n")
+        f.write(_member("version", 2, 2) + ",\n")
+        f.write(_member("model", model_name, 2) + ",\n")
+        f.write('  "chunks": {' + ("\n" if n else ""))
+        for r0 in range(0, n, block):
+            r1 = min(n, r0 + block)
+            rows = engine.index.fetch_rows(np.arange(r0, r1, dtype=np.uint64))
+            for r in range(r0, r1):
+                ch = engine._chunks[r]
+                md = (metadata or {}).get(ch.id) or ch.metadata or DEFAULT_METADATA
+                f.write("    " + json.dumps(ch.id, ensure_ascii=False) + ": {\n")
+                f.write(_member("id", ch.id, 6) + ",\n")
+                f.write(_member("document_name", ch.document_name, 6) + ",\n")
+                f.write(_member("text", ch.text, 6) + ",\n")
+                f.write('      "embedding": ' + _embedding_text(rows[r - r0], 6, buf) + ",\n")
+                f.write(_member("chunk_index", ch.chunk_index, 6) + ",\n")
+                f.write(_member("page_number", ch.page_number, 6) + ",\n")
+                f.write(_member("section", ch.section, 6) + ",\n")
+                f.write(_member("metadata", md, 6) + "\n")
+                f.write("    }" + (",\n" if r + 1 < n else "\n"))
+        f.write(("  }" if n else "}") + ",\n")
+        f.write(_member("needs_reindex", bool(needs_reindex), 2))
+        if document_hashes:  # skip_serializing_if = "HashMap::is_empty"
+            f.write(",\n" + _member("document_hashes", dict(document_hashes), 2))
+        f.write("\n}")
     os.replace(temp_path, final_path)  # atomic commit
     return final_path
 
 
-def _apply_loaded_state(engine: RagEngine, state: dict, source: str, data_dir: str, model_name: str,
+def _read_state(path: str, dim: int, native: bool):
+    """-> (state dict whose chunks carry no embeddings, rows f32 [n, dim]) in file order.
+    native: one streaming pass in C++ over the memory-mapped file (rlr_json_load_corpus); else the json module
+    (the comparator the parity test holds the native reader against)."""
+    if native:
+        c = N.JsonCorpusC()
+        N.check(N.lib().rlr_json_load_corpus(os.fsencode(path), dim, C.byref(c)))
+        try:
+            n = int(c.n_rows)
+            rows = np.ctypeslib.as_array(c.rows, shape=(n * dim,)).reshape(n, dim).copy() if n else \
+                np.zeros((0, dim), np.float32)
+            state = json.loads(C.string_at(c.meta_json, c.meta_len).decode("utf-8"))
+        finally:
+            N.lib().rlr_json_free_corpus(C.byref(c))
+        return state, rows
+    with open(path, encoding="utf-8") as f:
+        state = json.load(f)
+    chunks = state.get("chunks", {}) if isinstance(state, dict) else {}
+    rows = np.zeros((len(chunks) if isinstance(chunks, dict) else 0, dim), dtype=np.float32)
+    if isinstance(chunks, dict):
+        for r, c in enumerate(chunks.values()):
+            if not isinstance(c, dict):
+                continue
+            emb = np.asarray(c.get("embedding", []), dtype=np.float64).astype(np.float32)
+            m = min(emb.size, dim)  # dot_product's zip truncates / a short row contributes zeros
+            rows[r, :m] = emb[:m]
+    return state, rows
+
+
+def _apply_loaded_state(engine: RagEngine, state: dict, rows: np.ndarray, source: str, data_dir: str, model_name: str,
                         migrate: bool) -> LoadReport:
     """rag_engine.rs:1655-1709"""
     rep = LoadReport(source=source)
@@ -111,15 +172,13 @@ def _apply_loaded_state(engine: RagEngine, state: dict, source: str, data_dir: s
     chunks = state.get("chunks", {})
     ids = list(chunks.keys())
     n = len(ids)
-    rows = np.zeros((n, engine.dim), dtype=np.float32)
     metas = []
     for r, cid in enumerate(ids):
         c = chunks[cid]
-        emb = np.asarray(c.get("embedding", []), dtype=np.float64).astype(np.float32)
-        m = min(emb.size, engine.dim)  # dot_product's zip truncates / a short row contributes zeros
-        rows[r, :m] = emb[:m]
+        md = c.get("metadata")
         metas.append(DocumentChunk(c.get("id", cid), c.get("document_name", ""), c.get("text", ""),
-                                   int(c.get("chunk_index", 0)), int(c.get("page_number", 0)), c.get("section")))
+                                   int(c.get("chunk_index", 0)), int(c.get("page_number", 0)), c.get("section"),
+                                   md if isinstance(md, dict) else None))
     # `for chunk in self.chunks.values_mut() { normalize(&mut chunk.embedding) }` (:1678-1680), on the GPU
     engine.index.upload(rows, normalize=True)
     engine._chunks = metas
@@ -136,7 +195,7 @@ def _apply_loaded_state(engine: RagEngine, state: dict, source: str, data_dir: s
     # validate_index_sync (:1373-1425): drop hashes of documents that have no chunks left
     docs = {ch.document_name for ch in metas}
     rep.document_hashes = {d: h for d, h in rep.document_hashes.items() if d in docs}
-    if migrate:  # :1699-1706  legacy file is preserved
+    if migrate:  # :1699-1706  legacy file is preserved; the chunks' metadata goes back out as it came in
         save_to_disk(engine, data_dir, model_name, rep.needs_reindex, rep.document_hashes)
         rep.migrated = True
     return rep
@@ -167,7 +226,7 @@ def save_sidecar(engine: RagEngine, data_dir: str, model_name: str, report: "Loa
     rows = engine.index.fetch_rows(np.arange(n, dtype=np.uint64)) if n else np.zeros((0, engine.dim), np.float32)
     header = {"model": model_name, "dim": engine.dim, "n": n, "source": _file_identity(src),
               "needs_reindex": bool(report.needs_reindex), "document_hashes": report.document_hashes,
-              "chunks": [[ch.id, ch.document_name, ch.text, ch.chunk_index, ch.page_number, ch.section]
+              "chunks": [[ch.id, ch.document_name, ch.text, ch.chunk_index, ch.page_number, ch.section, ch.metadata]
                          for ch in engine._chunks]}
     blob = json.dumps(header, ensure_ascii=False).encode("utf-8")
     path = get_sidecar_path(data_dir, model_name)
@@ -210,38 +269,37 @@ def _load_sidecar(engine: RagEngine, data_dir: str, model_name: str) -> Optional
                       document_hashes=dict(header.get("document_hashes", {})))
 
 
-def load_from_disk(engine: RagEngine, data_dir: str, model_name: str, use_sidecar: bool = False) -> LoadReport:
+def load_from_disk(engine: RagEngine, data_dir: str, model_name: str, use_sidecar: bool = False,
+                   native: bool = True) -> LoadReport:
     """rag_engine.rs:1520-1653.  use_sidecar: take the binary cache when it matches the JSON file, and (re)write it
-    after a JSON load."""
+    after a JSON load.  native: read the file with the streaming C++ reader (default) or with the json module."""
     model_path = get_index_path(data_dir, model_name)
     legacy_path = get_legacy_path(data_dir)
     if use_sidecar:
         rep = _load_sidecar(engine, data_dir, model_name)
         if rep is not None:
             return rep
-        rep = load_from_disk(engine, data_dir, model_name, use_sidecar=False)
+        rep = load_from_disk(engine, data_dir, model_name, use_sidecar=False, native=native)
         if rep.source == model_path and os.path.exists(model_path):
             save_sidecar(engine, data_dir, model_name, rep)
         return rep
     if os.path.exists(model_path):
         try:
-            with open(model_path, encoding="utf-8") as f:
-                state = json.load(f)
+            state, rows = _read_state(model_path, engine.dim, native)
             if not isinstance(state, dict) or "version" not in state or "model" not in state or "chunks" not in state:
                 raise ValueError("missing field")
-        except (ValueError, OSError):
+        except (ValueError, OSError, N.RlrError):
             # corrupted model-specific file: keep it for inspection, start empty, mark for reindex (:1571-1585)
             return LoadReport(source=None, needs_reindex=True)
-        return _apply_loaded_state(engine, state, model_path, data_dir, model_name, migrate=False)
+        return _apply_loaded_state(engine, state, rows, model_path, data_dir, model_name, migrate=False)
     if os.path.exists(legacy_path):
         try:
-            with open(legacy_path, encoding="utf-8") as f:
-                state = json.load(f)
-        except (ValueError, OSError):
-            state = None
+            state, rows = _read_state(legacy_path, engine.dim, native)
+        except (ValueError, OSError, N.RlrError):
+            state, rows = None, None
         if isinstance(state, dict) and isinstance(state.get("model"), str):
             if state["model"] == model_name and "version" in state and "chunks" in state:
-                return _apply_loaded_state(engine, state, legacy_path, data_dir, model_name, migrate=True)
+                return _apply_loaded_state(engine, state, rows, legacy_path, data_dir, model_name, migrate=True)
             # belongs to another model: preserved, start fresh (:1620-1628)
             return LoadReport()
         if isinstance(state, dict) and state and all(isinstance(v, dict) for v in state.values()):

@@ -139,3 +139,159 @@ def test_legacy_migration_and_model_mismatch(rlr, tmp_path):
     rep = rlr.load_from_disk(eng3, d, "broken")
     assert rep.needs_reindex and rep.n_chunks == 0 and os.path.exists(bad)
     eng.close(); eng3.close()
+
+
+# ---------------------------------------------------------------- f1 at scale: streaming reader / writer (host code)
+def _native_read(rlr, path, dim):
+    import ctypes as C
+    N = rlr._native
+    c = N.JsonCorpusC()
+    N.check(N.lib().rlr_json_load_corpus(os.fsencode(path), dim, C.byref(c)))
+    n = int(c.n_rows)
+    rows = np.ctypeslib.as_array(c.rows, shape=(max(n * dim, 1),))[: n * dim].reshape(n, dim).copy()
+    meta = C.string_at(c.meta_json, c.meta_len).decode("utf-8")
+    N.lib().rlr_json_free_corpus(C.byref(c))
+    return rows, meta
+
+
+def test_streaming_reader_equals_the_json_module_on_hostile_documents(rlr, tmp_path):
+    """rlr_json_load_corpus against json.load + float64 -> float32 (what serde_json's f32 path does): strings that
+    contain the key it looks for, escapes, exponents, integers, null, short / long / missing / repeated embeddings,
+    nested metadata, compact and pretty layouts -- rows bit-identical, metadata document = the file with every
+    embedding array replaced by []."""
+    persistence = __import__("importlib").import_module("rust-local-rag_amd.persistence")
+    dim = 6
+    chunks = {
+        "a": {"id": "a", "text": 'he said "embedding": [9, 9, 9] \\" and left', "embedding": [1, -2.5, 3e-3, 4E+2, -0.0, 1e-50],
+              "metadata": {"page_range": [1, 2], "nested": {"embedding": [7, 7]}}},
+        "b\"q": {"embedding": [0.1, 0.2], "text": "short row é中", "document_name": "d.pdf"},
+        "c": {"text": "long row", "embedding": [1, 2, 3, 4, 5, 6, 7, 8, 9]},
+        "d": {"text": "no embedding at all"},
+        "e": {"embedding": [], "text": "empty"},
+        "f": {"embedding": [1.0000001, 16777217, 3.4028235e38, 1e39, -1e39, 1.401298464324817e-45], "text": "edges"},
+        "g": {"text": "null inside", "embedding": [None, 2, None]},
+    }
+    state = {"version": 2, "model": "m", "document_hashes": {"d.pdf": "h"}, "chunks": chunks, "needs_reindex": False,
+             "embedding": [5, 5], "trailer": {"chunks": {"x": {"embedding": [1]}}}}
+    for name, kw in (("compact.json", dict(separators=(",", ":"))), ("pretty.json", dict(indent=2)),
+                     ("ascii.json", dict(indent=1, ensure_ascii=True))):
+        path = str(tmp_path / name)
+        with open(path, "w", encoding="utf-8") as f:
+            json.dump(state, f, ensure_ascii=kw.pop("ensure_ascii", False), **kw)
+        rows, meta = _native_read(rlr, path, dim)
+        want_state, want_rows = persistence._read_state(path, dim, native=False)
+        assert rows.shape == (len(chunks), dim)
+        with np.errstate(over="ignore"):
+            assert np.array_equal(bits(rows), bits(want_rows)), name
+        got_state = json.loads(meta)
+        stripped = json.loads(json.dumps(state))
+        for c in stripped["chunks"].values():
+            if "embedding" in c:
+                c["embedding"] = []
+        assert got_state == stripped, name                      # top-level "embedding" and the trailer stay untouched
+        assert list(got_state["chunks"].keys()) == list(chunks.keys())
+    # a repeated key: the last one wins, as in every JSON map
+    path = str(tmp_path / "dup.json")
+    open(path, "w").write('{"chunks": {"k": {"embedding": [1, 1], "embedding": [2]}}, "version": 2, "model": "m"}')
+    rows, meta = _native_read(rlr, path, 3)
+    assert rows.tolist() == [[2.0, 0.0, 0.0]]
+    # malformed input is an error, not a guess
+    for bad in ('{"chunks": {"k": {"embedding": [1, 2', '{"chunks": {"k": {"embedding": [1, x]}}}', "[1, 2]", ""):
+        path = str(tmp_path / "bad.json")
+        open(path, "w").write(bad)
+        with pytest.raises(rlr.RlrError):
+            _native_read(rlr, path, 3)
+
+
+def test_embedding_text_is_the_shortest_round_trip_decimal(rlr):
+    import ctypes as C
+    N = rlr._native
+    rng = np.random.default_rng(12)
+    vals = np.concatenate([rng.standard_normal(500).astype(np.float32),
+                           rng.integers(0, 2 ** 32, 500, dtype=np.uint64).astype(np.uint32).view(np.float32),
+                           np.array([0.0, -0.0, 1.0, -3.0, 16777216.0, 1e-45, 3.4028235e38, 0.1, 1 / 3], np.float32)])
+    finite = np.isfinite(vals)
+    buf = C.create_string_buffer(vals.size * 40 + 64)
+    n = N.lib().rlr_json_format_embedding(vals.ctypes.data_as(N.f32p), vals.size, 6, buf, len(buf))
+    text = buf.raw[:n].decode("ascii")
+    lines = text.split("\n")
+    assert lines[0] == "[" and lines[-1] == "      ]" and len(lines) == vals.size + 2
+    assert all(l.startswith("        ") and not l.startswith("         ") for l in lines[1:-1])
+    back = json.loads(text)
+    got = np.array([np.nan if x is None else x for x in back], dtype=np.float64).astype(np.float32)
+    assert np.array_equal(bits(got[finite]), bits(vals[finite]))              # reads back as the same binary32
+    assert all(back[i] is None for i in np.flatnonzero(~finite))               # serde_json writes null for NaN / inf
+    for i in np.flatnonzero(finite)[:200]:                                     # and no shorter decimal does
+        s = lines[1 + i].strip().rstrip(",")
+        mant = s.split("e")[0].replace("-", "").replace(".", "").lstrip("0")
+        assert len(mant.rstrip("0")) <= 9
+        assert "." in s or "e" in s                                           # floats stay floats ("1.0", not "1")
+    assert N.lib().rlr_json_format_embedding(vals.ctypes.data_as(N.f32p), 0, 4, buf, len(buf)) == 2 and buf.raw[:2] == b"[]"
+    assert N.lib().rlr_json_format_embedding(vals.ctypes.data_as(N.f32p), 10, 4, buf, 5) > 5   # too small: size only
+
+
+def test_streaming_reader_is_faster_than_whole_file_parsing(rlr, tmp_path):
+    """4000 chunks x 768 (a 40 MB file): same rows as the json module, in a fraction of its time"""
+    import time
+    persistence = __import__("importlib").import_module("rust-local-rag_amd.persistence")
+    n, dim = 4000, 768
+    raw = np.random.default_rng(1).standard_normal((n, dim)).astype(np.float32)
+    path = str(tmp_path / "big.json")
+    with open(path, "w") as f:
+        f.write('{"version": 2, "model": "m", "chunks": {')
+        for i in range(n):
+            f.write(("," if i else "") + json.dumps(f"id{i}") + ": " +
+                    json.dumps({"id": f"id{i}", "text": f"t{i}", "embedding": [float(x) for x in raw[i]], "chunk_index": i}))
+        f.write('}, "needs_reindex": false}')
+    t0 = time.perf_counter()
+    rows, meta = _native_read(rlr, path, dim)
+    t_native = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, want = persistence._read_state(path, dim, native=False)
+    t_python = time.perf_counter() - t0
+    assert np.array_equal(bits(rows), bits(want)) and np.array_equal(bits(rows), bits(raw))
+    assert len(json.loads(meta)["chunks"]) == n
+    assert t_native < t_python, (t_native, t_python)
+
+
+@pytest.mark.gpu
+def test_metadata_survives_load_save_load_and_both_readers_agree(rlr, oracle, tmp_path):
+    """ChunkMetadata written back unchanged (rag_engine.rs:1477-1518, :1699-1706), also through the legacy migration;
+    the native and the json-module readers give byte-identical device rows."""
+    dim, n, model = 64, 40, "meta-model"
+    raw = (np.random.default_rng(8).standard_normal((n, dim)) * 2).astype(np.float32)
+    chunks = {}
+    for i in range(n):
+        c = _chunk(f"k{i}", f"doc{i % 3}.pdf", raw[i], i, page=2 + i)
+        c["metadata"] = {"page_range": [2 + i, 3 + i], "sentence_range": [i, i + 4], "section_title": f"S {i}" if i % 2 else None,
+                         "token_count": 100 + i, "overlap_with_previous": i % 3}
+        c["section"] = f"sec{i}" if i % 5 == 0 else None
+        chunks[f"k{i}"] = c
+    hashes = {"doc0.pdf": "a", "doc1.pdf": "b", "doc2.pdf": "c"}
+    _write(rlr.get_legacy_path(str(tmp_path)), {"version": 2, "model": model, "chunks": chunks, "needs_reindex": False,
+                                                "document_hashes": hashes})
+    a = rlr.RagEngine(dim)
+    rep = rlr.load_from_disk(a, str(tmp_path), model)                       # legacy -> migrated model file
+    assert rep.migrated and rep.n_chunks == n
+    migrated = json.load(open(rlr.get_index_path(str(tmp_path), model)))
+    assert list(migrated["chunks"].keys()) == list(chunks.keys())
+    for cid, c in chunks.items():
+        m = migrated["chunks"][cid]
+        assert m["metadata"] == c["metadata"] and m["section"] == c["section"] and m["page_number"] == c["page_number"]
+        assert m["text"] == c["text"] and m["chunk_index"] == c["chunk_index"]
+    assert migrated["document_hashes"] == hashes and migrated["model"] == model and migrated["version"] == 2
+    b, c_ = rlr.RagEngine(dim), rlr.RagEngine(dim)
+    rb = rlr.load_from_disk(b, str(tmp_path), model, native=True)
+    rc = rlr.load_from_disk(c_, str(tmp_path), model, native=False)
+    assert rb.n_chunks == rc.n_chunks == n and rb.document_hashes == rc.document_hashes
+    assert np.array_equal(bits(b.index.fetch_rows(np.arange(n))), bits(c_.index.fetch_rows(np.arange(n))))
+    assert [ch.metadata for ch in b._chunks] == [c["metadata"] for c in chunks.values()]
+    rlr.save_to_disk(b, str(tmp_path), model, document_hashes=rb.document_hashes)
+    again = json.load(open(rlr.get_index_path(str(tmp_path), model)))
+    assert {k: v["metadata"] for k, v in again["chunks"].items()} == {k: v["metadata"] for k, v in chunks.items()}
+    # the written file is what json.dumps(indent=2) would lay out, with one embedding value per line
+    text = open(rlr.get_index_path(str(tmp_path), model)).read()
+    assert text.startswith('{\n  "version": 2,\n  "model": "meta-model",\n  "chunks": {\n    "k0": {\n      "id": "k0",')
+    assert '\n      "embedding": [\n        ' in text and text.endswith("\n}")
+    for e in (a, b, c_):
+        e.close()
