@@ -405,21 +405,26 @@ def main():
             return ix.search_topk(qs[i], args.k)
         return sh.search_topk(qs[i], args.k)
 
-    # Untimed settle phase before the W warmup steps.  Two things are kept out of the timed region:
-    # (1) a cold GPU needs some hundred ms of work before clocks / HBM power state are at their sustained
-    # level; (2) the HIP runtime grows its per-queue launch resources once, about 200 searches (~1000
-    # kernel launches) into a process, which stalls that one call for 30-40 ms (measured with
-    # scratch/step_jitter.py: call 206 at every corpus size, never again afterwards).
-    t_settle, n_settle = time.perf_counter(), 0
+    # Untimed settle phase before the W warmup steps: a cold GPU needs some hundred ms of work before clocks and the
+    # HBM power state are at their sustained level.  (Round 1 also ran >= 256 calls here to keep "a one-off 30-40 ms
+    # HIP-runtime stall around call 206" out of the timed region.  A HIP API trace of 400 steps shows that stall
+    # BETWEEN two API calls, not inside one, and gc.callbacks puts the start of CPython's first full (generation-2)
+    # collection -- over the object graph `import torch` leaves behind -- at exactly that step
+    # (scratch/step_jitter.py, scratch/trace_stall.sh: 36 ms once, never with gc.freeze()).  It is the Python veneer's
+    # garbage collector, not the runtime and not the library; a Rust host has none.  So: collect once, freeze.)
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    t_settle = time.perf_counter()
     if dist:
         # every step holds a collective: all ranks must run the SAME number of settle steps, so the count cannot
         # depend on a local clock
-        for _ in range(768 if args.settle_ms > 0 else 0):
+        for _ in range(256 if args.settle_ms > 0 else 0):
             step(0)
     else:
-        while args.settle_ms > 0 and ((time.perf_counter() - t_settle) * 1e3 < args.settle_ms or n_settle < 256):
+        while args.settle_ms > 0 and (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
             step(0)
-            n_settle += 1
     for i in range(args.warmup):
         step(i)
 

@@ -116,7 +116,10 @@ int32_t rlr_index_enable_batch_image(rlr_index *idx, int32_t enable);
  *             reference order (rag_engine.rs:494) -- 3 KB, stays on the host so the staged
  *             query is bit-identical.
  *   k         results wanted per query (clamped to the index size).
- *   guard_eps half-width of the guard band; < 0 selects rlr_default_guard_eps(dim).
+ *   guard_eps half-width of the guard band FOR UNIT-NORM OPERANDS; < 0 selects rlr_default_guard_eps(dim).
+ *             The library widens it by |row|_max * |query|_max whenever that product exceeds 1 (rows stored
+ *             with normalize_on_device = 0 have their largest norm recorded at upload / append; the queries'
+ *             norms are taken per call), so unnormalised data keeps the exactness guarantee.
  *   rows_out  n_queries x k row numbers, cos_out n_queries x k scores, n_out[q] = count.
  * Result per query: the k rows with the largest reference-order dot product
  * (dot_product, rag_engine.rs:1777-1779), scores bit-identical to it, ordered by

@@ -911,8 +911,8 @@ hipError_t launch_normalize_store(float *staging, uint32_t n, uint32_t dim, int 
 {
     if (n == 0)
         return hipSuccess;
-    if (do_normalize)
-        hipLaunchKernelGGL(sumsq_kernel, dim3((n + 63) / 64), dim3(64), 0, s, staging, n, dim, norm_tmp);
+    // always: with do_normalize == 0 the caller still reads the row norms back (the guard band of unnormalised corpora)
+    hipLaunchKernelGGL(sumsq_kernel, dim3((n + 63) / 64), dim3(64), 0, s, staging, n, dim, norm_tmp);
     const size_t total = static_cast<size_t>(n) * pitch16 * (dtype == RLR_F16 ? 8 : 4);
     if (dtype == RLR_F16)
         hipLaunchKernelGGL(scale_store_kernel<true>, dim3(ew_blocks(total)), dim3(256), 0, s, staging, norm_tmp, n,

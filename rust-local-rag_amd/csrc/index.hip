@@ -134,6 +134,8 @@ struct rlr_index {
     int scan_variant = 0;
     uint32_t batch_min = 0;   // smallest batch that takes the matrix-core path; 0 = decide by the cost model,
                               // RLR_BATCH_MIN=n forces a threshold (a huge n disables the path)
+    float max_row_sumsq = 1.0f; // largest sum of squares of a row stored with normalize_on_device = 0 (>= 1): the guard
+                                // bands are derived for unit-norm operands and scale with |row| * |query|
     bool image_enabled = false; // keep a binary16 nomination image of the rows for the batched GEMM
     bool image_scan = false;    // single queries nominate over the image too (half the bytes of f32 rows)
     // optional 8-bit nomination copy for single queries (q8.hip): a quarter of the f32 bytes
@@ -414,6 +416,7 @@ int32_t ingest(rlr_index *ix, const float *rows, uint64_t n, uint64_t first, int
         return fail(RLR_E_OOM, "staging allocation failed");
     }
     int32_t st = RLR_OK;
+    std::vector<float> h_norm;
     for (uint64_t r0 = 0; r0 < n && st == RLR_OK; r0 += cr) {
         const uint64_t m = std::min(cr, n - r0);
         e = hipMemcpy(d_stage, rows + r0 * ix->dim, m * ix->dim * sizeof(float), hipMemcpyHostToDevice);
@@ -423,6 +426,14 @@ int32_t ingest(rlr_index *ix, const float *rows, uint64_t n, uint64_t first, int
                                        ix->dtype, d_norm, nullptr);
         if (e == hipSuccess)
             e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess && !normalize) {
+            // rows stored as given: remember the largest norm (NaN rows order last anyway; they do not widen the band)
+            h_norm.resize(m);
+            e = hipMemcpy(h_norm.data(), d_norm, m * sizeof(float), hipMemcpyDeviceToHost);
+            for (uint64_t i = 0; i < m && e == hipSuccess; ++i)
+                if (h_norm[i] > ix->max_row_sumsq)
+                    ix->max_row_sumsq = h_norm[i];
+        }
         if (e != hipSuccess)
             st = fail(RLR_E_HIP, "row ingest failed: %s", hipGetErrorString(e));
     }
@@ -437,7 +448,28 @@ struct SearchPlan {
     uint32_t cap;      // candidate capacity
     float two_eps;
     float two_eps_img; // band when the nomination scan ran over the binary16 image
+    float scale = 1.0f; // |row|_max * |query|_max when that exceeds 1 (the bands above already carry it)
 };
+
+// The guard bands are error bounds for unit-norm operands; every term of them is linear in |row| * |query|.
+// Rows stored with normalize_on_device = 0 and queries the caller did not normalise widen the band by that
+// product (norms rounded up); unit-norm data -- the reference's invariant, rag_engine.rs:359 / :494 -- gives 1.
+float band_scale(const rlr_index *ix, const float *queries, uint32_t nq)
+{
+    double qmax = 0.0;
+    for (uint32_t q = 0; q < nq; ++q) {
+        double s2 = 0.0;
+        const float *v = queries + static_cast<size_t>(q) * ix->dim;
+        for (uint32_t i = 0; i < ix->dim; ++i)
+            s2 += static_cast<double>(v[i]) * v[i];
+        if (s2 > qmax) // (a NaN query compares false: its scores are NaN and order last whatever the band)
+            qmax = s2;
+    }
+    const double f = std::sqrt(qmax) * std::sqrt(static_cast<double>(ix->max_row_sumsq)) * 1.000002;
+    if (!(f > 1.0001))
+        return 1.0f;
+    return std::isfinite(f) ? static_cast<float>(f) : 3.0e38f;
+}
 
 int32_t ctx_prepare(rlr_index *ix, Ctx *c, uint32_t nq, const SearchPlan &p)
 {
@@ -932,7 +964,7 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     // matrix-core pipeline -- about the cost of a single scan, scores in wavefront order (the tight f32 band)
     const bool use_multi = nq <= 8 && ix->dtype == RLR_F32 && ix->pitch16 % 64 == 0 && ix->pitch16 / 64 <= 4 &&
                            ix->pitch16 * 4 == ix->dim && !(ix->image_enabled && ix->d_image) && !env_is_one("RLR_NO_MULTI_SCAN");
-    const float eps_nom = use_multi ? 0.5f * p.two_eps : nomination_eps(ix->dim, ix->dtype);
+    const float eps_nom = use_multi ? 0.5f * p.two_eps : nomination_eps(ix->dim, ix->dtype) * p.scale;
     const float two_eps = 2.0f * eps_nom;
     // sample rows [0, S): large enough that the expected number of later rows above the sample's
     // k-th score (k * N / S) stays well inside the per-query candidate capacity.
@@ -1085,7 +1117,8 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     const uint32_t n = static_cast<uint32_t>(ix->n_rows);
     SearchPlan p;
     p.k = std::min<uint32_t>(k_req, n);
-    const float eps = guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim);
+    p.scale = band_scale(ix, queries, nq);
+    const float eps = (guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim)) * p.scale;
     p.two_eps = 2.0f * eps;
     p.two_eps_img = image_two_eps(ix, eps);
     p.cap = kLdsSortCap;
@@ -1365,6 +1398,7 @@ int32_t rlr_index_upload(rlr_index *ix, const float *rows, uint64_t n_rows, int3
         return fail(RLR_E_INVALID, "rows is null");
     RLR_TRY(use_device(ix));
     ix->n_rows = 0;
+    ix->max_row_sumsq = 1.0f;
     RLR_TRY(ensure_rows(ix, n_rows));
     RLR_TRY(ingest(ix, rows, n_rows, 0, normalize_on_device));
     ix->n_rows = n_rows;
@@ -1611,7 +1645,8 @@ int32_t rlr_search_topk_device_begin(rlr_index *ix, const float *queries, uint32
     lease.c = c; // released on every error path below
     SearchPlan p;
     p.k = k;
-    p.two_eps = 2.0f * (guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim));
+    p.scale = band_scale(ix, queries, n_queries);
+    p.two_eps = 2.0f * (guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim)) * p.scale;
     p.two_eps_img = image_two_eps(ix, p.two_eps * 0.5f);
     p.cap = kLdsSortCap;
     RLR_TRY(ctx_prepare(ix, c, n_queries, p));
@@ -1637,8 +1672,12 @@ int32_t rlr_search_topk_device_begin(rlr_index *ix, const float *queries, uint32
     for (uint32_t q = 0; q < n_queries && e == hipSuccess; ++q)
         e = enqueue_query(ix, c, q, p, out + static_cast<size_t>(q) * k, h_meta + q, timed);
     c->stream = own;
-    if (e != hipSuccess)
+    if (e != hipSuccess) {
+        // pipelines already enqueued on the caller's stream still use this context's buffers: wait for them before
+        // the lease hands the context back to the pool (ctx_acquire's recovery only knows the context's own stream)
+        (void)hipStreamSynchronize(s);
         return fail(RLR_E_HIP, "enqueue on the caller's stream failed: %s", hipGetErrorString(e));
+    }
     c->pending_stream = s;
     c->pending_timed = timed;
     c->pending_q = n_queries;
@@ -1888,7 +1927,8 @@ int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uin
     hipStream_t s = c->stream;
     SearchPlan p;
     p.k = fetch;
-    const float eps = guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim);
+    p.scale = band_scale(ix, query, 1);
+    const float eps = (guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim)) * p.scale;
     p.two_eps = 2.0f * eps;
     p.two_eps_img = image_two_eps(ix, eps);
     p.cap = kLdsSortCap;

@@ -870,6 +870,38 @@ def test_batch_image_same_results_and_tracks_mutation(rlr, oracle, dim, dtype):
     ix.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_unnormalised_rows_and_queries_keep_the_guarantee(rlr, oracle, dtype):
+    """rows of norm up to 40 stored as given and a query of norm 7 through the raw ABI: the guard bands are bounds for
+    unit-norm operands, so the library has to widen them by |row|_max * |query| -- single queries, a batch through the
+    matrix cores, the nomination image and the 8-bit copy must all still return the reference's rows and scores."""
+    n, dim = 60_000, 768
+    rng = np.random.default_rng(404)
+    base = oracle.synth_rows(n, dim, seed=4040, n_clusters=30, f16=False)
+    scale = rng.uniform(0.2, 40.0, size=(n, 1)).astype(np.float32)
+    rows = (base * scale).astype(np.float32)
+    if dtype == "f16":
+        rows = oracle.round_f16(rows)
+    qs = np.stack([oracle.synth_query(dim, seed=4100 + i) for i in range(24)])
+    qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True) * 7.0).astype(np.float32)
+    ix = rlr.GpuIndex(dim, dtype)
+    ix.upload(rows[: n // 2])
+    ix.append(rows[n // 2:])                                       # the recorded norm follows append as well
+    for mode in ("plain", "image", "image_scan", "q8"):
+        if mode == "q8":
+            ix.enable_batch_image(False, q8=True)
+        elif mode != "plain":
+            ix.enable_batch_image(True, single_query=(mode == "image_scan"))
+        r1, c1 = ix.search_topk(qs[0], 100)
+        wr, wc = oracle_topk(oracle, rows, qs[0], 100)
+        assert np.array_equal(r1[0], wr) and np.array_equal(bits(c1[0]), bits(wc)), mode
+        rb, cb = ix.search_topk(qs, 50)
+        for i in range(0, 24, 5):
+            wr, wc = oracle_topk(oracle, rows, qs[i], 50)
+            assert np.array_equal(rb[i], wr) and np.array_equal(bits(cb[i]), bits(wc)), (mode, i)
+    ix.close()
+
+
 def test_multi_index_rccl_exchange_world1_and_persistent_workers(rlr, oracle):
     """rlr_multi_set_exchange(m, 1): the partial top-k lists stay on the device, ncclAllGather (single-process
     communicator, here of one rank: the one-GPU box) + merge_topk_kernel -- same results as the host merge and as the
