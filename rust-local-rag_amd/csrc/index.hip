@@ -2033,7 +2033,11 @@ static int32_t mmr_batch_impl(rlr_index *ix, const uint64_t *pool_rows, const fl
     RLR_TRY(ctx_acquire(ix, &lease.c));
     Ctx *c = lease.c;
     hipStream_t s = c->stream;
-    const uint32_t QC = 64; // queries per pass: pool 64 x P x dim f32 + gram 64 x P x P
+    // queries per pass: the workspace (pool m x P x dim f32 + gram m x P x P) is capped at ~3 GB.  All queries of a
+    // pass run their greedy chains concurrently, one wavefront each, so the more queries per pass the better the
+    // chip is filled: at 64 per pass (the first version) 1024 pools took 16 rounds of gather + Gram + greedy + sync.
+    const uint64_t per_query = (pool_rows ? static_cast<uint64_t>(P) * ix->dim : 0) + static_cast<uint64_t>(P) * P + 3ull * P + 2;
+    const uint32_t QC = static_cast<uint32_t>(std::max<uint64_t>(64, std::min<uint64_t>(4096, (3ull << 30) / 4 / std::max<uint64_t>(per_query, 1))));
     std::vector<uint64_t> rows_chunk;
     for (uint32_t q0 = 0; q0 < n_queries; q0 += QC) {
         const uint32_t m = std::min(QC, n_queries - q0);
