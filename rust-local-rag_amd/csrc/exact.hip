@@ -464,13 +464,18 @@ __global__ __launch_bounds__(64) void gram_kernel(const float *__restrict__ pool
 // chunks in ascending k, so each sum is still the reference's strict left-to-right chain.  Reads
 // each pool row 2 x ceil(P/32) times from L2 instead of P times: 27 -> ~8 us per 300-row pool and
 // ~5x on the batched MMR.
-constexpr int kGT = 32;      // pairs per block side
 constexpr int kGK = 64;      // columns per staged chunk
 constexpr int kGPitch = 68;  // floats
 
+// R = side of the per-thread register tile of pairs: a workgroup (16 x 16 threads) owns a (16 R) x (16 R) block.
+// R = 2 (32 x 32 blocks, 55 of them for a 300-row pool) keeps many CUs busy for a single query; R = 4 (64 x 64)
+// halves the LDS reads per multiply (8 float4 per 64 products instead of 4 per 16) and is used for batches, where
+// there are thousands of blocks anyway: 3.7 -> see DESIGN.md for 1024 pools of 300 x 1024-d.
+template <int R>
 __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict__ pool, uint32_t P, uint32_t dim,
                                                          float *__restrict__ gram)
 {
+    constexpr int kGT = 16 * R; // pairs per block side
     __shared__ __attribute__((aligned(16))) float sa[kGT * kGPitch];
     __shared__ __attribute__((aligned(16))) float sb[kGT * kGPitch];
     pool += static_cast<size_t>(blockIdx.z) * P * dim;
@@ -484,10 +489,15 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
     const uint32_t bj = rem;
     const uint32_t i0 = bi * kGT, j0 = bj * kGT;
     const uint32_t t = threadIdx.x, ty = t >> 4, tx = t & 15;
-    float acc00 = 0.0f, acc01 = 0.0f, acc10 = 0.0f, acc11 = 0.0f;
+    float acc[R][R];
+#pragma unroll
+    for (int a = 0; a < R; ++a)
+#pragma unroll
+        for (int b = 0; b < R; ++b)
+            acc[a][b] = 0.0f;
     const bool vec = (dim & 3u) == 0;
-    // the next chunk's 64 rows x 64 columns travel global -> registers while the current chunk is multiplied out of
-    // LDS (one round of load latency per chunk used to sit between the two barriers: 41 -> see DESIGN.md)
+    // the next chunk's rows travel global -> registers while the current chunk is multiplied out of LDS (one round of
+    // load latency per chunk used to sit between the two barriers)
     constexpr int kPre = 2 * kGT * (kGK / 4) / 256; // float4 per thread per chunk
     float4 pre[kPre];
     auto fetch = [&](uint32_t k0) {
@@ -529,31 +539,35 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
         const bool more = k0 + kGK < dim;
         if (more)
             fetch(k0 + kGK);
-        const float4 *a0 = reinterpret_cast<const float4 *>(sa + ty * kGPitch);
-        const float4 *a1 = reinterpret_cast<const float4 *>(sa + (ty + 16) * kGPitch);
-        const float4 *b0 = reinterpret_cast<const float4 *>(sb + tx * kGPitch);
-        const float4 *b1 = reinterpret_cast<const float4 *>(sb + (tx + 16) * kGPitch);
         const uint32_t n4 = kc / 4;
+        // every sum is still the reference's strict left-to-right chain: k ascends, product rounded, then added
         for (uint32_t c = 0; c < n4; ++c) {
-            const float4 xa = a0[c], xb = a1[c], ya = b0[c], yb = b1[c];
-            float p;
-            p = xa.x * ya.x; acc00 = acc00 + p;  p = xa.y * ya.y; acc00 = acc00 + p;
-            p = xa.z * ya.z; acc00 = acc00 + p;  p = xa.w * ya.w; acc00 = acc00 + p;
-            p = xa.x * yb.x; acc01 = acc01 + p;  p = xa.y * yb.y; acc01 = acc01 + p;
-            p = xa.z * yb.z; acc01 = acc01 + p;  p = xa.w * yb.w; acc01 = acc01 + p;
-            p = xb.x * ya.x; acc10 = acc10 + p;  p = xb.y * ya.y; acc10 = acc10 + p;
-            p = xb.z * ya.z; acc10 = acc10 + p;  p = xb.w * ya.w; acc10 = acc10 + p;
-            p = xb.x * yb.x; acc11 = acc11 + p;  p = xb.y * yb.y; acc11 = acc11 + p;
-            p = xb.z * yb.z; acc11 = acc11 + p;  p = xb.w * yb.w; acc11 = acc11 + p;
+            float4 xa[R], yb[R];
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+                xa[a] = reinterpret_cast<const float4 *>(sa + (ty + 16 * a) * kGPitch)[c];
+#pragma unroll
+            for (int b = 0; b < R; ++b)
+                yb[b] = reinterpret_cast<const float4 *>(sb + (tx + 16 * b) * kGPitch)[c];
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int b = 0; b < R; ++b) {
+                    float p;
+                    p = xa[a].x * yb[b].x; acc[a][b] = acc[a][b] + p;
+                    p = xa[a].y * yb[b].y; acc[a][b] = acc[a][b] + p;
+                    p = xa[a].z * yb[b].z; acc[a][b] = acc[a][b] + p;
+                    p = xa[a].w * yb[b].w; acc[a][b] = acc[a][b] + p;
+                }
         }
         for (uint32_t e = n4 * 4; e < kc; ++e) { // dim % 4 tail
-            const float xa = sa[ty * kGPitch + e], xb = sa[(ty + 16) * kGPitch + e];
-            const float ya = sb[tx * kGPitch + e], yb = sb[(tx + 16) * kGPitch + e];
-            float p;
-            p = xa * ya; acc00 = acc00 + p;
-            p = xa * yb; acc01 = acc01 + p;
-            p = xb * ya; acc10 = acc10 + p;
-            p = xb * yb; acc11 = acc11 + p;
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int b = 0; b < R; ++b) {
+                    const float p = sa[(ty + 16 * a) * kGPitch + e] * sb[(tx + 16 * b) * kGPitch + e];
+                    acc[a][b] = acc[a][b] + p;
+                }
         }
         __syncthreads();
         if (more) {
@@ -561,16 +575,16 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
             __syncthreads();
         }
     }
-    const uint32_t ri[2] = {i0 + ty, i0 + ty + 16}, cj[2] = {j0 + tx, j0 + tx + 16};
-    const float v[2][2] = {{acc00, acc01}, {acc10, acc11}};
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < R; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-            if (ri[a] < P && cj[b] < P) {
-                gram[static_cast<size_t>(ri[a]) * P + cj[b]] = v[a][b];
-                gram[static_cast<size_t>(cj[b]) * P + ri[a]] = v[a][b]; // dot(i,j) == dot(j,i) bitwise
+        for (int b = 0; b < R; ++b) {
+            const uint32_t ri = i0 + ty + 16 * a, cj = j0 + tx + 16 * b;
+            if (ri < P && cj < P) {
+                gram[static_cast<size_t>(ri) * P + cj] = acc[a][b];
+                gram[static_cast<size_t>(cj) * P + ri] = acc[a][b]; // dot(i,j) == dot(j,i) bitwise
             }
+        }
 }
 
 __device__ inline bool finite_f(float x)
@@ -980,8 +994,13 @@ hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram,
         hipLaunchKernelGGL(gram_kernel, dim3((P + 63) / 64, P, n_queries), dim3(64), 0, s, pool, P, dim, gram);
         return hipGetLastError();
     }
-    const uint32_t nb = (P + kGT - 1) / kGT;
-    hipLaunchKernelGGL(gram_tiled_kernel, dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim, gram);
+    if (n_queries >= 8) {
+        const uint32_t nb = (P + 63) / 64;
+        hipLaunchKernelGGL(gram_tiled_kernel<4>, dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim, gram);
+    } else {
+        const uint32_t nb = (P + 31) / 32;
+        hipLaunchKernelGGL(gram_tiled_kernel<2>, dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim, gram);
+    }
     return hipGetLastError();
 }
 

@@ -1,0 +1,150 @@
+// TEST INFRASTRUCTURE -- a CPU stand-in for the device half of include/rlr_gpu.h, backed by the oracle, so that the
+// HOST code of the library (csrc/engine.cpp: lexical merge, fetch widening on rounding ties, pool sizing, reranker
+// blend; csrc/jsonio.cpp: the corpus-file reader and number formatter) can run under AddressSanitizer and
+// UndefinedBehaviorSanitizer on the CPU build (GPU sanitizers are not available on this pool).
+// Nothing here ships: it is linked only into tests/sanitize/host_san (see tests/test_host_sanitize_cpu.py).
+#include "../../include/rlr_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+extern "C" {
+void rlr_o_scan(const float *rows, size_t n, size_t d, const float *q, size_t dq, float *e_out);
+float rlr_o_dot(const float *a, size_t na, const float *b, size_t nb);
+size_t rlr_o_mmr(const float *emb, const float *score, size_t P, size_t d, size_t top_k, float lambda,
+                 uint32_t *order_out, float *mmr_out);
+void rlr_o_normalize(float *v, size_t n);
+}
+
+struct rlr_index {
+    uint32_t dim = 0;
+    std::vector<float> rows;
+    uint64_t n = 0;
+};
+
+static thread_local char g_err[256];
+
+namespace rlr {
+int32_t set_error(int32_t code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+} // namespace rlr
+
+extern "C" {
+
+const char *rlr_last_error(void) { return g_err; }
+
+int32_t rlr_index_create(uint32_t dim, int32_t, int32_t, rlr_index **out)
+{
+    *out = new rlr_index();
+    (*out)->dim = dim;
+    return RLR_OK;
+}
+
+int32_t rlr_index_destroy(rlr_index *ix)
+{
+    delete ix;
+    return RLR_OK;
+}
+
+int32_t rlr_index_info(const rlr_index *ix, uint64_t *n_rows, uint32_t *dim, int32_t *dtype, int32_t *device)
+{
+    if (n_rows) *n_rows = ix->n;
+    if (dim) *dim = ix->dim;
+    if (dtype) *dtype = RLR_F32;
+    if (device) *device = 0;
+    return RLR_OK;
+}
+
+int32_t rlr_index_upload(rlr_index *ix, const float *rows, uint64_t n_rows, int32_t normalize_on_device)
+{
+    ix->rows.assign(rows, rows + n_rows * ix->dim);
+    ix->n = n_rows;
+    if (normalize_on_device)
+        for (uint64_t r = 0; r < n_rows; ++r)
+            rlr_o_normalize(ix->rows.data() + r * ix->dim, ix->dim);
+    return RLR_OK;
+}
+
+// (score desc, NaN last, row asc): the build's definition of the reference's tie order
+int32_t rlr_search_topk(rlr_index *ix, const float *queries, uint32_t n_queries, uint32_t k, float, uint64_t *rows_out,
+                        float *cos_out, uint32_t *n_out)
+{
+    std::vector<float> e(ix->n);
+    std::vector<uint64_t> order(ix->n);
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        rlr_o_scan(ix->rows.data(), ix->n, ix->dim, queries + static_cast<size_t>(q) * ix->dim, ix->dim, e.data());
+        for (uint64_t r = 0; r < ix->n; ++r)
+            order[r] = r;
+        std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+            const bool an = std::isnan(e[a]), bn = std::isnan(e[b]);
+            if (an || bn)
+                return !an && bn;
+            return e[a] > e[b];
+        });
+        const uint32_t m = static_cast<uint32_t>(std::min<uint64_t>(k, ix->n));
+        for (uint32_t i = 0; i < m; ++i) {
+            rows_out[static_cast<size_t>(q) * k + i] = order[i];
+            cos_out[static_cast<size_t>(q) * k + i] = e[order[i]];
+        }
+        n_out[q] = m;
+    }
+    return RLR_OK;
+}
+
+int32_t rlr_score_rows(rlr_index *ix, const float *query, const uint64_t *rows, uint32_t n, float *cos_out)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        if (rows[i] >= ix->n)
+            return rlr::set_error(RLR_E_RANGE, "row out of range");
+        cos_out[i] = rlr_o_dot(query, ix->dim, ix->rows.data() + rows[i] * ix->dim, ix->dim);
+    }
+    return RLR_OK;
+}
+
+int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *pool_scores, uint32_t P, uint32_t k,
+                       float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out)
+{
+    std::vector<float> emb(static_cast<size_t>(P) * ix->dim);
+    for (uint32_t i = 0; i < P; ++i)
+        std::memcpy(emb.data() + static_cast<size_t>(i) * ix->dim, ix->rows.data() + pool_rows[i] * ix->dim, ix->dim * sizeof(float));
+    std::vector<float> mm(P ? P : 1);
+    *n_out = static_cast<uint32_t>(rlr_o_mmr(emb.data(), pool_scores, P, ix->dim, k, lambda, order_out, mm.data()));
+    if (mmr_out)
+        std::memcpy(mmr_out, mm.data(), *n_out * sizeof(float));
+    return RLR_OK;
+}
+
+int32_t rlr_mmr_select_batch(rlr_index *ix, const uint64_t *pool_rows, const float *pool_scores, const uint32_t *pool_sizes,
+                             uint32_t n_queries, uint32_t P, uint32_t k, float lambda, uint32_t *order_out, float *mmr_out,
+                             uint32_t *n_out)
+{
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        const int32_t st = rlr_mmr_select(ix, pool_rows + static_cast<size_t>(q) * P, pool_scores + static_cast<size_t>(q) * P,
+                                          pool_sizes[q], k, lambda, order_out + static_cast<size_t>(q) * P,
+                                          mmr_out ? mmr_out + static_cast<size_t>(q) * P : nullptr, &n_out[q]);
+        if (st != RLR_OK)
+            return st;
+    }
+    return RLR_OK;
+}
+
+// the fused device path does not exist here: always hand the query back to the two-call path
+int32_t rlr_search_diverse(rlr_index *, const float *, uint32_t, uint32_t, float, float, float, float, uint64_t *, float *,
+                           float *, uint32_t *n_out, int32_t *fallback)
+{
+    *n_out = 0;
+    *fallback = 1;
+    return RLR_OK;
+}
+
+} // extern "C"
