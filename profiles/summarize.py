@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output directories (gpurun_out/prof_*) into the small summaries kept
-under profiles/:  <tag>_kernel_stats.csv (verbatim --stats table) and <tag>_pmc.json
-(HBM traffic per launch of the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes).
+"""Condense rocprofv3 output directories (gpurun_out/<tag>_*) into the small summaries kept under profiles/.
 
-gfx950 corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB;
-FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so it is
-doubled; WRITE_SIZE is exact for 16-B/4-B per-lane streaming stores.
+  headline scan (kernel trace + the two HBM counter passes):
+      python profiles/summarize.py <tag> <kt dir> <fetch dir> <write dir> "<command>" [kernel substring]
+      -> <tag>_kernel_stats.csv (verbatim --stats table), <tag>_pmc.json (HBM traffic per launch)
 
-    python profiles/summarize.py r01 gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write "<command>"
+  any other run: the --stats table plus one JSON with the named kernels' averages, optional SQ / HBM counter passes:
+      python profiles/summarize.py kernels <out tag> <kt dir> "<command>" <substr,substr,...> [--pmc dir ...]
+      (counters are reported for the FIRST substring's kernel only)
+      -> <out tag>_kernel_stats.csv, <out tag>_kernels.json
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE reports
+exactly half of the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact for 16-B/4-B
+per-lane streaming stores.  SQ_* counters are reported as the mean per launch of the kernel they are filtered to
+(SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES cycles).
 """
 import collections
 import csv
@@ -17,28 +23,42 @@ import os
 import shutil
 import sys
 
-
-def counter_mean(d, counter, kernel_substr):
-    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
-    vals = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and kernel_substr in r["Kernel_Name"]:
-            vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    name = max(vals, key=lambda k: len(vals[k]))
-    v = vals[name]
-    return name, sum(v) / len(v), len(v)
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def main():
+def counter_means(d, kernel_substr):
+    """{counter: (mean per dispatch, dispatches)} of the kernel (by substring) with the most dispatches in `d`"""
+    fs = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    if not fs:
+        return "", {}
+    fs = fs[-1:]  # a re-used output directory keeps older runs' files: take the newest
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(fs[0])):
+        if kernel_substr in r["Kernel_Name"]:
+            vals[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if not vals:
+        return "", {}
+    name = max(vals, key=lambda k: max(len(v) for v in vals[k].values()))
+    return name, {c: (sum(v) / len(v), len(v), max(v)) for c, v in vals[name].items()}
+
+
+def stats_rows(d_kt):
+    fs = sorted(glob.glob(os.path.join(d_kt, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    if not fs:
+        raise SystemExit(f"no kernel_stats.csv under {d_kt}")
+    return fs[-1], list(csv.DictReader(open(fs[-1])))  # newest: a re-used directory keeps older runs' files
+
+
+def headline():
     tag, d_kt, d_fetch, d_write, command = sys.argv[1:6]
     kernel = sys.argv[6] if len(sys.argv) > 6 else "scan_"
-    here = os.path.dirname(os.path.abspath(__file__))
-    stats = glob.glob(os.path.join(d_kt, "**", "*_kernel_stats.csv"), recursive=True)[0]
-    shutil.copy(stats, os.path.join(here, f"{tag}_kernel_stats.csv"))
-    rows = list(csv.DictReader(open(stats)))
+    stats, rows = stats_rows(d_kt)
+    shutil.copy(stats, os.path.join(HERE, f"{tag}_kernel_stats.csv"))
     dom = next(r for r in rows if kernel in r["Name"])
-    name, fetch_kib, n_f = counter_mean(d_fetch, "FETCH_SIZE", kernel)
-    _, write_kib, n_w = counter_mean(d_write, "WRITE_SIZE", kernel)
+    name, f = counter_means(d_fetch, kernel)
+    _, w = counter_means(d_write, kernel)
+    fetch_kib, n_f, _ = f["FETCH_SIZE"]
+    write_kib, n_w, _ = w["WRITE_SIZE"]
     out = {
         "command": command,
         "kernel": name,
@@ -51,10 +71,45 @@ def main():
                 "write_bytes": write_kib * 1024.0,
                 "hbm_bytes_per_launch": 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0},
     }
-    with open(os.path.join(here, f"{tag}_pmc.json"), "w") as f:
-        json.dump(out, f, indent=1)
+    with open(os.path.join(HERE, f"{tag}_pmc.json"), "w") as fo:
+        json.dump(out, fo, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+def kernels():
+    tag, d_kt, command, subs = sys.argv[2:6]
+    pmc_dirs = sys.argv[7:] if len(sys.argv) > 6 and sys.argv[6] == "--pmc" else []
+    stats, rows = stats_rows(d_kt)
+    shutil.copy(stats, os.path.join(HERE, f"{tag}_kernel_stats.csv"))
+    out = {"command": command, "kernels": {}}
+    for sub in subs.split(","):
+        hit = [r for r in rows if sub in r["Name"]]
+        for r in hit:
+            entry = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
+                     "max_us": float(r["MaxNs"]) / 1e3, "pct_of_gpu_time": float(r["Percentage"])}
+            key = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("rlr::", "").split("(")[0]
+            if key.startswith("_Z"):  # a mangled name the tool left as it was: keep the readable middle
+                key = next((w for w in ("prep_queries_kernel", "build_image_kernel", "gemm_resident_kernel") if w in key), key)
+            out["kernels"][key] = entry
+        if pmc_dirs and sub == subs.split(",")[0]:
+            # counters of the FIRST kernel of the list only (the dominant one); `max` = its largest launch (a batch
+            # launches the same kernel over a small and a large row range: the large one is the one the claims are about)
+            counters = {}
+            for d in pmc_dirs:
+                kname, c = counter_means(d, sub)
+                for k, (mean, n, mx) in c.items():
+                    counters[k] = {"mean_per_launch": mean, "max_launch": mx, "launches": n}
+            if "FETCH_SIZE" in counters:
+                counters["FETCH_SIZE"]["max_launch_bytes_corrected_x2"] = 2.0 * 1024.0 * counters["FETCH_SIZE"]["max_launch"]
+            if counters:
+                out["counters"] = {"kernel": kname, "values": counters}
+    with open(os.path.join(HERE, f"{tag}_kernels.json"), "w") as fo:
+        json.dump(out, fo, indent=1)
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "kernels":
+        kernels()
+    else:
+        headline()

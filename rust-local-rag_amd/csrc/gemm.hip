@@ -322,22 +322,10 @@ __global__ __launch_bounds__(256) void build_image_kernel(const unsigned char *_
     }
 }
 
-// GEMM over the image.  Wave tile = 64 rows x 128 queries (wave w: rows 64*(w/2).., queries
-// 128*(w%2)..): the same 32 accumulator tiles as a 32 x 256 wave tile, but a K-step needs 8 B
-// fragments from LDS instead of 16 (LDS fragment latency, not bandwidth, paces this kernel: MFMA
-// pipe 31 % busy with 16), and 4 A fragments which come straight from the image (lane-linear 1 KiB
-// loads; the two waves that share rows hit L1/L2 on the second read).  A fragments rotate through
-// two register slots (the slot a phase has just consumed is refilled with the chunk after next),
-// B fragments are read two steps ahead; every workgroup walks the K-chunks in its own rotation so
-// the 256 CUs do not all read the same lines of the shared query image at once (-3 %).
-// Timing ablations of this kernel (256 queries x 10M x 768, 5.7 ms): without the per-phase B
-// (query chunk) global->LDS staging and barrier 3.4 ms, without the barrier alone 5.3 ms, without
-// the A (row) loads 5.1 ms; staging B with global_load_lds instead of registers: 5.7 ms.  The query
-// chunk re-read per 256-row tile (32 KB per phase, as many bytes as the rows themselves) is the
-// cost to attack next (larger row tile per staged chunk).
-// the loop is branch-free (past the end the last chunk is fetched again, never used).
+// Wave tiles over the image are 64 rows x (16 NBW) queries: 4 row groups of 16; A fragments come straight from the
+// image (lane-linear 1 KiB loads).  Used by the resident-query kernel below; the main batched kernel (gemm8_kernel)
+// stages both operands through LDS instead.
 constexpr int kRGI = 4;          // row groups per wave in the image kernel
-constexpr int kNBI = kNB / 2;    // query column blocks per wave
 
 template <bool MATERIALISE, int NBW>
 __device__ __forceinline__ void gemm_image_epilogue(const GemmArgs &a, f32x4 (&acc)[kRGI][NBW], uint32_t row0,
@@ -395,107 +383,6 @@ __device__ __forceinline__ void gemm_image_epilogue(const GemmArgs &a, f32x4 (&a
             }
         }
     }
-}
-
-template <bool MATERIALISE>
-__global__ __launch_bounds__(512) void gemm_image_kernel(const GemmArgs a, const half8 *__restrict__ image)
-{
-    __shared__ half8 s_b[2][kChunkFrags];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wq = wave & 1;
-    const uint32_t bid = blockIdx.x;
-    const uint32_t rt = (bid / (8 * a.n_qblocks)) * 8 + (bid & 7); // tile index relative to row_begin
-    const uint32_t qb = (bid >> 3) % a.n_qblocks;
-    const uint32_t n_rows = a.row_end - a.row_begin;
-    if (rt * kBM >= n_rows)
-        return;
-    const uint32_t row0 = a.row_begin + rt * kBM + wr * (kRGI * 16);
-    const uint32_t last_row = a.row_end - 1;
-    const uint32_t n_chunks = a.n_ksteps / kKsChunk;
-    const uint32_t tile = a.row_begin / kBM + rt;     // row_begin is a multiple of 256
-    // rows 64*wr + 16*rg + r of the tile are image wave (2*wr + rg/2), row group rg % 2:
-    //   image[(((tile*n_chunks + c)*8 + 2*wr + rg/2)*2 + rg%2)*2 + ks][lane]  ==  base + c*2048 + (rg*2 + ks)*64
-    const half8 *ap = image + (static_cast<size_t>(tile) * n_chunks * 8 + 2 * wr) * 4 * 64 + lane;
-    const half8 *bsrc = a.qfrag + static_cast<size_t>(qb) * a.n_ksteps * kNB * 64;
-
-    f32x4 acc[kRGI][kNBI];
-#pragma unroll
-    for (int rg = 0; rg < kRGI; ++rg)
-#pragma unroll
-        for (int nb = 0; nb < kNBI; ++nb)
-            acc[rg][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    half8 breg[4];
-    half8 ring[2][kRGI][kKsChunk];
-
-#define RLR_LOAD_B(CHUNK)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) breg[i] = bsrc[static_cast<size_t>(CHUNK) * kChunkFrags + tid + 512 * i]
-#define RLR_STORE_B(BUF) _Pragma("unroll") for (int i = 0; i < 4; ++i) s_b[BUF][tid + 512 * i] = breg[i]
-#define RLR_LOAD_A(CHUNK, SLOT)                                                                    \
-    _Pragma("unroll") for (int rg = 0; rg < kRGI; ++rg) _Pragma("unroll") for (int ks = 0; ks < kKsChunk; ++ks) \
-        ring[SLOT][rg][ks] = ap[static_cast<size_t>(CHUNK) * (8 * 4 * 64) + (rg * 2 + ks) * 64]
-// B fragments two steps ahead in a rotating set of four registers; 1 ds_read : 4 MFMA interleave
-#define RLR_COMPUTE(BUF, SLOT)                                                                     \
-    do {                                                                                           \
-        const half8 *sb = s_b[BUF] + wq * (kNBI * 64) + lane;                                      \
-        half8 bq[4];                                                                               \
-        bq[0] = sb[0];                                                                             \
-        bq[1] = sb[64];                                                                            \
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                         \
-        _Pragma("unroll") for (int f = 0; f < kKsChunk * kNBI; ++f)                                 \
-        {                                                                                          \
-            if (f + 2 < kKsChunk * kNBI) {                                                         \
-                bq[(f + 2) & 3] = sb[((f + 2) / kNBI) * (kNB * 64) + ((f + 2) % kNBI) * 64];        \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
-            }                                                                                      \
-            _Pragma("unroll") for (int rg = 0; rg < kRGI; ++rg) acc[rg][f % kNBI] =                 \
-                __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[SLOT][rg][f / kNBI], bq[f & 3], acc[rg][f % kNBI], 0, 0, 0); \
-            __builtin_amdgcn_sched_group_barrier(0x008, kRGI, 0);                                  \
-        }                                                                                          \
-    } while (0)
-// OFF = phase offset inside the two-phase iteration (c is even, so the A slot and the B buffer of
-// chunk c + OFF are both OFF & 1 -- compile-time constants)
-#define RLR_ROT(X) (((X) + c_rot) % n_chunks)
-#define RLR_PHASE(OFF)                                                                             \
-    do {                                                                                           \
-        const uint32_t cc = c + (OFF);                                                             \
-        RLR_LOAD_B(RLR_ROT(min(cc + 1, last_c)));                                                  \
-        __builtin_amdgcn_sched_barrier(0); /* do not sink the loads below the MFMAs */             \
-        RLR_COMPUTE((OFF) & 1, (OFF) & 1);                                                         \
-        /* the slot just consumed takes chunk cc + 2: one full phase of lookahead for it */        \
-        RLR_LOAD_A(RLR_ROT(min(cc + 2, last_c)), (OFF) & 1);                                       \
-        /* keep the LDS stores of the next query chunk down here: hoisted to the top of the phase  \
-           (hipcc does that) they wait for the loads issued a few instructions earlier */           \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        RLR_STORE_B(((OFF) & 1) ^ 1);                                                              \
-        __syncthreads();                                                                           \
-    } while (0)
-
-    const uint32_t last_c = n_chunks - 1;
-    // every workgroup walks the K-chunks in a rotated order, so that at any moment the 256 CUs read
-    // different chunks of the (shared, L2-resident) query image instead of all hitting the same lines
-    const uint32_t c_rot = (bid * 5u) % n_chunks;
-    RLR_LOAD_A(RLR_ROT(0), 0);
-    RLR_LOAD_A(RLR_ROT(1), 1);
-    RLR_LOAD_B(RLR_ROT(0));
-    RLR_STORE_B(0);
-    __syncthreads();
-    // loads past the last chunk are clamped re-fetches of it (never used); n_chunks is even
-#pragma unroll 1
-    for (uint32_t c = 0; c < n_chunks; c += 2) {
-        RLR_PHASE(0);
-        RLR_PHASE(1);
-    }
-#undef RLR_PHASE
-#undef RLR_ROT
-#undef RLR_COMPUTE
-#undef RLR_LOAD_A
-#undef RLR_STORE_B
-#undef RLR_LOAD_B
-    gemm_image_epilogue<MATERIALISE, kNBI>(a, acc, row0, last_row, qb * kQB + wq * (kNBI * 16), lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -563,8 +450,9 @@ __device__ __forceinline__ void lds_write_b32(uint32_t addr, uint32_t v)
     asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-// VAR (tuning A/B inside one build, RLR_GEMM8_VARIANT): bit 0 = s_setprio pair around each MFMA cluster, bit 1 = no
-// sched_barrier behind the phase's lgkmcnt(0), bit 2 = non-temporal DMA for the once-read row half-tiles
+// VAR (RLR_GEMM8_VARIANT, same-box A/B): bit 0 = s_setprio pair around each MFMA cluster (+2-5 % time: off), bit 1 = no
+// sched_barrier behind the phase's lgkmcnt(0) (-1 %), bit 2 = non-temporal DMA for the once-read row half-tiles
+// (-2.5 %).  Built: 6 (default) and 0.
 template <bool MATERIALISE, int VAR>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char *__restrict__ image, uint32_t n_tiles)
 {
@@ -1308,22 +1196,11 @@ hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pi
     return hipGetLastError();
 }
 
-static bool use_gemm8()
-{
-    static const bool on = [] {
-        const char *v = getenv("RLR_GEMM8"); // A/B switch: 0 = the round-1 register-staged image kernel
-        return !(v && v[0] == '0');
-    }();
-    return on;
-}
-
 // can a batch over `dim`-wide rows run over the nomination image?  (the caller prepares the query fragments in the
 // image's natural k order only then)
 bool gemm_image_usable(uint32_t dim)
 {
-    if (dim % 64 != 0)
-        return false;
-    return use_gemm8() ? (dim / 64) % 2 == 0 : (dim / 64) % 4 == 0;
+    return dim % 128 == 0; // K-tiles of 64, two per loop iteration of gemm8_kernel
 }
 
 // one workgroup per CU of the current device, rounded down to a multiple of 8 (the XCD round-robin of the unit lists)
@@ -1383,7 +1260,7 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
             hipLaunchKernelGGL((gemm_resident_kernel<false>), dim3(rgrid), dim3(512), 0, s, a, img, n_qg);
         return hipGetLastError();
     }
-    if (use_gemm8() && image && row_begin % kBM == 0 && a.n_ksteps % 4 == 0) {
+    if (image && row_begin % kBM == 0 && a.n_ksteps % 4 == 0) {
         const uint32_t n_units = n_rt * a.n_qblocks;
         const uint32_t g8 = std::max<uint32_t>(8, std::min<uint32_t>(persistent_grid(), (n_units + 7) / 8 * 8));
         const char *img = static_cast<const char *>(image);
@@ -1396,22 +1273,12 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
         hipLaunchKernelGGL((gemm8_kernel<true, VAR>), dim3(g8), dim3(512), 0, s, a, img, n_rt);               \
     else                                                                                                      \
         hipLaunchKernelGGL((gemm8_kernel<false, VAR>), dim3(g8), dim3(512), 0, s, a, img, n_rt)
-        switch (var) {
-        case 1: RLR_G8(1); break;
-        case 2: RLR_G8(2); break;
-        case 4: RLR_G8(4); break;
-        case 0: RLR_G8(0); break;
-        default: RLR_G8(6); break;
+        if (var == 0) {
+            RLR_G8(0);
+        } else {
+            RLR_G8(6);
         }
 #undef RLR_G8
-        return hipGetLastError();
-    }
-    if (image && row_begin % kBM == 0 && (a.n_ksteps / kKsChunk) % 4 == 0) {
-        const half8 *img = static_cast<const half8 *>(image);
-        if (mat)
-            hipLaunchKernelGGL((gemm_image_kernel<true>), dim3(grid), dim3(512), 0, s, a, img);
-        else
-            hipLaunchKernelGGL((gemm_image_kernel<false>), dim3(grid), dim3(512), 0, s, a, img);
         return hipGetLastError();
     }
     if (dtype == RLR_F16) {

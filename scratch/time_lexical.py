@@ -1,6 +1,6 @@
 import importlib, sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 lex = importlib.import_module("rust-local-rag_amd.lexical")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 rng = np.random.default_rng(0)
