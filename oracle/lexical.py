@@ -9,8 +9,11 @@ arithmetic does) and the C library's logf for `f32::ln` -- small cases only.
 
 Pinning: the reference's own tests hold ONE case for this structure
 (`test_lexical_index_contains_and_drop_stale`, :2295-2326), reproduced in tests/test_lexical_cpu.py.
-BM25 scores are not pinned by any reference test or fixture: for them this file is a restatement of
-the published formula as the reference spells it -- "parity unpinned" for the score values.
+BM25 score VALUES are pinned by no reference test or fixture; since round 2 they are pinned by
+tests/golden/bm25_vectors.json -- vectors derived with exact rational arithmetic and a correctly
+rounded ln (tests/golden/make_bm25_vectors.py: no numpy, no libm, none of this project's code)
+from the formula as the reference spells it (:2187-2217).  This file and the GPU index must both
+reproduce them bit for bit (tests/test_lexical_cpu.py, tests/test_gpu_lexical.py).
 Two things the reference leaves to HashMap iteration order are fixed here the way the GPU library
 defines them: query terms accumulate in order of first occurrence, ties order by insertion rank
 (the row number in the tests).

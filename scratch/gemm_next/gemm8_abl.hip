@@ -376,6 +376,127 @@ __global__ __launch_bounds__(512) void gemm8s_kernel(const char *__restrict__ A,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 4-wave variant: one wave per SIMD, wave (wm, wn) owns the 128 x 128 quadrant (A half wm, B half wn) = 64 accumulator
+// tiles (256 registers).  LDS fragment reads per K-tile drop from 192 KiB (8 waves x 24) to 128 KiB (4 x 32); one barrier
+// per k-step of 64 MFMAs instead of two per 16.  The ring is cut in k-steps (32 k): slot s & 3 = [A0 | A1 | B0 | B1] x
+// 8 KiB, every 1-KiB fragment is one DMA piece, wave w stages group w (8 DMAs per thread per k-step), 3 k-steps ahead.
+//   per k-step s:  lgkmcnt(0) [fragments of s in registers] -> vmcnt(16) [k-step s+1 landed] -> barrier ->
+//                  ds_read fragments of s+1 into the other register set -> stage k-step s+4 into slot s & 3 -> 64 MFMAs
+template <int ABL>
+__global__ __launch_bounds__(256) void gemm4w_kernel(const char *__restrict__ A, const char *__restrict__ B, uint32_t n_tiles,
+                                                     uint32_t T, float tau, unsigned *__restrict__ count,
+                                                     unsigned long long *__restrict__ stamps)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint32_t n_it = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const uint32_t n_ks = n_it * T * 2; // k-steps of this workgroup
+
+    // staging cursor: k-step (s_it, s_kt, s_ks), ring slot
+    uint32_t s_it = 0, s_kt = 0, s_ks = 0, s_slot = 0;
+    auto stage = [&]() {
+        const uint32_t it = s_it < n_it ? s_it : n_it - 1;
+        const uint32_t tile = blockIdx.x + it * gridDim.x;
+        char *dst = lds + s_slot * 32768 + wave * 8192;
+        const char *src;
+        uint32_t stride;
+        if (wave < 2) { // A half `wave`: fragments (rb, ks) at (rb * 2 + ks) KiB of the half-tile
+            src = A + ((static_cast<size_t>(tile) * T + s_kt) * 2 + wave) * kHalfBytes + s_ks * 1024 + lane * 16;
+            stride = 2048;
+        } else {        // B half `wave - 2`: fragments of k-step (2 kt + ks), col blocks hq * 8 ..
+            src = B + (static_cast<size_t>(s_kt * 2 + s_ks) * 16 + (wave - 2) * 8) * 1024 + lane * 16;
+            stride = 1024;
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if ((ABL & F_NT_A) && wave < 2)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * stride),
+                                                 (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 2);
+            else
+                GLDS(src + p * stride, dst + p * 1024);
+        }
+        s_slot = (s_slot + 1) & 3;
+        if (++s_ks == 2) {
+            s_ks = 0;
+            if (++s_kt == T) {
+                s_kt = 0;
+                ++s_it;
+            }
+        }
+    };
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+            acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    half8 fa[2][8], fb[2][8];
+    unsigned passed = 0;
+    const half8 *L = reinterpret_cast<const half8 *>(lds);
+    // fragment (group g, block blk) of slot sl: half8 index sl * 2048 + g * 512 + blk * 64 + lane
+#define W4_READ(BUF, SL)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                       \
+        fa[BUF][i] = L[(SL) * 2048 + wm * 512 + i * 64 + lane];                           \
+        fb[BUF][i] = L[(SL) * 2048 + (2 + wn) * 512 + i * 64 + lane];                     \
+    }
+#define W4_COMPUTE(BUF)                                                                   \
+    _Pragma("unroll") for (int rb = 0; rb < 8; ++rb) _Pragma("unroll") for (int cb = 0; cb < 8; ++cb) \
+        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[BUF][rb], fb[BUF][cb], acc[rb][cb], 0, 0, 0);
+
+    // prologue: k-steps 0..3 in flight; k-step 0 landed, its fragments in register set 0
+    stage(); stage(); stage(); stage();
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    FENCE();
+    W4_READ(0, 0)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t kt2 = 0; // k-steps consumed of the current row tile
+
+#define W4_STEP(BUF, SL)                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                     \
+    FENCE();                                                                              \
+    __builtin_amdgcn_s_barrier();                                                         \
+    FENCE();                                                                              \
+    W4_READ((BUF) ^ 1, ((SL) + 1) & 3)                                                    \
+    stage();                                                                              \
+    if (ABL & F_SCHED) __builtin_amdgcn_sched_barrier(0);                                 \
+    W4_COMPUTE(BUF)
+
+#pragma unroll 1
+    for (uint32_t s = 0; s < n_ks; s += 4) {
+        W4_STEP(0, 0)
+        W4_STEP(1, 1)
+        W4_STEP(0, 2)
+        W4_STEP(1, 3)
+        kt2 += 4;
+        if (kt2 == 2 * T) {
+            kt2 = 0;
+#pragma unroll
+            for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        passed += acc[rb][cb][j] > tau;
+                    acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (passed)
+        atomicAdd(count, passed);
+    if (tid == 0) {
+        stamps[blockIdx.x * 2] = t1 - t0;
+        stamps[blockIdx.x * 2 + 1] = r1 - r0;
+    }
+}
+
 __global__ void fill_half_kernel(_Float16 *p, size_t n, uint32_t seed)
 {
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
@@ -437,6 +558,31 @@ static int run_s(const char *A, const char *B, uint32_t tiles, uint32_t T, uint3
     return 0;
 }
 
+template <int ABL>
+static int run_4w(const char *A, const char *B, uint32_t tiles, uint32_t T, uint32_t grid, unsigned *dCount, unsigned long long *dStamps,
+                  float *ms, double *ghz)
+{
+    static bool attr = false;
+    if (!attr) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm4w_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+        attr = true;
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(gemm4w_kernel<ABL>, dim3(grid), dim3(256), 4 * 32768, 0, A, B, tiles, T, 0.002f, dCount, dStamps);
+    CK(hipGetLastError());
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(ms, e0, e1));
+    std::vector<unsigned long long> st(grid * 2);
+    CK(hipMemcpy(st.data(), dStamps, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> c(grid);
+    for (uint32_t i = 0; i < grid; ++i)
+        c[i] = st[2 * i + 1] ? static_cast<double>(st[2 * i]) / static_cast<double>(st[2 * i + 1]) * 0.1 : 0.0; // GHz
+    std::sort(c.begin(), c.end());
+    *ghz = c[grid / 2];
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const uint32_t K = 768, T = K / 64, NQ = 256;
@@ -456,15 +602,12 @@ int main(int argc, char **argv)
     const char *A = reinterpret_cast<const char *>(dA), *B = reinterpret_cast<const char *>(dB);
     struct V { const char *name; int (*fn)(const char *, const char *, uint32_t, uint32_t, uint32_t, unsigned *, unsigned long long *, float *, double *); };
     const V vs[] = {
-        {"prio", run<F_PRIO>},
         {"plain", run<0>},
+        {"plain+ntA", run<F_NT_A>},
         {"stag+prio", run<F_STAG | F_LGKM_EARLY | F_PRIO>},
-        {"stag+sched+hi", run<F_STAG | F_LGKM_EARLY | F_SCHED | F_PRIO_HI>},
-        {"split+prio", run_s<F_PRIO>},
-        {"split+sched", run_s<F_SCHED>},
-        {"split+sched+hi", run_s<F_SCHED | F_PRIO_HI>},
-        {"split+prio+ntA", run_s<F_PRIO | F_NT_A>},
-        {"split plain", run_s<0>},
+        {"4w", run_4w<0>},
+        {"4w+ntA", run_4w<F_NT_A>},
+        {"4w+sched", run_4w<F_SCHED>},
     };
     const int nv = sizeof(vs) / sizeof(vs[0]);
     for (int rep = 0; rep < 5; ++rep) {

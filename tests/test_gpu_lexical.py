@@ -141,3 +141,22 @@ def test_engine_hybrid_search_from_query_text(rlr, oracle):
     assert eng.lexical.contains(0) and not eng.lexical.contains(1) and eng.lexical.info()["total_docs"] == 1
     assert eng.lexical.score("solitaryterm", 5)[0].size == 0
     eng.close()
+
+
+def test_gpu_bm25_against_the_hand_derived_vectors(rlr):
+    """the GPU BM25 index against tests/golden/bm25_vectors.json (exact-arithmetic derivation, no oracle involved)"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "bm25_vectors.json")) as f:
+        doc = json.load(f)
+    lex = importlib.import_module("rust-local-rag_amd.lexical")
+    for case in doc["cases"]:
+        g = lex.LexicalIndex(0)
+        for r, tokens in enumerate(case["docs"]):
+            g.add_tokens(r, tokens)
+        for q in case["queries"]:
+            rows, sc = g.score_tokens(q["terms"], q["limit"])
+            assert [int(r) for r in rows] == q["rows"], (case["name"], q["terms"])
+            assert [int(x) for x in bits(sc)] == q["score_bits"], (case["name"], q["terms"])
+        g.close()

@@ -68,3 +68,40 @@ def test_library_tokenizer_ascii_exact(rlr):
         assert lex.tokenize_ascii(text) == OL.tokenize(text)
         assert lex.tokenize(text) == OL.tokenize(text)
     assert lex.tokenize("naïve café ÉTÉ né") == OL.tokenize("naïve café ÉTÉ né")
+
+
+def _bm25_vectors():
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "bm25_vectors.json")) as f:
+        return json.load(f), root
+
+
+def test_oracle_against_the_hand_derived_bm25_vectors():
+    """tests/golden/bm25_vectors.json: BM25 values derived with exact rational arithmetic + correctly rounded ln
+    (make_bm25_vectors.py: no numpy, no libm, none of the project's code) pin `LexicalIndex::score`'s VALUES
+    (rag_engine.rs:2169-2225), which no reference test does."""
+    doc, _ = _bm25_vectors()
+    n_pos = 0
+    for case in doc["cases"]:
+        ix = OL.LexicalIndex()
+        for r, tokens in enumerate(case["docs"]):
+            ix.add_chunk(r, " ".join(tokens), rank=r)
+        for q in case["queries"]:
+            res = ix.score(" ".join(q["terms"]), q["limit"], keep_zero=False)
+            assert [r for r, _ in res] == q["rows"], (case["name"], q["terms"])
+            assert [int(np.float32(s).view(np.uint32)) for _, s in res] == q["score_bits"], (case["name"], q["terms"])
+            n_pos += len(res)
+    assert n_pos >= 50
+
+
+def test_bm25_vector_file_is_what_its_generator_writes():
+    import importlib.util
+    import json
+    import os
+    doc, root = _bm25_vectors()
+    spec = importlib.util.spec_from_file_location("make_bm25_vectors", os.path.join(root, "tests", "golden", "make_bm25_vectors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert json.loads(json.dumps(mod.build())) == doc
