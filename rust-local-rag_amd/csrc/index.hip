@@ -112,6 +112,7 @@ struct Ctx {
     size_t h_pin_bytes = 0;
     std::vector<float> q_norm; // ||q||_2 of the staged queries (band of the 8-bit nomination scan)
     bool hist_dirty = false; // a pipeline was enqueued and did not complete: d_hist may hold counts
+    uint32_t *h_assert = nullptr; // RLR_POISON_ALLOC=1 only: pinned word the zero-histogram assertion kernel counts into
     // rlr_search_topk_device_begin / _end
     hipStream_t pending_stream = nullptr;
     uint32_t pending_q = 0, pending_k = 0;
@@ -164,12 +165,18 @@ size_t row_bytes(const rlr_index *ix)
 } // namespace
 
 namespace rlr {
-hipError_t dev_malloc(void **p, size_t bytes)
+bool poison_mode()
 {
     static const bool poison = [] {
         const char *v = getenv("RLR_POISON_ALLOC");
         return v && v[0] == '1';
     }();
+    return poison;
+}
+
+hipError_t dev_malloc(void **p, size_t bytes)
+{
+    const bool poison = poison_mode();
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess)
         (void)hipGetLastError(); // reported through the return value; do not leave it for a later launch check to find
@@ -248,6 +255,7 @@ void ctx_free(Ctx *c)
     for (auto &e : c->bev)
         if (e) (void)hipEventDestroy(e);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_assert) (void)hipHostFree(c->h_assert);
     delete c;
 }
 
@@ -283,6 +291,11 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
     // on the first search of a fresh context, caught by the multi-shard fuzz with five contexts starting at once).
     if (e == hipSuccess)
         e = hipMemsetAsync(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess && rlr::poison_mode()) {
+        e = hipHostMalloc(reinterpret_cast<void **>(&c->h_assert), 64, hipHostMallocDefault);
+        if (e == hipSuccess)
+            *c->h_assert = 0;
+    }
     if (e == hipSuccess)
         e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
@@ -501,6 +514,21 @@ int32_t ctx_prepare(rlr_index *ix, Ctx *c, uint32_t nq, const SearchPlan &p)
 } // namespace
 
 namespace rlr {
+// Debug assertion (RLR_POISON_ALLOC=1 runs only): every single-query pipeline relies on "the histograms are zero on
+// entry" -- established at context creation and re-established by the previous query's re-score kernel, which is only
+// stream-order-safe.  A second stream, a reordered launch or a skipped clear would break it silently (a wrong threshold,
+// not a crash); this kernel runs in front of every scan in the poisoned test runs and counts non-zero bins into a
+// pinned host word that the host checks at the call's synchronisation.
+__global__ __launch_bounds__(256) void hist_assert_zero_kernel(const uint32_t *__restrict__ hist, uint32_t n,
+                                                               uint32_t *__restrict__ flag)
+{
+    uint32_t bad = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        bad += hist[i] != 0;
+    if (bad)
+        atomicAdd(flag, bad);
+}
+
 // device-side: sort the re-scored candidates (<= kLdsSortCap) and emit the best k.
 __global__ __launch_bounds__(1024) void sort_emit_kernel(uint64_t *__restrict__ packed, const SelectState *__restrict__ st,
                                                          uint64_t *__restrict__ out, uint32_t k,
@@ -802,6 +830,17 @@ float image_two_eps(const rlr_index *ix, float guard_eps)
     return 2.0f * nomination_eps(ix->dim, ix->dtype) * scale;
 }
 
+// after a synchronisation: did the zero-histogram assertion of a poisoned run fire?
+int32_t check_hist_assert(Ctx *c)
+{
+    if (c->h_assert && *c->h_assert) {
+        const uint32_t n = *c->h_assert;
+        *c->h_assert = 0;
+        return fail(RLR_E_INTERNAL, "zero-histogram invariant violated: %u non-zero bins in front of a scan", n);
+    }
+    return RLR_OK;
+}
+
 // Enqueue the whole pipeline for query `qi` on the context's stream:
 //   scan (+digit-1 histogram) -> digit-2 histogram (bin search folded in) -> collect (bin search
 //   folded in) -> LDS-staged reference-order re-score (clears the histograms for the next query)
@@ -817,6 +856,10 @@ hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p
     SelectState *st = c->d_state + qi;
     const float *dq = c->d_query + static_cast<size_t>(qi) * ix->q_pitch;
 
+    if (c->h_assert) {
+        hipLaunchKernelGGL(rlr::hist_assert_zero_kernel, dim3(4), dim3(256), 0, s, c->d_hist, 2u * kHistBins, c->h_assert);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if (timed && (e = hipEventRecord(c->ev[0], s)) != hipSuccess) return e;
     ScanArgs sa;
     sa.rows = ix->d_rows;
@@ -1216,6 +1259,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
         }
     }
     RLR_HIP(hipStreamSynchronize(s));
+    RLR_TRY(check_hist_assert(c));
     if (timed && nq == 1) {
         float a = 0, b = 0, d = 0;
         RLR_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
@@ -1700,6 +1744,7 @@ int32_t rlr_search_topk_device_end(rlr_index *ix, void *ticket, uint32_t *n_over
     lease.c = c;
     RLR_TRY(use_device(ix));
     RLR_HIP(hipStreamSynchronize(c->pending_stream));
+    RLR_TRY(check_hist_assert(c));
     uint32_t over = 0;
     uint64_t n_cand = 0;
     for (uint32_t q = 0; q < c->pending_q; ++q) {
@@ -1975,6 +2020,7 @@ int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uin
     RLR_HIP(hipGetLastError());
     if (timed) RLR_HIP(hipEventRecord(c->bev[1], s));
     RLR_HIP(hipStreamSynchronize(s));
+    RLR_TRY(check_hist_assert(c));
     c->hist_dirty = false;
     const uint32_t n_sel = h_out[3 * k_cap], status = h_out[3 * k_cap + 1];
     {

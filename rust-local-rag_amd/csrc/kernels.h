@@ -12,6 +12,7 @@ namespace rlr {
 // has written shows up as a wrong answer in the parity tests instead of hiding behind the zero pages a fresh
 // process usually gets (tests/test_gpu_fuzz.py::test_poisoned_allocations).
 hipError_t dev_malloc(void **p, size_t bytes);
+bool poison_mode(); // RLR_POISON_ALLOC=1
 
 // index.hip: sets the thread-local rlr_last_error() message, returns `code`
 int32_t set_error(int32_t code, const char *fmt, ...);

@@ -12,20 +12,16 @@ if ROOT not in sys.path:
 
 
 def _ensure_built():
-    """The library normally travels with the tree (or `__graft_entry__.build()` ran first).  If neither
-    happened, compile it once here -- compile only, nothing touches a GPU -- so that collection does not
-    fail on a missing .so; a missing hipcc still fails loudly."""
-    so = os.path.join(ROOT, "rust-local-rag_amd", "librlr_gpu.so")
-    if os.path.exists(so):
-        return
+    """Bring librlr_gpu.so up to date with csrc/ and include/ before anything imports it: build.py recompiles only
+    what is stale (a no-op when the shipped binary is fresh; compile only, nothing touches a GPU), so a source edit can
+    never be tested against an old binary.  A missing hipcc fails loudly."""
     import fcntl
 
     with open(os.path.join(ROOT, "rust-local-rag_amd", ".build.lock"), "w") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
-        if not os.path.exists(so):
-            import __graft_entry__
+        import __graft_entry__
 
-            __graft_entry__._load_build_module().build()
+        __graft_entry__._load_build_module().build()
 
 
 _ensure_built()
