@@ -3,20 +3,27 @@
 // straight into a dense f32 matrix, and the matching number formatter for the writer.  Host code only.
 //
 // The reference parses the whole pretty-printed file with serde_json (:1555-1557); at 10^5..10^6 chunks the
-// `Vec<f32>` literals are > 99 % of the bytes.  Here the file is memory-mapped and walked once by a small JSON
-// tokenizer that tracks where it is (top level -> "chunks" -> chunk object -> "embedding"): every number of an
-// embedding array goes through std::from_chars<double> (correctly rounded) and is then narrowed to binary32 --
-// serde_json's f32 path (visit_f64 + `as f32`) and the Python loader's float64 -> float32 do exactly that, so the
-// rows are bit-identical to theirs -- and everything else is copied verbatim into a "metadata document" in which
-// each embedding array is replaced by [], small enough for any JSON library.  Row r = the r-th chunk of the file.
+// `Vec<f32>` literals are > 99 % of the bytes.  Here the file is memory-mapped and read in two passes:
+//   1. structure: a small JSON tokenizer walks the document once, tracking where it is (top level -> "chunks" ->
+//      chunk object -> "embedding"); an embedding array holds no strings, so its end is one memchr for ']' -- the
+//      pass only records the byte range of every array (GB/s) and copies everything else verbatim into a "metadata
+//      document" in which each embedding array is replaced by [], small enough for any JSON library;
+//   2. numbers: the recorded ranges are parsed by all host cores at once (std::from_chars<double>, correctly
+//      rounded, then narrowed to binary32 -- serde_json's f32 path (visit_f64 + `as f32`) and the Python loader's
+//      float64 -> float32 do exactly that, so the rows are bit-identical to theirs), each range into its own row of
+//      the matrix: about 25 ns per number per core.
+// Row r = the r-th chunk of the file.
 #include "../../include/rlr_engine.h"
 
+#include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <fcntl.h>
@@ -130,36 +137,28 @@ bool key_is(const char *s, const char *e, const char *lit)
     return static_cast<size_t>(e - s) == n && memcmp(s, lit, n) == 0;
 }
 
-// p at '[' of an embedding array: numbers (or null = a non-finite value serde_json wrote) into row[0..dim), extra
-// components dropped, missing ones left 0 (dot_product's zip, rag_engine.rs:1778)
-bool parse_embedding(Cursor &c, float *row, uint32_t dim)
+// [p, end) = the inside of an embedding array (between '[' and ']'): numbers (or null = a non-finite value serde_json
+// wrote) into row[0..dim), extra components dropped, missing ones left 0 (dot_product's zip, rag_engine.rs:1778).
+// Returns nullptr, or the position of the first byte that is not part of a number list.
+const char *parse_embedding(const char *p, const char *end, float *row, uint32_t dim)
 {
-    ++c.p; // '['
     uint32_t i = 0;
     for (;;) {
-        c.ws();
-        if (c.p >= c.end)
-            return c.fail("unterminated embedding array");
-        if (*c.p == ']') {
-            ++c.p;
-            return true;
-        }
-        if (*c.p == ',') {
-            ++c.p;
-            continue;
-        }
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r' || *p == ','))
+            ++p;
+        if (p >= end)
+            return nullptr;
         double v;
-        if (c.end - c.p >= 4 && memcmp(c.p, "null", 4) == 0) {
+        if (end - p >= 4 && memcmp(p, "null", 4) == 0) {
             v = std::nan("");
-            c.p += 4;
+            p += 4;
         } else {
-            const auto r = std::from_chars(c.p, c.end, v);
+            const auto r = std::from_chars(p, end, v);
             if (r.ec == std::errc::result_out_of_range) {
-                // from_chars leaves v unmodified on overflow / underflow: serde_json gives +-inf -> error, or 0
-                const char *q = c.p;
-                const bool neg = *q == '-';
+                // from_chars leaves v unmodified on overflow / underflow: serde_json's f64 gives +-inf or 0 there
+                const bool neg = *p == '-';
                 v = 0.0;
-                for (const char *t = q; t < r.ptr; ++t)
+                for (const char *t = p; t < r.ptr; ++t)
                     if (*t == 'e' || *t == 'E') {
                         v = (t + 1 < r.ptr && t[1] == '-') ? 0.0 : HUGE_VAL;
                         break;
@@ -167,9 +166,9 @@ bool parse_embedding(Cursor &c, float *row, uint32_t dim)
                 if (neg)
                     v = -v;
             } else if (r.ec != std::errc()) {
-                return c.fail("bad number in an embedding array");
+                return p;
             }
-            c.p = r.ptr;
+            p = r.ptr;
         }
         if (i < dim)
             row[i] = static_cast<float>(v);
@@ -177,13 +176,18 @@ bool parse_embedding(Cursor &c, float *row, uint32_t dim)
     }
 }
 
+struct Range {
+    const char *b, *e; // inside of the array
+    uint64_t row;
+};
+
 struct Corpus {
-    std::vector<float> rows;
+    std::vector<Range> ranges; // one per embedding array found (a chunk without one keeps its zero row)
     uint64_t n = 0;
     std::string meta;
 };
 
-bool parse_document(Cursor &c, uint32_t dim, Corpus &out)
+bool parse_document(Cursor &c, Corpus &out)
 {
     const char *last = c.begin; // everything in [last, p) still has to be copied to the metadata document
     c.ws();
@@ -232,9 +236,8 @@ bool parse_document(Cursor &c, uint32_t dim, Corpus &out)
             ++c.p;
             c.ws();
             // one row per chunk, whatever the chunk holds
-            out.rows.resize((out.n + 1) * static_cast<size_t>(dim), 0.0f);
-            float *row = out.rows.data() + out.n * static_cast<size_t>(dim);
-            ++out.n;
+            const uint64_t row = out.n++;
+            size_t first_range = out.ranges.size();
             if (c.p >= c.end || *c.p != '{') {
                 if (!skip_value(c))
                     return false;
@@ -260,9 +263,13 @@ bool parse_document(Cursor &c, uint32_t dim, Corpus &out)
                 c.ws();
                 if (key_is(ks, ke, "embedding") && c.p < c.end && *c.p == '[') {
                     const char *a0 = c.p;
-                    std::fill(row, row + dim, 0.0f); // a repeated key: the last one wins, as in a map
-                    if (!parse_embedding(c, row, dim))
-                        return false;
+                    // numbers, commas, white space and null only: the array ends at the next ']'
+                    const char *close = static_cast<const char *>(memchr(c.p + 1, ']', static_cast<size_t>(c.end - c.p - 1)));
+                    if (!close)
+                        return c.fail("unterminated embedding array");
+                    out.ranges.resize(first_range); // a repeated key: the last one wins, as in a map
+                    out.ranges.push_back({c.p + 1, close, row});
+                    c.p = close + 1;
                     out.meta.append(last, a0);
                     out.meta.append("[]");
                     last = c.p;
@@ -276,8 +283,53 @@ bool parse_document(Cursor &c, uint32_t dim, Corpus &out)
     return true;
 }
 
-int32_t load_corpus(const char *path, uint32_t dim, Corpus &out)
+// pass 2: every recorded array into its row, all host cores (bounded), work handed out in blocks of 64 arrays
+const char *parse_ranges(const std::vector<Range> &ranges, float *rows, uint32_t dim)
 {
+    const size_t n = ranges.size();
+    unsigned n_thr = std::thread::hardware_concurrency();
+    n_thr = std::max(1u, std::min(n_thr ? n_thr : 1u, 32u));
+    if (n < 256)
+        n_thr = 1;
+    std::atomic<size_t> next{0};
+    std::atomic<const char *> bad{nullptr};
+    auto work = [&] {
+        for (;;) {
+            const size_t i0 = next.fetch_add(64);
+            if (i0 >= n || bad.load(std::memory_order_relaxed))
+                return;
+            for (size_t i = i0; i < std::min(n, i0 + 64); ++i) {
+                const char *err = parse_embedding(ranges[i].b, ranges[i].e, rows + ranges[i].row * dim, dim);
+                if (err) {
+                    bad.store(err);
+                    return;
+                }
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_thr; ++t)
+        th.emplace_back(work);
+    work();
+    for (auto &t : th)
+        t.join();
+    return bad.load();
+}
+
+struct Mapped {
+    void *map = MAP_FAILED;
+    size_t size = 0;
+    ~Mapped()
+    {
+        if (map != MAP_FAILED)
+            munmap(map, size);
+    }
+};
+
+// rows_out: malloc'ed n x dim floats (zero rows for chunks without an embedding)
+int32_t load_corpus(const char *path, uint32_t dim, Corpus &out, float **rows_out)
+{
+    *rows_out = nullptr;
     const int fd = open(path, O_RDONLY);
     if (fd < 0)
         return rlr::set_error(RLR_E_INVALID, "cannot open %s", path);
@@ -286,18 +338,27 @@ int32_t load_corpus(const char *path, uint32_t dim, Corpus &out)
         close(fd);
         return rlr::set_error(RLR_E_INVALID, "%s is empty or unreadable", path);
     }
-    void *map = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+    Mapped m;
+    m.size = static_cast<size_t>(st.st_size);
+    m.map = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
-    if (map == MAP_FAILED)
+    if (m.map == MAP_FAILED)
         return rlr::set_error(RLR_E_OOM, "cannot map %s", path);
-    (void)madvise(map, static_cast<size_t>(st.st_size), MADV_SEQUENTIAL);
+    (void)madvise(m.map, m.size, MADV_WILLNEED);
     Cursor c;
-    c.begin = c.p = static_cast<const char *>(map);
-    c.end = c.p + st.st_size;
-    const bool ok = parse_document(c, dim, out);
-    munmap(map, static_cast<size_t>(st.st_size));
-    if (!ok)
+    c.begin = c.p = static_cast<const char *>(m.map);
+    c.end = c.p + m.size;
+    if (!parse_document(c, out))
         return rlr::set_error(RLR_E_INVALID, "%s: %s", path, c.err.c_str());
+    float *rows = static_cast<float *>(std::calloc(std::max<size_t>(out.n * static_cast<size_t>(dim), 1), sizeof(float)));
+    if (!rows)
+        return rlr::set_error(RLR_E_OOM, "host allocation of %llu x %u floats failed", static_cast<unsigned long long>(out.n), dim);
+    if (const char *err = parse_ranges(out.ranges, rows, dim)) {
+        std::free(rows);
+        return rlr::set_error(RLR_E_INVALID, "%s: bad number in an embedding array at byte %zu", path,
+                              static_cast<size_t>(err - c.begin));
+    }
+    *rows_out = rows;
     return RLR_OK;
 }
 
@@ -311,19 +372,19 @@ int32_t rlr_json_load_corpus(const char *path, uint32_t dim, rlr_json_corpus *ou
         return RLR_E_INVALID;
     std::memset(out, 0, sizeof(*out));
     Corpus c;
-    const int32_t st = load_corpus(path, dim, c);
+    float *rows = nullptr;
+    const int32_t st = load_corpus(path, dim, c, &rows);
     if (st != RLR_OK)
         return st;
     out->n_rows = c.n;
     out->dim = dim;
     out->meta_len = c.meta.size();
-    out->rows = static_cast<float *>(std::malloc(std::max<size_t>(c.rows.size(), 1) * sizeof(float)));
+    out->rows = rows;
     out->meta_json = static_cast<char *>(std::malloc(c.meta.size() + 1));
-    if (!out->rows || !out->meta_json) {
+    if (!out->meta_json) {
         rlr_json_free_corpus(out);
         return rlr::set_error(RLR_E_OOM, "host allocation failed");
     }
-    std::memcpy(out->rows, c.rows.data(), c.rows.size() * sizeof(float));
     std::memcpy(out->meta_json, c.meta.data(), c.meta.size());
     out->meta_json[c.meta.size()] = '\0';
     return RLR_OK;
