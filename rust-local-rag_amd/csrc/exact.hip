@@ -471,14 +471,21 @@ constexpr int kGPitch = 68;  // floats
 // R = 2 (32 x 32 blocks, 55 of them for a 300-row pool) keeps many CUs busy for a single query; R = 4 (64 x 64)
 // halves the LDS reads per multiply (8 float4 per 64 products instead of 4 per 16) and is used for batches, where
 // there are thousands of blocks anyway: 3.7 -> see DESIGN.md for 1024 pools of 300 x 1024-d.
-template <int R>
+// SRC 0: `pool` is a dense P x dim f32 matrix per query.  SRC 1 / 2: the pool rows are read straight from the index
+// (f32 / binary16 rows, widened exactly) through the query's row list -- no gathered f32 copy in between: config 5's
+// share used to write and re-read 1.26 GB of it per 1024 pools.
+template <int R, int SRC>
 __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict__ pool, uint32_t P, uint32_t dim,
-                                                         float *__restrict__ gram)
+                                                         float *__restrict__ gram, const void *__restrict__ rows,
+                                                         uint32_t pitch16, const uint32_t *__restrict__ list)
 {
     constexpr int kGT = 16 * R; // pairs per block side
     __shared__ __attribute__((aligned(16))) float sa[kGT * kGPitch];
     __shared__ __attribute__((aligned(16))) float sb[kGT * kGPitch];
-    pool += static_cast<size_t>(blockIdx.z) * P * dim;
+    if constexpr (SRC == 0)
+        pool += static_cast<size_t>(blockIdx.z) * P * dim;
+    else
+        list += static_cast<size_t>(blockIdx.z) * P;
     gram += static_cast<size_t>(blockIdx.z) * P * P;
     // linear block id -> (bi >= bj) in the lower triangle
     uint32_t bi = 0, rem = blockIdx.x;
@@ -509,14 +516,30 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
             const uint32_t row = r >= kGT ? j0 + (r - kGT) : i0 + r;
             float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (row < P && c4 * 4 < kc) {
-                const float *src = pool + static_cast<size_t>(row) * dim + k0 + c4 * 4;
-                if (vec) {
-                    v = *reinterpret_cast<const float4 *>(src);
+                const uint32_t col = k0 + c4 * 4;
+                if constexpr (SRC == 2) {
+                    const uint16_t *src = static_cast<const uint16_t *>(rows) + static_cast<size_t>(list[row]) * pitch16 * 8 + col;
+                    if (vec) {
+                        const uint2 h = *reinterpret_cast<const uint2 *>(src);
+                        v = make_float4(h2f(static_cast<uint16_t>(h.x)), h2f(static_cast<uint16_t>(h.x >> 16)),
+                                        h2f(static_cast<uint16_t>(h.y)), h2f(static_cast<uint16_t>(h.y >> 16)));
+                    } else {
+                        v.x = h2f(src[0]);
+                        if (c4 * 4 + 1 < kc) v.y = h2f(src[1]);
+                        if (c4 * 4 + 2 < kc) v.z = h2f(src[2]);
+                        if (c4 * 4 + 3 < kc) v.w = h2f(src[3]);
+                    }
                 } else {
-                    v.x = src[0];
-                    if (c4 * 4 + 1 < kc) v.y = src[1];
-                    if (c4 * 4 + 2 < kc) v.z = src[2];
-                    if (c4 * 4 + 3 < kc) v.w = src[3];
+                    const float *src = SRC == 0 ? pool + static_cast<size_t>(row) * dim + col
+                                                : static_cast<const float *>(rows) + static_cast<size_t>(list[row]) * pitch16 * 4 + col;
+                    if (vec) {
+                        v = *reinterpret_cast<const float4 *>(src);
+                    } else {
+                        v.x = src[0];
+                        if (c4 * 4 + 1 < kc) v.y = src[1];
+                        if (c4 * 4 + 2 < kc) v.z = src[2];
+                        if (c4 * 4 + 3 < kc) v.w = src[3];
+                    }
                 }
             }
             pre[u] = v;
@@ -985,6 +1008,22 @@ hipError_t launch_compact_rows(const void *src, void *dst, uint32_t pitch16, con
     return hipGetLastError();
 }
 
+template <int SRC>
+static hipError_t launch_gram_src(const float *pool, uint32_t P, uint32_t dim, float *gram, uint32_t n_queries,
+                                  const void *rows, uint32_t pitch16, const uint32_t *list, hipStream_t s)
+{
+    if (n_queries >= 8) {
+        const uint32_t nb = (P + 63) / 64;
+        hipLaunchKernelGGL((gram_tiled_kernel<4, SRC>), dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim,
+                           gram, rows, pitch16, list);
+    } else {
+        const uint32_t nb = (P + 31) / 32;
+        hipLaunchKernelGGL((gram_tiled_kernel<2, SRC>), dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim,
+                           gram, rows, pitch16, list);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram, uint32_t n_queries, hipStream_t s)
 {
     if (P == 0 || n_queries == 0)
@@ -994,14 +1033,18 @@ hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram,
         hipLaunchKernelGGL(gram_kernel, dim3((P + 63) / 64, P, n_queries), dim3(64), 0, s, pool, P, dim, gram);
         return hipGetLastError();
     }
-    if (n_queries >= 8) {
-        const uint32_t nb = (P + 63) / 64;
-        hipLaunchKernelGGL(gram_tiled_kernel<4>, dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim, gram);
-    } else {
-        const uint32_t nb = (P + 31) / 32;
-        hipLaunchKernelGGL(gram_tiled_kernel<2>, dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim, gram);
-    }
-    return hipGetLastError();
+    return launch_gram_src<0>(pool, P, dim, gram, n_queries, nullptr, 0, nullptr, s);
+}
+
+// the same Gram matrices with the pool rows read from the index through `list` (n_queries x P row numbers)
+hipError_t launch_gram_rows(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const uint32_t *list, uint32_t P,
+                            float *gram, uint32_t n_queries, hipStream_t s)
+{
+    if (P == 0 || n_queries == 0)
+        return hipSuccess;
+    if (dtype == RLR_F16)
+        return launch_gram_src<2>(nullptr, P, dim, gram, n_queries, rows, pitch16, list, s);
+    return launch_gram_src<1>(nullptr, P, dim, gram, n_queries, rows, pitch16, list, s);
 }
 
 // n_queries > 1 (or sizes != null): per-query arrays strided by P, pool sizes in sizes[q] (<= P <= 1024)

@@ -1923,8 +1923,7 @@ int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *po
     const bool timed = ix->profiling;
     RLR_HIP(hipMemcpyAsync(d_sc, pool_scores, static_cast<size_t>(P) * sizeof(float), hipMemcpyHostToDevice, s));
     if (timed) RLR_HIP(hipEventRecord(c->ev[0], s));
-    RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_pool, s));
-    RLR_HIP(launch_gram(d_pool, P, ix->dim, d_gram, 1, s));
+    RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
     RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, nullptr, 1, s));
     if (timed) RLR_HIP(hipEventRecord(c->ev[1], s));
     // one D2H: order | mmr | n are contiguous
@@ -2012,8 +2011,7 @@ int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uin
     hipLaunchKernelGGL(rlr::pool_prepare_kernel, dim3(1), dim3(1024), 0, s, c->d_out, fetch, need, n, w_embedding, w_lexical,
                        c->d_list, d_comb, d_cos, d_info);
     RLR_HIP(hipGetLastError());
-    RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_pool, s));
-    RLR_HIP(launch_gram(d_pool, P, ix->dim, d_gram, 1, s));
+    RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
     RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, k, lambda, d_order, d_mmr, d_nsel, d_info, 1, s));
     hipLaunchKernelGGL(rlr::diverse_emit_kernel, dim3(1), dim3(256), 0, s, c->d_list, d_comb, d_cos, d_order, d_nsel, d_info,
                        k_cap, h_out);
@@ -2079,10 +2077,10 @@ static int32_t mmr_batch_impl(rlr_index *ix, const uint64_t *pool_rows, const fl
     RLR_TRY(ctx_acquire(ix, &lease.c));
     Ctx *c = lease.c;
     hipStream_t s = c->stream;
-    // queries per pass: the workspace (pool m x P x dim f32 + gram m x P x P) is capped at ~3 GB.  All queries of a
+    // queries per pass: the workspace (gram m x P x P + scores / order / mmr) is capped at ~3 GB.  All queries of a
     // pass run their greedy chains concurrently, one wavefront each, so the more queries per pass the better the
     // chip is filled: at 64 per pass (the first version) 1024 pools took 16 rounds of gather + Gram + greedy + sync.
-    const uint64_t per_query = (pool_rows ? static_cast<uint64_t>(P) * ix->dim : 0) + static_cast<uint64_t>(P) * P + 3ull * P + 2;
+    const uint64_t per_query = static_cast<uint64_t>(P) * P + 3ull * P + 2;
     const uint32_t QC = static_cast<uint32_t>(std::max<uint64_t>(64, std::min<uint64_t>(4096, (3ull << 30) / 4 / std::max<uint64_t>(per_query, 1))));
     std::vector<uint64_t> rows_chunk;
     for (uint32_t q0 = 0; q0 < n_queries; q0 += QC) {
@@ -2105,7 +2103,7 @@ static int32_t mmr_batch_impl(rlr_index *ix, const uint64_t *pool_rows, const fl
                             pool_sizes[q0 + q] * sizeof(uint64_t));
             RLR_TRY(upload_list(ix, c, rows_chunk.data(), n_list));
         }
-        const uint64_t pool_floats = pool_rows ? static_cast<uint64_t>(n_list) * ix->dim : 0;
+        const uint64_t pool_floats = 0; // (the pool rows are read in place)
         const uint64_t floats = pool_floats + static_cast<uint64_t>(m) * P * P + 3ull * n_list + 2ull * m + 8;
         RLR_TRY(grow(&c->d_pool, &c->pool_cap, floats));
         float *d_pool = c->d_pool;
@@ -2122,14 +2120,12 @@ static int32_t mmr_batch_impl(rlr_index *ix, const uint64_t *pool_rows, const fl
         std::memcpy(h_sizes, pool_sizes + q0, m * sizeof(uint32_t));
         RLR_HIP(hipMemcpyAsync(d_sc, h_sc, static_cast<size_t>(n_list) * sizeof(float), hipMemcpyHostToDevice, s));
         RLR_HIP(hipMemcpyAsync(d_sizes, h_sizes, m * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        const float *d_rows_f32 = d_pool;
         const bool timed = ix->profiling;
         if (timed) RLR_HIP(hipEventRecord(c->ev[0], s));
-        if (pool_rows)
-            RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, n_list, d_pool, s));
+        if (pool_rows) // the Gram kernel reads the index rows through the list: no gathered copy
+            RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, m, s));
         else
-            d_rows_f32 = d_values + static_cast<size_t>(q0) * P * ix->dim;
-        RLR_HIP(launch_gram(d_rows_f32, P, ix->dim, d_gram, m, s));
+            RLR_HIP(launch_gram(d_values + static_cast<size_t>(q0) * P * ix->dim, P, ix->dim, d_gram, m, s));
         RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, d_sizes, m, s));
         if (timed) RLR_HIP(hipEventRecord(c->ev[1], s));
         // results: order | mmr | n are contiguous

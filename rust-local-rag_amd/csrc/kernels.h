@@ -128,6 +128,9 @@ hipError_t launch_compact_rows(const void *src, void *dst, uint32_t pitch16, con
                                uint32_t n_keep, hipStream_t s);
 // gram[i*P + j] = dot_ref(pool[i], pool[j]) over a dense f32 P x dim pool.
 hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram, uint32_t n_queries, hipStream_t s);
+// the same with the pool rows read straight from the index through list[q * P + i] (no gathered f32 copy)
+hipError_t launch_gram_rows(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const uint32_t *list, uint32_t P,
+                            float *gram, uint32_t n_queries, hipStream_t s);
 // greedy MMR over the gram matrix; out_order/out_mmr/out_n on the device.
 hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P, uint32_t k,
                              float lambda, uint32_t *out_order, float *out_mmr, uint32_t *out_n,
