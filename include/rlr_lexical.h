@@ -32,8 +32,10 @@
  *   - equal scores order by lower row first (the reference's order among ties is arbitrary);
  *   - documents whose total is exactly 0.0 (every matching term has idf 0) are not returned:
  *     in the caller (:515-532) they contribute lexical = 0 exactly like absent documents.
- * Threading: score calls may come from several threads (they serialise on the index's one
- * workspace); mutators need external exclusion, like the reference's write lock.
+ * Threading: the handle carries a readers/writer lock like the reference's RwLock around its engine: score calls
+ * from several threads run concurrently, each on its own stream and workspace (up to 8; further callers wait for
+ * one); add / remove / clear take the lock exclusively and wait for running score calls.  The first score call
+ * after a mutation rebuilds the device postings under the exclusive lock.  destroy needs every call returned.
  */
 #ifndef RLR_LEXICAL_H
 #define RLR_LEXICAL_H

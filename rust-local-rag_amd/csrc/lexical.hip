@@ -4,7 +4,8 @@
 //
 // Host side: term dictionary, per-row term counts, corpus statistics; CSR postings are rebuilt
 // and uploaded lazily by the first score call after a mutation.
-// Device side, per query (one stream, no host round trip until the results are read):
+// Device side, per query (the call's own workspace and stream out of a small pool, so calls on different host threads
+// overlap; no host round trip until the results are read):
 //   bm25_term_kernel   one launch per unique query term, in query order: every posting adds its
 //                      BM25 contribution to a dense per-row accumulator (one writer per row per
 //                      launch, so the f32 sum order is the term order -- deterministic); rows
@@ -24,8 +25,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -300,26 +303,12 @@ void split_tokens(const char *s, size_t len, std::vector<std::string> *out)
 
 } // namespace
 
-struct rlr_lexical {
-    int32_t device = 0;
-    int n_cu = 256;
+// One scoring call's device state: its own stream, dense accumulator and selection buffers, so calls on different host
+// threads run side by side (the reference's engine sits behind a tokio RwLock and serves reads concurrently).
+struct LexWorkspace {
     hipStream_t stream = nullptr;
-    std::mutex mu;
-    // ---- host state (LexicalIndex fields, rag_engine.rs:2084-2090, keyed by row instead of chunk id)
-    std::unordered_map<std::string, uint32_t> term_id;
-    std::vector<uint32_t> df;                                          // term -> documents holding it
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> doc_terms; // row -> (term, count); empty = absent
-    std::vector<uint32_t> doc_len;                                     // row -> token count
-    uint64_t total_docs = 0, total_length = 0, n_postings = 0, n_live_terms = 0;
-    bool dirty = true;
-    bool workspace_dirty = false; // a score call failed after enqueuing work: accumulators / control may be non-zero
-    // ---- device CSR
-    std::vector<uint64_t> term_off;
-    uint32_t *d_post_row = nullptr, *d_post_tf = nullptr, *d_doc_len = nullptr;
-    uint64_t post_cap = 0, post_tf_cap = 0, doc_cap = 0;
-    float *d_scores = nullptr;
+    float *d_scores = nullptr; // one f32 per row, all zero between calls
     uint64_t scores_cap = 0;
-    // ---- per-query workspace
     uint32_t *d_touched = nullptr;
     uint64_t touched_cap = 0;
     uint64_t *d_keys = nullptr;
@@ -328,6 +317,31 @@ struct rlr_lexical {
     LexControl *d_ctl = nullptr;
     uint64_t *d_out = nullptr; // kMaxLimit keys + count
     uint64_t *h_out = nullptr; // pinned mirror
+    bool dirty = false;        // a call failed after enqueuing work: accumulators / control may be non-zero
+};
+
+constexpr int kMaxWorkspaces = 8; // callers beyond this wait for a free one
+
+struct rlr_lexical {
+    int32_t device = 0;
+    int n_cu = 256;
+    std::shared_mutex mu; // mutators and commit exclusive, scoring calls shared
+    // ---- host state (LexicalIndex fields, rag_engine.rs:2084-2090, keyed by row instead of chunk id)
+    std::unordered_map<std::string, uint32_t> term_id;
+    std::vector<uint32_t> df;                                          // term -> documents holding it
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> doc_terms; // row -> (term, count); empty = absent
+    std::vector<uint32_t> doc_len;                                     // row -> token count
+    uint64_t total_docs = 0, total_length = 0, n_postings = 0, n_live_terms = 0;
+    bool dirty = true;
+    // ---- device CSR
+    std::vector<uint64_t> term_off;
+    uint32_t *d_post_row = nullptr, *d_post_tf = nullptr, *d_doc_len = nullptr;
+    uint64_t post_cap = 0, post_tf_cap = 0, doc_cap = 0;
+    // ---- per-call workspaces
+    std::mutex ws_mu;
+    std::condition_variable ws_cv;
+    std::vector<LexWorkspace *> ws_free;
+    int ws_made = 0;
 };
 
 namespace {
@@ -352,6 +366,89 @@ void remove_row_stats(rlr_lexical *lx, uint64_t row)
     lx->doc_len[row] = 0;
 }
 
+void workspace_destroy(LexWorkspace *ws)
+{
+    if (!ws)
+        return;
+    if (ws->stream) {
+        (void)hipStreamSynchronize(ws->stream);
+        (void)hipStreamDestroy(ws->stream);
+    }
+    void *dev[] = {ws->d_scores, ws->d_touched, ws->d_keys, ws->d_sel, ws->d_ctl, ws->d_out};
+    for (void *p : dev)
+        if (p)
+            (void)hipFree(p);
+    if (ws->h_out)
+        (void)hipHostFree(ws->h_out);
+    delete ws;
+}
+
+int32_t workspace_create(LexWorkspace **out)
+{
+    LexWorkspace *ws = new (std::nothrow) LexWorkspace();
+    if (!ws)
+        return set_error(RLR_E_OOM, "host allocation failed");
+    hipError_t e = hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = rlr::dev_malloc(reinterpret_cast<void **>(&ws->d_ctl), sizeof(LexControl));
+    if (e == hipSuccess)
+        e = hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), ws->stream); // ordered before every call on this stream
+    if (e == hipSuccess)
+        e = rlr::dev_malloc(reinterpret_cast<void **>(&ws->d_sel), kMaxLimit * sizeof(uint64_t));
+    if (e == hipSuccess)
+        e = rlr::dev_malloc(reinterpret_cast<void **>(&ws->d_out), (kMaxLimit + 1) * sizeof(uint64_t));
+    if (e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void **>(&ws->h_out), (kMaxLimit + 1) * sizeof(uint64_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        workspace_destroy(ws);
+        return set_error(e == hipErrorOutOfMemory ? RLR_E_OOM : RLR_E_HIP, "lexical workspace setup failed: %s",
+                         hipGetErrorString(e));
+    }
+    *out = ws;
+    return RLR_OK;
+}
+
+// A free workspace, a new one while fewer than kMaxWorkspaces exist, else wait for a call to finish.
+int32_t workspace_acquire(rlr_lexical *lx, LexWorkspace **out)
+{
+    std::unique_lock<std::mutex> lk(lx->ws_mu);
+    for (;;) {
+        if (!lx->ws_free.empty()) {
+            *out = lx->ws_free.back();
+            lx->ws_free.pop_back();
+            return RLR_OK;
+        }
+        if (lx->ws_made < kMaxWorkspaces) {
+            lx->ws_made++;
+            lk.unlock();
+            const int32_t st = workspace_create(out);
+            if (st != RLR_OK) {
+                lk.lock();
+                lx->ws_made--;
+                lx->ws_cv.notify_one();
+            }
+            return st;
+        }
+        lx->ws_cv.wait(lk);
+    }
+}
+
+struct WorkspaceLease {
+    rlr_lexical *lx;
+    LexWorkspace *ws = nullptr;
+    explicit WorkspaceLease(rlr_lexical *l) : lx(l) {}
+    ~WorkspaceLease()
+    {
+        if (!ws)
+            return;
+        {
+            std::lock_guard<std::mutex> lk(lx->ws_mu);
+            lx->ws_free.push_back(ws);
+        }
+        lx->ws_cv.notify_one();
+    }
+};
+
 int32_t commit(rlr_lexical *lx)
 {
     const uint64_t n_rows = lx->doc_terms.size();
@@ -371,10 +468,6 @@ int32_t commit(rlr_lexical *lx)
     LEX_TRY(dev_grow(&lx->d_post_row, &lx->post_cap, total));
     LEX_TRY(dev_grow(&lx->d_post_tf, &lx->post_tf_cap, total));
     LEX_TRY(dev_grow(&lx->d_doc_len, &lx->doc_cap, n_rows));
-    if (lx->scores_cap < n_rows || !lx->d_scores) {
-        LEX_HIP(hipStreamSynchronize(lx->stream));
-        LEX_TRY(dev_grow(&lx->d_scores, &lx->scores_cap, n_rows + n_rows / 4, /*zero=*/true));
-    }
     if (total) {
         LEX_HIP(hipMemcpy(lx->d_post_row, rows.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
         LEX_HIP(hipMemcpy(lx->d_post_tf, tfs.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -409,23 +502,20 @@ int32_t rlr_lexical_create(int32_t device_id, rlr_lexical **out)
         e = hipGetDeviceProperties(&prop, device_id);
     if (e == hipSuccess) {
         lx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        e = hipStreamCreateWithFlags(&lx->stream, hipStreamNonBlocking);
     }
-    if (e == hipSuccess)
-        e = rlr::dev_malloc(reinterpret_cast<void **>(&lx->d_ctl), sizeof(LexControl));
-    if (e == hipSuccess)
-        e = hipMemsetAsync(lx->d_ctl, 0, sizeof(LexControl), lx->stream); // ordered before every scoring call
-    if (e == hipSuccess)
-        e = rlr::dev_malloc(reinterpret_cast<void **>(&lx->d_sel), kMaxLimit * sizeof(uint64_t));
-    if (e == hipSuccess)
-        e = rlr::dev_malloc(reinterpret_cast<void **>(&lx->d_out), (kMaxLimit + 1) * sizeof(uint64_t));
-    if (e == hipSuccess)
-        e = hipHostMalloc(reinterpret_cast<void **>(&lx->h_out), (kMaxLimit + 1) * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         rlr_lexical_destroy(lx);
         return set_error(e == hipErrorOutOfMemory ? RLR_E_OOM : RLR_E_HIP, "lexical index setup failed: %s",
                          hipGetErrorString(e));
     }
+    LexWorkspace *ws = nullptr; // the first workspace now, so a device without memory fails here and not in score
+    const int32_t st = workspace_create(&ws);
+    if (st != RLR_OK) {
+        rlr_lexical_destroy(lx);
+        return st;
+    }
+    lx->ws_free.push_back(ws);
+    lx->ws_made = 1;
     *out = lx;
     return RLR_OK;
 }
@@ -435,17 +525,12 @@ void rlr_lexical_destroy(rlr_lexical *lx)
     if (!lx)
         return;
     (void)hipSetDevice(lx->device);
-    if (lx->stream) {
-        (void)hipStreamSynchronize(lx->stream);
-        (void)hipStreamDestroy(lx->stream);
-    }
-    void *dev[] = {lx->d_post_row, lx->d_post_tf, lx->d_doc_len, lx->d_scores, lx->d_touched,
-                   lx->d_keys,     lx->d_sel,     lx->d_ctl,     lx->d_out};
+    for (LexWorkspace *ws : lx->ws_free) // every call has returned (the caller's contract), so all of them are here
+        workspace_destroy(ws);
+    void *dev[] = {lx->d_post_row, lx->d_post_tf, lx->d_doc_len};
     for (void *p : dev)
         if (p)
             (void)hipFree(p);
-    if (lx->h_out)
-        (void)hipHostFree(lx->h_out);
     delete lx;
 }
 
@@ -457,7 +542,7 @@ int32_t rlr_lexical_add_chunk(rlr_lexical *lx, uint64_t row, const char *tokens,
         return set_error(RLR_E_INVALID, "tokens is null");
     if (row >= 0xFFFFFFFFull)
         return set_error(RLR_E_RANGE, "row %llu does not fit the 32-bit postings", static_cast<unsigned long long>(row));
-    std::lock_guard<std::mutex> lk(lx->mu);
+    std::unique_lock<std::shared_mutex> lk(lx->mu);
     if (row >= lx->doc_terms.size()) {
         lx->doc_terms.resize(row + 1);
         lx->doc_len.resize(row + 1, 0);
@@ -507,7 +592,7 @@ int32_t rlr_lexical_remove_rows(rlr_lexical *lx, const uint64_t *rows, uint32_t 
         return RLR_OK;
     if (!rows)
         return set_error(RLR_E_INVALID, "rows is null");
-    std::lock_guard<std::mutex> lk(lx->mu);
+    std::unique_lock<std::shared_mutex> lk(lx->mu);
     const uint64_t size = lx->doc_terms.size();
     std::vector<char> dead(size, 0);
     bool any = false;
@@ -538,7 +623,7 @@ int32_t rlr_lexical_clear(rlr_lexical *lx)
 {
     if (!lx)
         return set_error(RLR_E_INVALID, "lexical handle is null");
-    std::lock_guard<std::mutex> lk(lx->mu);
+    std::unique_lock<std::shared_mutex> lk(lx->mu);
     lx->term_id.clear();
     lx->df.clear();
     lx->doc_terms.clear();
@@ -552,7 +637,7 @@ int32_t rlr_lexical_contains(rlr_lexical *lx, uint64_t row)
 {
     if (!lx)
         return set_error(RLR_E_INVALID, "lexical handle is null");
-    std::lock_guard<std::mutex> lk(lx->mu);
+    std::unique_lock<std::shared_mutex> lk(lx->mu);
     return row < lx->doc_terms.size() && !lx->doc_terms[row].empty() ? 1 : 0;
 }
 
@@ -561,7 +646,7 @@ int32_t rlr_lexical_info(rlr_lexical *lx, uint64_t *total_docs, uint64_t *total_
 {
     if (!lx)
         return set_error(RLR_E_INVALID, "lexical handle is null");
-    std::lock_guard<std::mutex> lk(lx->mu);
+    std::unique_lock<std::shared_mutex> lk(lx->mu);
     if (total_docs) *total_docs = lx->total_docs;
     if (total_length) *total_length = lx->total_length;
     if (n_terms) *n_terms = lx->n_live_terms;
@@ -579,26 +664,29 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     *n_out = 0;
     if (len && !query_tokens)
         return set_error(RLR_E_INVALID, "query_tokens is null");
-    std::lock_guard<std::mutex> lk(lx->mu);
-    if (lx->total_docs == 0) // :2170-2172
-        return RLR_OK;
     std::vector<std::string> toks;
     split_tokens(query_tokens, len, &toks);
     if (toks.empty()) // :2175-2177
         return RLR_OK;
     const uint32_t lim = limit == 0 ? kMaxLimit : std::min(limit, kMaxLimit);
+    // Scoring calls share the index; only rebuilding the device postings after a mutation needs it alone.
+    std::shared_lock<std::shared_mutex> rd(lx->mu);
+    if (lx->total_docs == 0) // :2170-2172
+        return RLR_OK;
     if (!rows_out || !scores_out)
         return set_error(RLR_E_INVALID, "rows_out / scores_out is null");
     LEX_HIP(hipSetDevice(lx->device));
-    if (lx->dirty)
-        LEX_TRY(commit(lx));
-    if (lx->workspace_dirty) { // restore the all-zero invariant a failed call may have broken
-        LEX_HIP(hipStreamSynchronize(lx->stream));
-        if (lx->d_scores)
-            LEX_HIP(hipMemsetAsync(lx->d_scores, 0, lx->scores_cap * sizeof(float), lx->stream));
-        LEX_HIP(hipMemsetAsync(lx->d_ctl, 0, sizeof(LexControl), lx->stream));
-        lx->workspace_dirty = false;
+    while (lx->dirty) {
+        rd.unlock();
+        {
+            std::unique_lock<std::shared_mutex> wr(lx->mu);
+            if (lx->dirty)
+                LEX_TRY(commit(lx));
+        }
+        rd.lock();
     }
+    if (lx->total_docs == 0) // emptied by another thread while the lock was released
+        return RLR_OK;
 
     // unique query terms in order of first occurrence (:2179-2182 uses a HashSet: order unspecified there)
     std::vector<uint32_t> terms;
@@ -615,12 +703,28 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     if (upper == 0)
         return RLR_OK;
     upper = std::min<uint64_t>(upper, lx->doc_terms.size()); // at most one touched entry per row
-    LEX_TRY(dev_grow(&lx->d_touched, &lx->touched_cap, upper));
+    WorkspaceLease lease(lx); // back to the pool on every return path
+    LEX_TRY(workspace_acquire(lx, &lease.ws));
+    LexWorkspace *ws = lease.ws;
+    const uint64_t n_rows = lx->doc_terms.size();
+    if (ws->scores_cap < n_rows || !ws->d_scores) { // the index grew since this workspace last ran
+        LEX_HIP(hipStreamSynchronize(ws->stream));
+        LEX_TRY(dev_grow(&ws->d_scores, &ws->scores_cap, n_rows + n_rows / 4, /*zero=*/true));
+        ws->dirty = false;
+        LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), ws->stream));
+    }
+    if (ws->dirty) { // restore the all-zero invariant a failed call may have broken
+        LEX_HIP(hipStreamSynchronize(ws->stream));
+        LEX_HIP(hipMemsetAsync(ws->d_scores, 0, ws->scores_cap * sizeof(float), ws->stream));
+        LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), ws->stream));
+        ws->dirty = false;
+    }
+    LEX_TRY(dev_grow(&ws->d_touched, &ws->touched_cap, upper));
 
     const float n_docs = static_cast<float>(lx->total_docs);
     const float avg = static_cast<float>(lx->total_length) / n_docs; // :2184-2188
-    hipStream_t s = lx->stream;
-    lx->workspace_dirty = true; // cleared below once the whole pipeline has run
+    hipStream_t s = ws->stream;
+    ws->dirty = true; // cleared below once the whole pipeline has run
     const uint32_t max_blocks = static_cast<uint32_t>(lx->n_cu) * 8;
     for (uint32_t t : terms) {
         const float df = static_cast<float>(lx->df[t]);
@@ -630,38 +734,38 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
         const uint64_t off = lx->term_off[t];
         const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, max_blocks);
         hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_post_row + off, lx->d_post_tf + off, cnt,
-                           lx->d_doc_len, avg, idf, lx->d_scores, lx->d_touched, lx->d_ctl);
+                           lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
     }
     LEX_HIP(hipGetLastError());
-    uint32_t *d_out_n = reinterpret_cast<uint32_t *>(lx->d_out + kMaxLimit);
+    uint32_t *d_out_n = reinterpret_cast<uint32_t *>(ws->d_out + kMaxLimit);
     const uint32_t blocks_u = std::min<uint32_t>(static_cast<uint32_t>((upper + 255) / 256), max_blocks);
     if (upper <= kMaxLimit) {
-        hipLaunchKernelGGL(lex_sort_kernel<true>, dim3(1), dim3(1024), 0, s, lx->d_scores, lx->d_touched, nullptr, lx->d_ctl,
-                           lim, lx->d_out, d_out_n);
+        hipLaunchKernelGGL(lex_sort_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, nullptr, ws->d_ctl,
+                           lim, ws->d_out, d_out_n);
     } else {
-        LEX_TRY(dev_grow(&lx->d_keys, &lx->keys_cap, upper));
-        hipLaunchKernelGGL(lex_pack_kernel, dim3(blocks_u), dim3(256), 0, s, lx->d_scores, lx->d_touched, lx->d_ctl,
-                           lx->d_keys);
+        LEX_TRY(dev_grow(&ws->d_keys, &ws->keys_cap, upper));
+        hipLaunchKernelGGL(lex_pack_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl,
+                           ws->d_keys);
         for (int p = 0; p < kPasses; ++p)
-            hipLaunchKernelGGL(lex_select_pass_kernel, dim3(blocks_u), dim3(256), 0, s, lx->d_keys, lx->d_ctl, lim, p);
-        hipLaunchKernelGGL(lex_collect_kernel, dim3(blocks_u), dim3(256), 0, s, lx->d_keys, lx->d_ctl, lim, lx->d_sel);
-        hipLaunchKernelGGL(lex_sort_kernel<false>, dim3(1), dim3(1024), 0, s, nullptr, nullptr, lx->d_sel, lx->d_ctl, lim,
-                           lx->d_out, d_out_n);
+            hipLaunchKernelGGL(lex_select_pass_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, p);
+        hipLaunchKernelGGL(lex_collect_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, ws->d_sel);
+        hipLaunchKernelGGL(lex_sort_kernel<false>, dim3(1), dim3(1024), 0, s, nullptr, nullptr, ws->d_sel, ws->d_ctl, lim,
+                           ws->d_out, d_out_n);
     }
     LEX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(lex_clear_kernel, dim3(blocks_u), dim3(256), 0, s, lx->d_scores, lx->d_touched, lx->d_ctl);
+    hipLaunchKernelGGL(lex_clear_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl);
     LEX_HIP(hipGetLastError());
-    LEX_HIP(hipMemsetAsync(lx->d_ctl, 0, sizeof(LexControl), s));
+    LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), s));
     // one copy: the count sits right behind the keys; only `lim` keys can be valid
-    LEX_HIP(hipMemcpyAsync(lx->h_out + kMaxLimit, lx->d_out + kMaxLimit, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    LEX_HIP(hipMemcpyAsync(lx->h_out, lx->d_out, static_cast<size_t>(lim) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    LEX_HIP(hipMemcpyAsync(ws->h_out + kMaxLimit, ws->d_out + kMaxLimit, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    LEX_HIP(hipMemcpyAsync(ws->h_out, ws->d_out, static_cast<size_t>(lim) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     LEX_HIP(hipStreamSynchronize(s));
-    lx->workspace_dirty = false;
-    const uint32_t n = std::min<uint32_t>(*reinterpret_cast<const uint32_t *>(lx->h_out + kMaxLimit), lim);
+    ws->dirty = false;
+    const uint32_t n = std::min<uint32_t>(*reinterpret_cast<const uint32_t *>(ws->h_out + kMaxLimit), lim);
     for (uint32_t i = 0; i < n; ++i) {
         float sc;
         uint32_t row;
-        unpack_result(lx->h_out[i], &sc, &row);
+        unpack_result(ws->h_out[i], &sc, &row);
         rows_out[i] = row;
         scores_out[i] = sc;
     }

@@ -25,3 +25,19 @@ for name, toks in [("rare 1 term", ["t20000"]), ("mid 3 terms", ["t00100", "t002
             r, s = g.score_tokens(toks, lim)
         dt = (time.perf_counter() - t0) / 20
         print("%-20s limit %4d: %7.1f us, %d results, top %.4f" % (name, lim, dt * 1e6, len(r), s[0] if len(s) else 0))
+
+# concurrent callers: each call has its own workspace and stream (csrc/lexical.hip), so the waits overlap
+import threading
+mix = [["t20000"], ["t00100", "t00200", "t00300"], ["t00001"], ["t00001", "t00002", "t00010", "t00100", "t01000"]]
+def run(n_threads, per=200):
+    def w(tid):
+        for i in range(per):
+            g.score_tokens(mix[(tid + i) % 4], 500)
+    ts = [threading.Thread(target=w, args=(t,)) for t in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in ts: t.start()
+    for t in ts: t.join()
+    dt = time.perf_counter() - t0
+    print("%2d caller threads: %8.0f score calls/s" % (n_threads, n_threads * per / dt), flush=True)
+for nt in (1, 2, 4, 8, 16):
+    run(nt)

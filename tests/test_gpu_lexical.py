@@ -160,3 +160,56 @@ def test_gpu_bm25_against_the_hand_derived_vectors(rlr):
             assert [int(r) for r in rows] == q["rows"], (case["name"], q["terms"])
             assert [int(x) for x in bits(sc)] == q["score_bits"], (case["name"], q["terms"])
         g.close()
+
+
+def test_bm25_concurrent_score_calls_use_their_own_workspaces(rlr):
+    """Scoring calls from several host threads run side by side (one workspace and stream each, more callers than
+    workspaces wait): every answer is the serial one, bit for bit, on both selection paths, and a mutation between
+    two waves of calls is seen by all of them."""
+    import threading
+
+    texts = make_texts(30000, seed=11, lo=2, hi=10, common_every=2)  # "ubiquitous": 15 000 postings -> select path
+    g, o = build_pair(rlr, texts)
+    queries = [("ubiquitous", 100), ("w000x w001x", 50), ("w017x", 0), ("ubiquitous w003x common", 500),
+               ("frequent the of", 25), ("w399x w398x w397x", 10)]
+    want = {}
+    for q, lim in queries:
+        rows, sc = g.score(q, lim)
+        check(g, o, q, lim)
+        want[(q, lim)] = (rows.copy(), sc.copy())
+
+    def wave(expect, n_threads=12, rounds=25):
+        errors = []
+
+        def worker(tid):
+            try:
+                for i in range(rounds):
+                    q, lim = queries[(tid + i) % len(queries)]
+                    rows, sc = g.score(q, lim)
+                    er, es = expect[(q, lim)]
+                    if not (np.array_equal(rows, er) and np.array_equal(bits(sc), bits(es))):
+                        errors.append((tid, i, q, lim))
+            except Exception as e:  # noqa: BLE001 -- reported below
+                errors.append((tid, repr(e)))
+
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors[:5]
+
+    wave(want)
+    # grow the index past every workspace's accumulator and change the statistics
+    extra = make_texts(12000, seed=12, lo=2, hi=10, common_every=2)
+    for i, t in enumerate(extra):
+        g.add_chunk(len(texts) + i, t)
+        o.add_chunk(len(texts) + i, t, rank=len(texts) + i)
+    want2 = {}
+    for q, lim in queries:
+        check(g, o, q, lim)
+        rows, sc = g.score(q, lim)
+        want2[(q, lim)] = (rows.copy(), sc.copy())
+    assert any(not np.array_equal(want[k][0], want2[k][0]) for k in want)
+    wave(want2)
+    g.close()
