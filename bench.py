@@ -311,19 +311,26 @@ def config_c5_share(rlr, torch):
         qs = queries_without_oracle(rlr, dim, nq, 0x5EED0005)
         ix = eng.index
         pool = max(3 * k, k + 10)
-        ix.search_topk(qs[:256], pool + 8)
+        # one untimed full-size pass first: it grows the per-call workspaces (hipMalloc / hipHostMalloc of the candidate
+        # lists, the 1024 x 300 x 300 Gram block, the pinned staging) -- a server pays that once, not per batch
+        r, c = ix.search_topk(qs, pool + 8)
+        sc = (np.float32(0.7) * c[:, :pool]).astype(np.float32)
+        rows_in, sizes = np.ascontiguousarray(r[:, :pool]), np.full(nq, pool, np.uint32)
+        ix.mmr_select_batch(rows_in, sc, sizes, k, lam)
         ix.profile_read(reset=True)
         ix.profile_enable(True)
+        reps = 3
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        r, c = ix.search_topk(qs, pool + 8)                       # what search_with_diversity_batch fetches
+        for _ in range(reps):
+            r, c = ix.search_topk(qs, pool + 8)                   # what search_with_diversity_batch fetches
         torch.cuda.synchronize()
-        t_search = time.perf_counter() - t0
-        sc = (np.float32(0.7) * c[:, :pool]).astype(np.float32)
+        t_search = (time.perf_counter() - t0) / reps
         t0 = time.perf_counter()
-        ix.mmr_select_batch(np.ascontiguousarray(r[:, :pool]), sc, np.full(nq, pool, np.uint32), k, lam)
+        for _ in range(reps):
+            ix.mmr_select_batch(rows_in, sc, sizes, k, lam)
         torch.cuda.synchronize()
-        t_mmr = time.perf_counter() - t0
+        t_mmr = (time.perf_counter() - t0) / reps
         ix.profile_enable(False)
         p = ix.profile_read()
     finally:
@@ -332,9 +339,9 @@ def config_c5_share(rlr, torch):
                         f"MMR lambda={lam} (pool {pool}); nomination image",
             "value": nq / (t_search + t_mmr), "unit": "queries/s",
             "stages_ms": {"batched_search_pool308": t_search * 1e3, "batched_mmr": t_mmr * 1e3,
-                          "gemm_all_launches": p.batch_gemm_ms, "select_and_finish": p.batch_other_ms,
-                          "mmr_kernels": p.mmr_ms},
-            "fallback_queries": p.n_batch_fallbacks, "roofline": batched_roofline(p, dim, nq, True)}
+                          "gemm_all_launches": p.batch_gemm_ms / reps, "select_and_finish": p.batch_other_ms / reps,
+                          "mmr_kernels": p.mmr_ms / reps},
+            "timed_passes": reps, "fallback_queries": p.n_batch_fallbacks, "roofline": batched_roofline(p, dim, nq, True)}
 
 
 def main():

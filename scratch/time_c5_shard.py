@@ -17,13 +17,18 @@ if "--image" in sys.argv:
     ix.enable_batch_image(True)
 # raw batched top-308 search
 ix.search_topk(qn[:64], 308)
+if "--cold" not in sys.argv:  # steady state: the first full-size call grows the per-call workspaces (hipMalloc / hipHostMalloc)
+    ix.search_topk(qn, 308)
 ix.profile_read(reset=True); ix.profile_enable(True)
 t0 = time.perf_counter(); r, c = ix.search_topk(qn, 308); t_search = time.perf_counter() - t0
 p = ix.profile_read(); ix.profile_enable(False)
 # batched MMR alone
 sc = (np.float32(0.7) * c).astype(np.float32)
 sizes = np.full(nq, 308, np.uint32)
-t0 = time.perf_counter(); order, mmr, nn = ix.mmr_select_batch(r[:, :300].copy(), sc[:, :300].copy(), np.full(nq, 300, np.uint32), k, lam); t_mmr = time.perf_counter() - t0
+if "--cold" not in sys.argv:
+    ix.mmr_select_batch(r[:, :300].copy(), sc[:, :300].copy(), np.full(nq, 300, np.uint32), k, lam)
+rr, ss, zz = r[:, :300].copy(), sc[:, :300].copy(), np.full(nq, 300, np.uint32)
+t0 = time.perf_counter(); order, mmr, nn = ix.mmr_select_batch(rr, ss, zz, k, lam); t_mmr = time.perf_counter() - t0
 # single-path spot check of 3 queries
 ok = True
 for i in (0, 511, 1023):
