@@ -73,10 +73,18 @@ int32_t rlr_lexical_contains(rlr_lexical *lex, uint64_t row);
 int32_t rlr_lexical_info(rlr_lexical *lex, uint64_t *total_docs, uint64_t *total_length,
                          uint64_t *n_terms, uint64_t *n_postings);
 
+/* How the postings sit on the device (no reference counterpart: the reference's HashMap needs no rebuild).  The
+ * main segment holds the rows present at the last full rebuild, the appended segment the rows added since; a commit
+ * that finds only appends rebuilds the appended segment alone.  Any pointer may be null. */
+int32_t rlr_lexical_segments(rlr_lexical *lex, uint64_t *main_postings, uint64_t *appended_postings,
+                             uint64_t *full_rebuilds, uint64_t *append_rebuilds);
+
 /* LexicalIndex::score (:2169-2225).  `query_tokens` like `tokens` above.  Writes at most
  * min(limit, RLR_LEXICAL_MAX_LIMIT) pairs, ordered (score desc, row asc); limit == 0 means
  * "no truncation" in the reference (:2220) and is served up to RLR_LEXICAL_MAX_LIMIT pairs.
- * The first call after a mutation rebuilds and uploads the postings. */
+ * The first call after a mutation brings the device postings up to date: appends (rows beyond every row present at
+ * the last full rebuild) cost O(terms + appended postings); a replaced or removed row, or an appended segment that
+ * has outgrown an eighth of the main one, costs a full rebuild. */
 int32_t rlr_lexical_score(rlr_lexical *lex, const char *query_tokens, size_t len, uint32_t limit,
                           uint64_t *rows_out, float *scores_out, uint32_t *n_out);
 

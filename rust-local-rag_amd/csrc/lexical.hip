@@ -332,11 +332,20 @@ struct rlr_lexical {
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> doc_terms; // row -> (term, count); empty = absent
     std::vector<uint32_t> doc_len;                                     // row -> token count
     uint64_t total_docs = 0, total_length = 0, n_postings = 0, n_live_terms = 0;
-    bool dirty = true;
+    // Two posting segments on the device, both CSR by term.  MAIN holds rows [0, main_rows) as of the last full
+    // rebuild; DELTA holds the rows appended since (row >= main_rows) and is the only thing rebuilt when a commit finds
+    // nothing but appends -- an ingest loop that searches after every document would otherwise re-upload the whole
+    // corpus' postings each time.  Every row lives in exactly one segment, so a term still adds to a row once per
+    // launch and the f32 sum order is unchanged.  DELTA is folded into MAIN when it outgrows main / 8 (amortised O(1)).
+    bool full_dirty = true;   // a row of MAIN changed (replace / remove / clear), or nothing was built yet
+    bool delta_dirty = false; // only rows >= main_rows changed since the last commit
+    uint64_t main_rows = 0, main_postings = 0, delta_postings = 0, n_full_commits = 0, n_delta_commits = 0;
+    std::vector<uint32_t> main_df; // documents per term inside MAIN (terms born later: beyond its end, 0)
     // ---- device CSR
-    std::vector<uint64_t> term_off;
+    std::vector<uint64_t> term_off, dterm_off; // MAIN / DELTA offsets by term
     uint32_t *d_post_row = nullptr, *d_post_tf = nullptr, *d_doc_len = nullptr;
-    uint64_t post_cap = 0, post_tf_cap = 0, doc_cap = 0;
+    uint32_t *d_dpost_row = nullptr, *d_dpost_tf = nullptr;
+    uint64_t post_cap = 0, post_tf_cap = 0, doc_cap = 0, dpost_cap = 0, dpost_tf_cap = 0;
     // ---- per-call workspaces
     std::mutex ws_mu;
     std::condition_variable ws_cv;
@@ -449,7 +458,7 @@ struct WorkspaceLease {
     }
 };
 
-int32_t commit(rlr_lexical *lx)
+int32_t commit_full(rlr_lexical *lx)
 {
     const uint64_t n_rows = lx->doc_terms.size();
     const size_t n_terms = lx->df.size();
@@ -467,15 +476,70 @@ int32_t commit(rlr_lexical *lx)
         }
     LEX_TRY(dev_grow(&lx->d_post_row, &lx->post_cap, total));
     LEX_TRY(dev_grow(&lx->d_post_tf, &lx->post_tf_cap, total));
-    LEX_TRY(dev_grow(&lx->d_doc_len, &lx->doc_cap, n_rows));
+    LEX_TRY(dev_grow(&lx->d_doc_len, &lx->doc_cap, n_rows + n_rows / 4)); // headroom: appends upload only their part
     if (total) {
         LEX_HIP(hipMemcpy(lx->d_post_row, rows.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
         LEX_HIP(hipMemcpy(lx->d_post_tf, tfs.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (n_rows)
         LEX_HIP(hipMemcpy(lx->d_doc_len, lx->doc_len.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice));
-    lx->dirty = false;
+    lx->main_rows = n_rows;
+    lx->main_postings = total;
+    lx->main_df = lx->df;
+    lx->dterm_off.clear();
+    lx->delta_postings = 0;
+    lx->full_dirty = lx->delta_dirty = false;
+    lx->n_full_commits++;
     return RLR_OK;
+}
+
+// Only rows >= main_rows changed: rebuild DELTA from them (O(terms + their postings)), upload their lengths.
+int32_t commit_delta(rlr_lexical *lx)
+{
+    const uint64_t n_rows = lx->doc_terms.size();
+    const size_t n_terms = lx->df.size();
+    lx->dterm_off.assign(n_terms + 1, 0);
+    for (size_t t = 0; t < n_terms; ++t) {
+        const uint32_t in_main = t < lx->main_df.size() ? lx->main_df[t] : 0u;
+        lx->dterm_off[t + 1] = lx->dterm_off[t] + (lx->df[t] - in_main); // MAIN is untouched, so the rest is DELTA's
+    }
+    const uint64_t total = lx->dterm_off[n_terms];
+    std::vector<uint32_t> rows(std::max<uint64_t>(total, 1)), tfs(std::max<uint64_t>(total, 1));
+    std::vector<uint64_t> fill(lx->dterm_off.begin(), lx->dterm_off.end() - 1);
+    for (uint64_t r = lx->main_rows; r < n_rows; ++r)
+        for (const auto &tc : lx->doc_terms[r]) {
+            const uint64_t at = fill[tc.first]++;
+            rows[at] = static_cast<uint32_t>(r);
+            tfs[at] = tc.second;
+        }
+    LEX_TRY(dev_grow(&lx->d_dpost_row, &lx->dpost_cap, total + total / 2));
+    LEX_TRY(dev_grow(&lx->d_dpost_tf, &lx->dpost_tf_cap, total + total / 2));
+    if (total) {
+        LEX_HIP(hipMemcpy(lx->d_dpost_row, rows.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+        LEX_HIP(hipMemcpy(lx->d_dpost_tf, tfs.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (n_rows > lx->doc_cap || !lx->d_doc_len) { // outgrew the headroom: new buffer, every length again
+        LEX_TRY(dev_grow(&lx->d_doc_len, &lx->doc_cap, n_rows + n_rows / 4));
+        LEX_HIP(hipMemcpy(lx->d_doc_len, lx->doc_len.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice));
+    } else if (n_rows > lx->main_rows) {
+        LEX_HIP(hipMemcpy(lx->d_doc_len + lx->main_rows, lx->doc_len.data() + lx->main_rows,
+                          (n_rows - lx->main_rows) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    lx->delta_postings = total;
+    lx->delta_dirty = false;
+    lx->n_delta_commits++;
+    return RLR_OK;
+}
+
+// caller holds the index exclusively
+int32_t commit(rlr_lexical *lx)
+{
+    if (!lx->full_dirty) {
+        const uint64_t pending = lx->n_postings - lx->main_postings; // what DELTA would hold
+        if (pending <= std::max<uint64_t>(65536, lx->main_postings / 8))
+            return commit_delta(lx);
+    }
+    return commit_full(lx);
 }
 
 } // namespace
@@ -527,7 +591,7 @@ void rlr_lexical_destroy(rlr_lexical *lx)
     (void)hipSetDevice(lx->device);
     for (LexWorkspace *ws : lx->ws_free) // every call has returned (the caller's contract), so all of them are here
         workspace_destroy(ws);
-    void *dev[] = {lx->d_post_row, lx->d_post_tf, lx->d_doc_len};
+    void *dev[] = {lx->d_post_row, lx->d_post_tf, lx->d_doc_len, lx->d_dpost_row, lx->d_dpost_tf};
     for (void *p : dev)
         if (p)
             (void)hipFree(p);
@@ -548,7 +612,10 @@ int32_t rlr_lexical_add_chunk(rlr_lexical *lx, uint64_t row, const char *tokens,
         lx->doc_len.resize(row + 1, 0);
     }
     remove_row_stats(lx, row); // `if self.doc_terms.contains_key(id) { self.remove_chunk(id) }`
-    lx->dirty = true;
+    if (row < lx->main_rows)
+        lx->full_dirty = true; // a row of the main segment changes
+    else
+        lx->delta_dirty = true;
     std::vector<std::string> toks;
     split_tokens(tokens, len, &toks);
     if (toks.empty())
@@ -615,7 +682,7 @@ int32_t rlr_lexical_remove_rows(rlr_lexical *lx, const uint64_t *rows, uint32_t 
         }
     lx->doc_terms.resize(w);
     lx->doc_len.resize(w);
-    lx->dirty = true;
+    lx->full_dirty = true; // rows are renumbered
     return RLR_OK;
 }
 
@@ -629,7 +696,7 @@ int32_t rlr_lexical_clear(rlr_lexical *lx)
     lx->doc_terms.clear();
     lx->doc_len.clear();
     lx->total_docs = lx->total_length = lx->n_postings = lx->n_live_terms = 0;
-    lx->dirty = true;
+    lx->full_dirty = true;
     return RLR_OK;
 }
 
@@ -637,7 +704,7 @@ int32_t rlr_lexical_contains(rlr_lexical *lx, uint64_t row)
 {
     if (!lx)
         return set_error(RLR_E_INVALID, "lexical handle is null");
-    std::unique_lock<std::shared_mutex> lk(lx->mu);
+    std::shared_lock<std::shared_mutex> lk(lx->mu);
     return row < lx->doc_terms.size() && !lx->doc_terms[row].empty() ? 1 : 0;
 }
 
@@ -646,11 +713,24 @@ int32_t rlr_lexical_info(rlr_lexical *lx, uint64_t *total_docs, uint64_t *total_
 {
     if (!lx)
         return set_error(RLR_E_INVALID, "lexical handle is null");
-    std::unique_lock<std::shared_mutex> lk(lx->mu);
+    std::shared_lock<std::shared_mutex> lk(lx->mu);
     if (total_docs) *total_docs = lx->total_docs;
     if (total_length) *total_length = lx->total_length;
     if (n_terms) *n_terms = lx->n_live_terms;
     if (n_postings) *n_postings = lx->n_postings;
+    return RLR_OK;
+}
+
+int32_t rlr_lexical_segments(rlr_lexical *lx, uint64_t *main_postings, uint64_t *appended_postings, uint64_t *full_rebuilds,
+                             uint64_t *append_rebuilds)
+{
+    if (!lx)
+        return set_error(RLR_E_INVALID, "lexical handle is null");
+    std::shared_lock<std::shared_mutex> lk(lx->mu);
+    if (main_postings) *main_postings = lx->main_postings;
+    if (appended_postings) *appended_postings = lx->delta_postings;
+    if (full_rebuilds) *full_rebuilds = lx->n_full_commits;
+    if (append_rebuilds) *append_rebuilds = lx->n_delta_commits;
     return RLR_OK;
 }
 
@@ -676,11 +756,11 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     if (!rows_out || !scores_out)
         return set_error(RLR_E_INVALID, "rows_out / scores_out is null");
     LEX_HIP(hipSetDevice(lx->device));
-    while (lx->dirty) {
+    while (lx->full_dirty || lx->delta_dirty) {
         rd.unlock();
         {
             std::unique_lock<std::shared_mutex> wr(lx->mu);
-            if (lx->dirty)
+            if (lx->full_dirty || lx->delta_dirty)
                 LEX_TRY(commit(lx));
         }
         rd.lock();
@@ -730,11 +810,21 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
         const float df = static_cast<float>(lx->df[t]);
         float idf = std::log((n_docs - df + 0.5f) / (df + 0.5f)); // f32 ln (:2198-2200)
         idf = idf > 0.0f ? idf : 0.0f;                            // f32::max(0.0): NaN -> 0
-        const uint32_t cnt = lx->df[t];
-        const uint64_t off = lx->term_off[t];
-        const uint32_t blocks = std::min<uint32_t>((cnt + 255) / 256, max_blocks);
-        hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_post_row + off, lx->d_post_tf + off, cnt,
-                           lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
+        // the term's postings in the main segment, then in the appended one (a row is in exactly one of them)
+        const uint32_t cnt_m = t < lx->main_df.size() ? lx->main_df[t] : 0u;
+        if (cnt_m) {
+            const uint64_t off = lx->term_off[t];
+            const uint32_t blocks = std::min<uint32_t>((cnt_m + 255) / 256, max_blocks);
+            hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_post_row + off, lx->d_post_tf + off, cnt_m,
+                               lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
+        }
+        const uint32_t cnt_d = lx->dterm_off.empty() ? 0u : static_cast<uint32_t>(lx->dterm_off[t + 1] - lx->dterm_off[t]);
+        if (cnt_d) {
+            const uint64_t off = lx->dterm_off[t];
+            const uint32_t blocks = std::min<uint32_t>((cnt_d + 255) / 256, max_blocks);
+            hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_dpost_row + off, lx->d_dpost_tf + off,
+                               cnt_d, lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
+        }
     }
     LEX_HIP(hipGetLastError());
     uint32_t *d_out_n = reinterpret_cast<uint32_t *>(ws->d_out + kMaxLimit);

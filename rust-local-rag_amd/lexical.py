@@ -84,6 +84,12 @@ class LexicalIndex:
         N.check(self._L.rlr_lexical_info(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("total_docs", "total_length", "n_terms", "n_postings"), (x.value for x in v)))
 
+    def segments(self) -> dict:
+        """device posting segments: what the last commits rebuilt (appends rebuild only the appended segment)"""
+        v = [C.c_uint64() for _ in range(4)]
+        N.check(self._L.rlr_lexical_segments(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("main_postings", "appended_postings", "full_rebuilds", "append_rebuilds"), (x.value for x in v)))
+
     def score(self, query: str, limit: int) -> Tuple[np.ndarray, np.ndarray]:
         """LexicalIndex::score :2169-2225 -> (rows u64, scores f32), (score desc, row asc)"""
         return self.score_tokens(tokenize(query), limit)

@@ -41,3 +41,12 @@ def run(n_threads, per=200):
     print("%2d caller threads: %8.0f score calls/s" % (n_threads, n_threads * per / dt), flush=True)
 for nt in (1, 2, 4, 8, 16):
     run(nt)
+
+# ingest loop: one appended chunk, then a search (the commit rebuilds only the appended segment)
+ts = []
+for i in range(50):
+    g.add_tokens(n + i, vocab[rng.choice(V, size=30, p=zipf)])
+    t0 = time.perf_counter(); g.score_tokens(["t00100", "t00200"], 100); ts.append(time.perf_counter() - t0)
+print("search right after appending one chunk: median %.2f ms, max %.2f ms   segments %s" % (np.median(ts) * 1e3, max(ts) * 1e3, g.segments()), flush=True)
+g.add_tokens(5, vocab[rng.choice(V, size=30, p=zipf)])
+t0 = time.perf_counter(); g.score_tokens(["t00100", "t00200"], 100); print("search after replacing an old chunk (full rebuild): %.1f ms" % ((time.perf_counter() - t0) * 1e3))

@@ -213,3 +213,60 @@ def test_bm25_concurrent_score_calls_use_their_own_workspaces(rlr):
     assert any(not np.array_equal(want[k][0], want2[k][0]) for k in want)
     wave(want2)
     g.close()
+
+
+def test_bm25_appends_rebuild_only_the_appended_segment(rlr):
+    """An ingest loop that searches after every document: appended rows land in the second posting segment (no full
+    rebuild), answers stay bit-equal to the oracle while statistics (df, average length) move under both segments;
+    replacing an old row, removing rows, and an appended segment that outgrows main / 8 each force one full rebuild."""
+    texts = make_texts(6000, seed=21, lo=30, hi=60)             # ~200 k postings in the main segment
+    g, o = build_pair(rlr, texts)
+    queries = [("w000x w001x", 50), ("common frequent w010x", 200), ("w017x", 0), ("né Straße w399x", 20)]
+    for q, lim in queries:
+        check(g, o, q, lim)
+    seg = g.segments()
+    assert seg["full_rebuilds"] == 1 and seg["append_rebuilds"] == 0 and seg["appended_postings"] == 0
+    main = seg["main_postings"]
+    extra = make_texts(300, seed=22, lo=5, hi=30) + ["brandnewterm w000x", "brandnewterm brandnewterm zzzunique"]
+    n = len(texts)
+    for i, t in enumerate(extra):
+        g.add_chunk(n + i, t)
+        o.add_chunk(n + i, t, rank=n + i)
+        q, lim = queries[i % len(queries)]
+        check(g, o, q, lim)
+    check(g, o, "brandnewterm zzzunique", 10)                    # terms born after the main segment was built
+    seg = g.segments()
+    assert seg["full_rebuilds"] == 1 and seg["append_rebuilds"] == len(extra) and seg["main_postings"] == main
+    assert seg["appended_postings"] == g.info()["n_postings"] - main > 0
+    # replace a row of the appended segment: still no full rebuild
+    g.add_chunk(n + 3, "w000x w000x replaced")
+    o.add_chunk(n + 3, "w000x w000x replaced", rank=n + 3)
+    check(g, o, "w000x replaced", 100)
+    assert g.segments()["full_rebuilds"] == 1
+    # replace a row of the main segment: full rebuild, appended segment folded in
+    g.add_chunk(5, "w001x rewritten early row")
+    o.add_chunk(5, "w001x rewritten early row", rank=5)
+    check(g, o, "w001x rewritten", 100)
+    seg = g.segments()
+    assert seg["full_rebuilds"] == 2 and seg["appended_postings"] == 0 and seg["main_postings"] == g.info()["n_postings"]
+    # removal renumbers rows: full rebuild
+    g.remove_rows([0, 17, n + 1])
+    o2 = OL.LexicalIndex()
+    kept = [t for i, t in enumerate(texts + extra) if i not in (0, 17, n + 1)]
+    kept[5 - 1] = "w001x rewritten early row"                   # row 5 moved down by the removal of row 0
+    kept[n + 3 - 3] = "w000x w000x replaced"
+    for r, t in enumerate(kept):
+        o2.add_chunk(r, t, rank=r)
+    for q, lim in queries:
+        check(g, o2, q, lim)
+    assert g.segments()["full_rebuilds"] == 3
+    # an appended segment larger than max(65536, main / 8) postings is folded into the main one
+    big = make_texts(3000, seed=23, lo=30, hi=60)
+    for i, t in enumerate(big):
+        g.add_chunk(len(kept) + i, t)
+        o2.add_chunk(len(kept) + i, t, rank=len(kept) + i)
+    for q, lim in queries:
+        check(g, o2, q, lim)
+    seg = g.segments()
+    assert seg["full_rebuilds"] == 4 and seg["appended_postings"] == 0
+    g.close()
