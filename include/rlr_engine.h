@@ -15,6 +15,7 @@
 #define RLR_ENGINE_H
 
 #include "rlr_gpu.h"
+#include "rlr_lexical.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -82,6 +83,21 @@ int32_t rlr_engine_search_with_diversity(rlr_index *idx, const float *query_raw,
                                          const rlr_query_weights *weights, const uint64_t *lex_rows,
                                          const float *lex_scores, uint32_t n_lex,
                                          rlr_search_hit *out, uint32_t cap, uint32_t *n_out);
+
+/* search / search_with_diversity as the reference calls them from search_documents (mcp_server.rs:81-110): with the
+ * query TEXT, whose BM25 scores it blends in (`self.lexical_index.score(query, top_k.saturating_mul(5))`, :505).
+ * `query_tokens`: the host's tokenize(query), space separated (as for rlr_lexical_score); `lex`: the GPU LexicalIndex
+ * whose rows are the rows of `idx`.  diversity_factor == 0 (after the clamp): search(top_k) with `stage` as in
+ * rlr_engine_search; otherwise search_with_diversity (stage ignored).  Same results as rlr_lexical_score followed by
+ * rlr_engine_search / rlr_engine_search_with_diversity with its pairs -- but the BM25 kernels run on their own stream
+ * beside the cosine scan, their result never leaves the device, and blend, ordering, cut and MMR follow in the same
+ * enqueue: one host synchronisation per query (0.96 -> see DESIGN.md ms at 100 k chunks).  Falls back to exactly those
+ * two calls when the fused kernels do not cover the request (w_embedding == 0, more than 1024 candidates kept or
+ * 2048 lexical pairs, a rounding-tie chain at the fetch boundary). */
+int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *query_raw, uint32_t dq,
+                               const char *query_tokens, size_t tokens_len, uint32_t top_k, float diversity_factor,
+                               int32_t stage, const rlr_query_weights *weights, rlr_search_hit *out, uint32_t cap,
+                               uint32_t *n_out);
 
 /* Additive batched entry point (the reference has no batched API; its oracle is "loop
  * search_with_diversity over the batch"): n_queries raw query embeddings,

@@ -188,6 +188,28 @@ int32_t rlr_search_diverse(rlr_index *idx, const float *query, uint32_t pool, ui
                            float w_embedding, float w_lexical, float guard_eps, uint64_t *rows_out,
                            float *cos_out, float *score_out, uint32_t *n_out, int32_t *fallback);
 
+/* The same single enqueue for the HYBRID search the reference runs whenever the query has text (rag_engine.rs:505-561:
+ * `lexical_index.score(query, top_k * 5)`, then combined = w_e*cos + w_l*(lex / max_lex) over every chunk, order
+ * (combined desc, row asc), cut to `need`), optionally followed by mmr_diversify (:756) -- scan -> select -> re-score ->
+ * cosines of the lexical rows -> blend + order + cut -> [Gram -> greedy] -> results in pinned memory, one
+ * synchronisation.  Candidates are the need + n_lex + 8 best rows by cosine united with the lexical rows: a row
+ * without a lexical score is ordered by its cosine alone, so nothing else can reach the first `need`.
+ *   need         candidates the search keeps: min(top_k, 3*top_k) for a plain search (:544, :667-698), the pool
+ *                max(3*top_k, top_k+10) under diversification (:734); <= 1024
+ *   diversify    0: return the first `need` candidates in order (search); != 0: MMR-select k of them with `lambda`
+ *   lex_rows / lex_scores   the BM25 pairs as rows: ascending, unique, inside the index; n_lex <= 2048 and
+ *                need + 2*n_lex + 8 <= 4096
+ *   max_lex      max(lexical scores, f32::EPSILON) as the reference computes it (:515-519)
+ *   rows_out / cos_out / score_out / lex_out   `need` entries (diversify: min(max(k,1), need)): row, embedding_score,
+ *                combined score, normalised lexical score (0 for rows without one)
+ *   *fallback    != 0: nothing was written, take the host path (same conditions as rlr_search_diverse, or sizes
+ *                outside the limits above).
+ * Results are identical to the host path of csrc/engine.cpp (tests: test_engine_hybrid_*, fuzz_engine). */
+int32_t rlr_search_hybrid(rlr_index *idx, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
+                          float w_embedding, float w_lexical, const uint64_t *lex_rows, const float *lex_scores,
+                          uint32_t n_lex, float max_lex, float guard_eps, uint64_t *rows_out, float *cos_out,
+                          float *score_out, float *lex_out, uint32_t *n_out, int32_t *fallback);
+
 /* ---- device-resident variant (multi-GPU sharding) ------- */
 /* Same search, but the per-query result stays in device memory so the caller can hand it
  * to an RCCL all-gather without a host round trip.

@@ -100,6 +100,8 @@ PROTOTYPES = [
                                          u32p]),
     ("rlr_search_diverse", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float, u64p,
                                        f32p, f32p, u32p, i32p]),
+    ("rlr_search_hybrid", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_int32, C.c_float, C.c_float, u64p, f32p,
+                                      C.c_uint32, C.c_float, C.c_float, u64p, f32p, f32p, f32p, u32p, i32p]),
     ("rlr_json_load_corpus", C.c_int32, [C.c_char_p, C.c_uint32, C.POINTER(JsonCorpusC)]),
     ("rlr_json_free_corpus", None, [C.POINTER(JsonCorpusC)]),
     ("rlr_index_load_json", C.c_int32, [_H, C.c_char_p, C.c_int32, C.POINTER(JsonCorpusC)]),
@@ -125,6 +127,8 @@ PROTOTYPES = [
     ("rlr_engine_search_with_diversity", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float,
                                                      C.POINTER(QueryWeightsC), u64p, f32p, C.c_uint32,
                                                      C.POINTER(SearchHitC), C.c_uint32, u32p]),
+    ("rlr_engine_search_text", C.c_int32, [_H, _H, f32p, C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32, C.c_float, C.c_int32,
+                                           C.POINTER(QueryWeightsC), C.POINTER(SearchHitC), C.c_uint32, u32p]),
     ("rlr_engine_search_with_diversity_batch", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
                                                            C.POINTER(QueryWeightsC), C.POINTER(SearchHitC), C.c_uint32,
                                                            u32p]),

@@ -5,6 +5,8 @@
 // No dot product over corpus rows is ever computed on the host: cosines come from
 // rlr_search_topk / rlr_score_rows, MMR from rlr_mmr_select.
 #include "../../include/rlr_engine.h"
+#include "../../include/rlr_lexical.h"
+#include "lexical_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -89,6 +91,48 @@ std::vector<float> prepare_query(const float *query_raw, uint32_t dq, uint32_t d
     return q;
 }
 
+// The lexical map of search() (:505-506, a HashMap: a repeated chunk keeps its LAST score) as ascending unique rows,
+// and max_lexical (:515-519: over every pair, floored at f32::EPSILON).
+struct LexPrep {
+    std::vector<uint64_t> rows;
+    std::vector<float> scores;
+    float max_lex = 1.1920929e-07f;
+    // normalised lexical score of `row`, 0 when it has none (:527-530)
+    bool find(uint64_t row, float *l) const
+    {
+        const auto it = std::lower_bound(rows.begin(), rows.end(), row);
+        if (it == rows.end() || *it != row)
+            return false;
+        *l = scores[static_cast<size_t>(it - rows.begin())] / max_lex;
+        return true;
+    }
+};
+
+LexPrep prepare_lexical(uint64_t N, const uint64_t *lex_rows, const float *lex_scores, uint32_t n_lex)
+{
+    LexPrep p;
+    float max_lex = 0.0f;
+    std::vector<uint32_t> order;
+    order.reserve(n_lex);
+    for (uint32_t i = 0; i < n_lex; ++i) {
+        max_lex = std::fmax(max_lex, lex_scores[i]);
+        if (lex_rows[i] < N)
+            order.push_back(i);
+    }
+    if (max_lex >= 1.1920929e-07f)
+        p.max_lex = max_lex;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lex_rows[a] < lex_rows[b]; });
+    p.rows.reserve(order.size());
+    p.scores.reserve(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        if (i + 1 < order.size() && lex_rows[order[i + 1]] == lex_rows[order[i]])
+            continue; // a later pair for the same chunk overwrites this one
+        p.rows.push_back(lex_rows[order[i]]);
+        p.scores.push_back(lex_scores[order[i]]);
+    }
+    return p;
+}
+
 int32_t search_impl(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_t top_k,
                     const rlr_resolved_weights &w, const uint64_t *lex_rows, const float *lex_scores,
                     uint32_t n_lex, int32_t stage, std::vector<Cand> &result)
@@ -104,32 +148,40 @@ int32_t search_impl(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_
     if (top_k < 1) // :490
         top_k = 1;
     const std::vector<float> q = prepare_query(query_raw, dq, dim);
+    const LexPrep lex = prepare_lexical(N, lex_rows, lex_scores, n_lex);
+    const std::vector<uint64_t> &lrows = lex.rows;
 
-    // lexical map (:505-506) and max_lexical (:515-519)
-    std::unordered_map<uint64_t, float> lex;
-    float max_lex = 0.0f;
-    for (uint32_t i = 0; i < n_lex; ++i) {
-        max_lex = std::fmax(max_lex, lex_scores[i]);
-        if (lex_rows[i] < N)
-            lex[lex_rows[i]] = lex_scores[i];
+    const uint64_t want3 = static_cast<uint64_t>(top_k) * 3 > top_k ? static_cast<uint64_t>(top_k) * 3 : top_k;
+    const uint64_t initial_k = std::min<uint64_t>(N, want3);                              // :544
+    const uint64_t need = stage ? initial_k : std::min<uint64_t>(initial_k, top_k);       // :667-698
+
+    if (w.embedding > 0.0f && !lrows.empty() && need <= 1024) {
+        // lexical candidates: scan -> blend -> order -> cut in one enqueue on the device (rlr_search_hybrid); it hands
+        // the query back (fallback) when its fetch cannot decide the order or the sizes exceed its kernels
+        const uint32_t nd = static_cast<uint32_t>(need);
+        std::vector<uint64_t> rows(nd);
+        std::vector<float> cosv(nd), sc(nd), lx(nd);
+        uint32_t got = 0;
+        int32_t fb = 0;
+        st = rlr_search_hybrid(idx, q.data(), nd, 0, 0.0f, 0, w.embedding, w.lexical, lrows.data(), lex.scores.data(),
+                               static_cast<uint32_t>(lrows.size()), lex.max_lex, -1.0f, rows.data(), cosv.data(), sc.data(),
+                               lx.data(), &got, &fb);
+        if (st != RLR_OK)
+            return st;
+        if (!fb) {
+            result.resize(got);
+            for (uint32_t i = 0; i < got; ++i)
+                result[i] = {rows[i], sc[i], cosv[i], lx[i]};
+            return RLR_OK;
+        }
     }
-    if (!(max_lex >= 1.1920929e-07f))
-        max_lex = 1.1920929e-07f;
-    std::vector<uint64_t> lrows;
-    lrows.reserve(lex.size());
-    for (const auto &kv : lex)
-        lrows.push_back(kv.first);
-    std::sort(lrows.begin(), lrows.end());
+
     std::vector<float> lcos(lrows.size());
     if (!lrows.empty()) {
         st = rlr_score_rows(idx, q.data(), lrows.data(), static_cast<uint32_t>(lrows.size()), lcos.data());
         if (st != RLR_OK)
             return st;
     }
-
-    const uint64_t want3 = static_cast<uint64_t>(top_k) * 3 > top_k ? static_cast<uint64_t>(top_k) * 3 : top_k;
-    const uint64_t initial_k = std::min<uint64_t>(N, want3);                              // :544
-    const uint64_t need = stage ? initial_k : std::min<uint64_t>(initial_k, top_k);       // :667-698
 
     std::vector<Cand> cands;
     if (w.embedding == 0.0f) {
@@ -144,13 +196,13 @@ int32_t search_impl(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_
         if (st != RLR_OK)
             return st;
         for (uint64_t r = 0; r < take; ++r) {
-            auto it = lex.find(r);
-            const float l = it == lex.end() ? 0.0f : it->second / max_lex;
+            float l = 0.0f;
+            (void)lex.find(r, &l);
             cands.push_back({r, combine(w, cosv[r], l), cosv[r], l});
         }
         for (size_t i = 0; i < lrows.size(); ++i)
             if (lrows[i] >= take) {
-                const float l = lex[lrows[i]] / max_lex;
+                const float l = lex.scores[i] / lex.max_lex;
                 cands.push_back({lrows[i], combine(w, lcos[i], l), lcos[i], l});
             }
         std::sort(cands.begin(), cands.end(), cand_before);
@@ -162,6 +214,7 @@ int32_t search_impl(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_
         uint64_t fetch = std::min<uint64_t>(N, need + lrows.size() + 8);
         std::vector<uint64_t> rows;
         std::vector<float> cosv;
+        std::vector<char> seen(lrows.size());
         for (;;) {
             rows.assign(fetch, 0);
             cosv.assign(fetch, 0.0f);
@@ -170,17 +223,20 @@ int32_t search_impl(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_
             if (st != RLR_OK)
                 return st;
             cands.clear();
-            std::unordered_map<uint64_t, char> seen;
-            seen.reserve(got * 2);
+            std::fill(seen.begin(), seen.end(), 0);
             for (uint32_t i = 0; i < got; ++i) {
-                auto it = lex.find(rows[i]);
-                const float l = it == lex.end() ? 0.0f : it->second / max_lex;
+                float l = 0.0f;
+                const auto it = std::lower_bound(lrows.begin(), lrows.end(), rows[i]);
+                if (it != lrows.end() && *it == rows[i]) {
+                    const size_t j = static_cast<size_t>(it - lrows.begin());
+                    l = lex.scores[j] / lex.max_lex;
+                    seen[j] = 1;
+                }
                 cands.push_back({rows[i], combine(w, cosv[i], l), cosv[i], l});
-                seen[rows[i]] = 1;
             }
             for (size_t i = 0; i < lrows.size(); ++i)
-                if (!seen.count(lrows[i])) {
-                    const float l = lex[lrows[i]] / max_lex;
+                if (!seen[i]) {
+                    const float l = lex.scores[i] / lex.max_lex;
                     cands.push_back({lrows[i], combine(w, lcos[i], l), lcos[i], l});
                 }
             std::sort(cands.begin(), cands.end(), cand_before);
@@ -317,6 +373,40 @@ int32_t rlr_engine_search_with_diversity(rlr_index *idx, const float *query_raw,
             return RLR_OK;
         }
     }
+    if (n_lex > 0 && w.embedding > 0.0f && pool_size <= 1024) {
+        // lexical candidates (the usual case: search() scores the query text, :505): the blended pool and the MMR picks
+        // come from one enqueue as well (rlr_search_hybrid, diversify = 1)
+        uint64_t N = 0;
+        uint32_t dim = 0;
+        int32_t st0 = rlr_index_info(idx, &N, &dim, nullptr, nullptr);
+        if (st0 != RLR_OK)
+            return st0;
+        if (N == 0)
+            return RLR_OK;
+        const LexPrep lex = prepare_lexical(N, lex_rows, lex_scores, n_lex);
+        if (!lex.rows.empty()) {
+            const std::vector<float> q = prepare_query(query_raw, dq, dim);
+            const uint32_t kk = static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(top_k, 1u), pool_size));
+            std::vector<uint64_t> rows(kk);
+            std::vector<float> cosv(kk), sc(kk), lx(kk);
+            uint32_t n_sel = 0;
+            int32_t fb = 0;
+            st0 = rlr_search_hybrid(idx, q.data(), pool_size, top_k, diversity_factor, 1, w.embedding, w.lexical, lex.rows.data(),
+                                    lex.scores.data(), static_cast<uint32_t>(lex.rows.size()), lex.max_lex, -1.0f, rows.data(),
+                                    cosv.data(), sc.data(), lx.data(), &n_sel, &fb);
+            if (st0 != RLR_OK)
+                return st0;
+            if (!fb) {
+                if (n_sel && !out)
+                    return RLR_E_INVALID;
+                std::vector<Cand> picked(n_sel);
+                for (uint32_t i = 0; i < n_sel; ++i)
+                    picked[i] = {rows[i], sc[i], cosv[i], lx[i]};
+                emit(picked, out, cap, n_out);
+                return RLR_OK;
+            }
+        }
+    }
     int32_t st = search_impl(idx, query_raw, dq, pool_size, w, lex_rows, lex_scores, n_lex, 0, pool); // :735
     if (st != RLR_OK)
         return st;
@@ -342,6 +432,81 @@ int32_t rlr_engine_search_with_diversity(rlr_index *idx, const float *query_raw,
         return RLR_E_INVALID;
     emit(picked, out, cap, n_out);
     return RLR_OK;
+}
+
+int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *query_raw, uint32_t dq, const char *query_tokens,
+                               size_t tokens_len, uint32_t top_k, float diversity_factor, int32_t stage,
+                               const rlr_query_weights *weights, rlr_search_hit *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!idx || !lex || !n_out || (!query_raw && dq) || (tokens_len && !query_tokens))
+        return RLR_E_INVALID;
+    *n_out = 0;
+    if (diversity_factor < 0.0f) diversity_factor = 0.0f; // f32::clamp(0.0, 1.0) (:725); NaN takes the MMR branch
+    if (diversity_factor > 1.0f) diversity_factor = 1.0f;
+    const bool diversify = !(diversity_factor == 0.0f);
+    rlr_resolved_weights w;
+    rlr_resolve_weights(weights, &w);
+    const uint64_t p3 = static_cast<uint64_t>(top_k) * 3, p10 = static_cast<uint64_t>(top_k) + 10;
+    const uint32_t pool_size = static_cast<uint32_t>(std::min<uint64_t>(std::max(p3, p10), 0xFFFFFFFFull)); // :734
+    const uint32_t k_seen = std::max<uint32_t>(diversify ? pool_size : top_k, 1u); // the top_k `search` works with (:490)
+    const uint32_t limit = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(k_seen) * 5, 0xFFFFFFFFull)); // :505
+
+    // BM25 on its own stream; nothing below waits for it on the host unless the fused path is not taken
+    rlr::LexPending lp;
+    int32_t st = rlr::lexical_enqueue(lex, query_tokens, tokens_len, limit, &lp);
+    if (st != RLR_OK)
+        return st;
+    if (lp.limit == 0) { // no lexical candidate at all: the embedding-only paths
+        rlr::lexical_finish(&lp, true);
+        return diversify ? rlr_engine_search_with_diversity(idx, query_raw, dq, top_k, diversity_factor, weights, nullptr, nullptr, 0,
+                                                             out, cap, n_out)
+                         : rlr_engine_search(idx, query_raw, dq, top_k, weights, nullptr, nullptr, 0, stage, out, cap, n_out);
+    }
+    uint64_t N = 0;
+    uint32_t dim = 0;
+    st = rlr_index_info(idx, &N, &dim, nullptr, nullptr);
+    if (st != RLR_OK || N == 0) { // :476-478
+        rlr::lexical_finish(&lp, st == RLR_OK);
+        return st;
+    }
+    const uint64_t want3 = static_cast<uint64_t>(k_seen) * 3;
+    const uint64_t initial_k = std::min<uint64_t>(N, want3);                                            // :544
+    const uint64_t need = (diversify || !stage) ? std::min<uint64_t>(initial_k, k_seen) : initial_k;    // :667-698
+    if (w.embedding > 0.0f && need <= 1024) {
+        const std::vector<float> q = prepare_query(query_raw, dq, dim);
+        const uint32_t nd = static_cast<uint32_t>(need);
+        const uint32_t n_res = diversify ? static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(top_k, 1u), nd)) : nd;
+        std::vector<uint64_t> rows(n_res);
+        std::vector<float> cosv(n_res), sc(n_res), lx(n_res);
+        uint32_t got = 0;
+        int32_t fb = 0;
+        st = rlr::search_hybrid_device(idx, q.data(), nd, top_k, diversity_factor, diversify ? 1 : 0, w.embedding, w.lexical, &lp,
+                                       -1.0f, rows.data(), cosv.data(), sc.data(), lx.data(), &got, &fb);
+        if (st != RLR_OK || !fb) {
+            rlr::lexical_finish(&lp, st == RLR_OK);
+            if (st != RLR_OK)
+                return st;
+            if (got && !out)
+                return RLR_E_INVALID;
+            std::vector<Cand> res(got);
+            for (uint32_t i = 0; i < got; ++i)
+                res[i] = {rows[i], sc[i], cosv[i], lx[i]};
+            emit(res, out, cap, n_out);
+            return RLR_OK;
+        }
+    }
+    // the pairs on the host, then the entry points that take them
+    std::vector<uint64_t> lrows(lp.limit);
+    std::vector<float> lscores(lp.limit);
+    uint32_t n_lex = 0;
+    st = rlr::lexical_fetch(&lp, lrows.data(), lscores.data(), &n_lex);
+    rlr::lexical_finish(&lp, st == RLR_OK);
+    if (st != RLR_OK)
+        return st;
+    return diversify ? rlr_engine_search_with_diversity(idx, query_raw, dq, top_k, diversity_factor, weights, lrows.data(),
+                                                         lscores.data(), n_lex, out, cap, n_out)
+                     : rlr_engine_search(idx, query_raw, dq, top_k, weights, lrows.data(), lscores.data(), n_lex, stage, out, cap,
+                                         n_out);
 }
 
 int32_t rlr_engine_search_with_diversity_batch(rlr_index *idx, const float *queries_raw, uint32_t dq, uint32_t n_queries,

@@ -236,14 +236,52 @@ template <bool F16>
 __global__ __launch_bounds__(64) void score_rows_kernel(const float4 *__restrict__ rows, uint32_t pitch16,
                                                         uint32_t dim, const float *__restrict__ query,
                                                         const uint32_t *__restrict__ list, uint32_t n,
-                                                        float *__restrict__ out)
+                                                        float *__restrict__ out, const uint32_t *__restrict__ n_dev,
+                                                        uint32_t n_rows_clamp)
 {
     extern __shared__ __attribute__((aligned(16))) float s_q[];
     stage_query(s_q, query, dim);
+    if (n_dev)
+        n = min(n, *n_dev);
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n)
         return;
-    out[i] = dot_ref_row<F16>(rows + static_cast<size_t>(list[i]) * pitch16, s_q, dim);
+    const uint32_t r = list[i] < n_rows_clamp ? list[i] : 0u;
+    out[i] = dot_ref_row<F16>(rows + static_cast<size_t>(r) * pitch16, s_q, dim);
+}
+
+// The same scores with the rows staged through LDS (coalesced loads, products in parallel, then one reference-order
+// chain per row): 8 rows per workgroup instead of 64 sequential lanes in one wave -- 1500 lexical rows of a hybrid
+// search spread over 188 workgroups instead of 24 (24.5 -> see DESIGN.md us at 768-d).
+template <bool F16>
+__global__ __launch_bounds__(256) void score_rows_staged_kernel(const float4 *__restrict__ rows, uint32_t pitch16, uint32_t dim,
+                                                               const float *__restrict__ query,
+                                                               const uint32_t *__restrict__ list, uint32_t n,
+                                                               float *__restrict__ out, uint32_t cpb,
+                                                               const uint32_t *__restrict__ n_dev, uint32_t n_rows_clamp)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const uint32_t q_floats = (dim + 7) & ~7u;
+    float *s_q = s_mem;
+    float *s_p = s_mem + q_floats;
+    __shared__ uint32_t s_cand[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * cpb;
+    if (n_dev)
+        n = min(n, *n_dev);
+    if (base >= n)
+        return;
+    const uint32_t cnt = min(cpb, n - base);
+    for (uint32_t i = tid; i < q_floats; i += 256)
+        s_q[i] = i < dim ? query[i] : 0.0f;
+    if (tid < cnt) {
+        const uint32_t r = list[base + tid];
+        s_cand[tid] = r < n_rows_clamp ? r : 0u;
+    }
+    __syncthreads();
+    const float sc = staged_reference_dot<F16>(rows, pitch16, dim, s_q, s_p, s_cand, cnt, tid);
+    if (tid < cnt)
+        out[base + tid] = sc;
 }
 
 // ---- normalize ---------------------------------------------------------------------
@@ -927,19 +965,38 @@ bool launch_batch_rescore(const void *rows, uint32_t pitch16, uint32_t dim, int 
 }
 
 hipError_t launch_score_rows(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *query,
-                             const uint32_t *list, uint32_t n, float *cos_out, hipStream_t s)
+                             const uint32_t *list, uint32_t n, float *cos_out, hipStream_t s, const uint32_t *n_dev,
+                             uint32_t n_rows_clamp)
 {
     if (n == 0)
         return hipSuccess;
+    const float4 *r4 = static_cast<const float4 *>(rows);
+    // staged form when it fits LDS (the conditions of launch_rescore_staged)
+    const size_t q_bytes = static_cast<size_t>((dim + 7) & ~7u) * sizeof(float);
+    const size_t row_bytes = q_bytes + 16;
+    uint32_t cpb = 8;
+    while (cpb > 1 && q_bytes + cpb * row_bytes > 60 * 1024)
+        cpb >>= 1;
+    const bool fits = q_bytes + cpb * row_bytes <= 60 * 1024 && pitch16 * (dtype == RLR_F16 ? 8u : 4u) >= ((dim + 7) & ~7u);
+    if (fits && n > 64) {
+        const uint32_t blocks = (n + cpb - 1) / cpb;
+        const size_t lds = q_bytes + cpb * row_bytes;
+        if (dtype == RLR_F16)
+            hipLaunchKernelGGL(score_rows_staged_kernel<true>, dim3(blocks), dim3(256), lds, s, r4, pitch16, dim, query, list, n,
+                               cos_out, cpb, n_dev, n_rows_clamp);
+        else
+            hipLaunchKernelGGL(score_rows_staged_kernel<false>, dim3(blocks), dim3(256), lds, s, r4, pitch16, dim, query, list, n,
+                               cos_out, cpb, n_dev, n_rows_clamp);
+        return hipGetLastError();
+    }
     const uint32_t blocks = (n + 63) / 64;
     const size_t lds = static_cast<size_t>(dim) * sizeof(float);
-    const float4 *r4 = static_cast<const float4 *>(rows);
     if (dtype == RLR_F16)
         hipLaunchKernelGGL(score_rows_kernel<true>, dim3(blocks), dim3(64), lds, s, r4, pitch16, dim, query, list, n,
-                           cos_out);
+                           cos_out, n_dev, n_rows_clamp);
     else
         hipLaunchKernelGGL(score_rows_kernel<false>, dim3(blocks), dim3(64), lds, s, r4, pitch16, dim, query, list, n,
-                           cos_out);
+                           cos_out, n_dev, n_rows_clamp);
     return hipGetLastError();
 }
 

@@ -26,6 +26,7 @@
 #include "common.h"
 #include "exact_dot.h"
 #include "kernels.h"
+#include "lds_select.h"
 #include "../../include/rlr_gpu.h"
 
 #include <cstdlib>
@@ -1006,63 +1007,6 @@ __global__ __launch_bounds__(256) void batch_finish_kernel(const float4 *__restr
 //   batch_band_kernel   order the nominated candidates, cut the guard band, leave it in cand[q][0..band)
 //   batch_rescore_kernel (exact.hip)  reference-order scores, in place
 //   batch_emit_kernel   order the band by the exact scores, emit k
-// k-th largest 32-bit key among the packed candidates s_c[0, n) (key = high word), by three radix passes over LDS
-// (11 + 11 + 10 bits; histogram by LDS atomics, the bin search by one wavefront).  All threads must call it; the result
-// is returned to every thread.  Replaces a full bitonic sort of the list (91 barrier-separated stages at 8192 entries:
-// 179 us per batch of 256 queries) where only the k-th score and the set above a threshold are needed.
-__device__ inline uint32_t lds_kth_key(const uint64_t *s_c, uint32_t n, uint32_t k, uint32_t *s_hist, uint32_t *s_sel,
-                                       uint32_t nthreads)
-{
-    uint32_t prefix = 0, mask = 0, rank = k; // rank: 1-based position, counted from the largest, inside the current bin
-#pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {
-        const uint32_t shift = pass == 0 ? 21u : pass == 1 ? 10u : 0u;
-        const uint32_t nb = pass == 2 ? 1024u : 2048u;
-        for (uint32_t i = threadIdx.x; i < nb; i += nthreads)
-            s_hist[i] = 0;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += nthreads) {
-            const uint32_t key = static_cast<uint32_t>(s_c[i] >> 32);
-            if ((key & mask) == prefix)
-                atomicAdd(&s_hist[(key >> shift) & (nb - 1)], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            // lane l owns bins [l * W, (l + 1) * W); suffix sums over the lanes from the top, then inside the lane
-            const uint32_t W = nb / 64, lane = threadIdx.x;
-            uint32_t mine = 0;
-            for (uint32_t b = 0; b < W; ++b)
-                mine += s_hist[lane * W + b];
-            uint32_t incl = mine; // sum over lanes >= lane
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_down(incl, d);
-                if (lane + d < 64)
-                    incl += o;
-            }
-            const uint32_t above = incl - mine; // keys in bins of higher lanes
-            if (above < rank && rank <= incl) {
-                uint32_t acc = above;
-                for (int b = static_cast<int>(W) - 1; b >= 0; --b) {
-                    const uint32_t h = s_hist[lane * W + b];
-                    if (rank <= acc + h) {
-                        s_sel[0] = lane * W + b;
-                        s_sel[1] = rank - acc;
-                        break;
-                    }
-                    acc += h;
-                }
-            }
-        }
-        __syncthreads();
-        prefix |= s_sel[0] << shift;
-        mask |= (nb - 1) << shift;
-        rank = s_sel[1];
-        __syncthreads();
-    }
-    return prefix;
-}
-
 __global__ __launch_bounds__(1024) void batch_band_kernel(uint64_t *__restrict__ cand, uint32_t cand_stride,
                                                           SelectState *__restrict__ st, uint32_t k, float two_eps,
                                                           uint32_t *__restrict__ status)

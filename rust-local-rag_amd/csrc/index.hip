@@ -6,6 +6,8 @@
 #include "../../include/rlr_gpu.h"
 #include "common.h"
 #include "kernels.h"
+#include "lds_select.h"
+#include "lexical_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -780,6 +782,232 @@ __global__ __launch_bounds__(256) void diverse_emit_kernel(const uint32_t *__res
     if (threadIdx.x == 0) {
         h_out[3 * k_cap] = n;
         h_out[3 * k_cap + 1] = info[1];
+    }
+}
+
+// ---- hybrid search without host round trips (rlr_search_hybrid) -------------------------------------------
+// The device twin of search_impl's candidate list when lexical (BM25) candidates exist (csrc/engine.cpp;
+// rag_engine.rs:505-561): candidates = the `fetch` best rows by cosine UNITED with the lexical rows,
+// combined = w_e * cos + w_l * (lex / max_lex) (two rounded products, one add; IEEE division), ordered
+// (combined desc, NaN last, row asc), cut to `need`.  Slots [0, fetch) hold the fetched rows, [fetch, fetch + n_lex)
+// the lexical rows that were not fetched; one bitonic sort in LDS orders them.  The same boundary rule as the host:
+// every unfetched row is non-lexical and scores at most combine(cos of the last fetched row, 0); if the need-th
+// candidate does not beat that, info[1] = 2 and the host takes the widening path.
+constexpr uint32_t kHybridSlots = 4096, kHybridLexMax = 2048, kHybridSelMax = 2048, kHybridHash = 4096;
+
+// What the blend needs to know about the lexical pairs, in device memory: written by the host copy (pairs handed in by
+// the caller) or by lex_unpack_kernel (pairs left on the device by a BM25 scoring call).
+struct HybridLexHeader {
+    uint32_t n_lex;
+    float max_lex; // max(lexical scores, f32::EPSILON) (rag_engine.rs:515-519)
+};
+
+// A scoring call's result list (pack_result(score, row), score desc) -> rows, scores, header.  Rows outside the index
+// (a lexical index that ran ahead of the embedding matrix) keep their place but are marked: they still count for
+// max_lexical, as in the reference, and never become candidates.
+__global__ __launch_bounds__(256) void lex_unpack_kernel(const uint64_t *__restrict__ packed, const uint32_t *__restrict__ count,
+                                                         uint32_t limit, uint32_t n_rows, uint32_t *__restrict__ lrow,
+                                                         float *__restrict__ lscore, HybridLexHeader *__restrict__ hdr)
+{
+    const uint32_t n = min(*count, limit);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float sc;
+        uint32_t row;
+        unpack_result(packed[i], &sc, &row);
+        lrow[i] = row < n_rows ? row : 0xFFFFFFFFu;
+        lscore[i] = sc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr->n_lex = n;
+        float mx = 0.0f; // fold(0.0, f32::max) over a list that is sorted descending: its first entry
+        if (n) {
+            float sc;
+            uint32_t row;
+            unpack_result(packed[0], &sc, &row);
+            mx = fmaxf(mx, sc);
+        }
+        hdr->max_lex = mx >= 1.1920929e-07f ? mx : 1.1920929e-07f;
+    }
+}
+
+__global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__restrict__ packed, uint32_t fetch, uint32_t need,
+                                                           uint32_t n_rows, float w_e, float w_l,
+                                                           const uint32_t *__restrict__ lrow, const float *__restrict__ lscore,
+                                                           const float *__restrict__ lcos,
+                                                           const HybridLexHeader *__restrict__ hdr,
+                                                           float *__restrict__ cand, // 3 x kHybridSlots: combined | cos | lex
+                                                           uint32_t *__restrict__ list, float *__restrict__ comb,
+                                                           float *__restrict__ cosv, float *__restrict__ lexv,
+                                                           uint32_t *__restrict__ info)
+{
+    __shared__ uint64_t s_key[kHybridSlots];   // slot -> (ordered combined score, ~row); 0 = empty
+    __shared__ uint64_t s_sel[kHybridSelMax];  // the keys that can be among the first `need`
+    __shared__ uint32_t s_slot[kHybridSelMax]; // ... and their slots
+    __shared__ uint32_t s_hrow[kHybridHash];   // open-addressing map lexical row + 1 -> its index in the pair list
+    __shared__ uint32_t s_hidx[kHybridHash];
+    __shared__ uint32_t s_flag[kHybridLexMax]; // lexical pair j was reached by the fetch
+    __shared__ uint32_t s_hist[2048];
+    __shared__ uint32_t s_pick[2];
+    __shared__ uint32_t s_got, s_cand, s_nsel;
+    __shared__ float s_cneed;
+    const uint32_t t = threadIdx.x;
+    float *cc = cand, *ce = cand + kHybridSlots, *cl = cand + 2 * kHybridSlots;
+    const uint32_t n_lex = min(hdr->n_lex, kHybridLexMax);
+    const float max_lex = hdr->max_lex;
+    if (t == 0) {
+        s_got = 0;
+        s_cand = 0;
+        s_nsel = 0;
+        s_cneed = 0.0f;
+    }
+    for (uint32_t i = t; i < kHybridHash; i += 1024)
+        s_hrow[i] = 0;
+    for (uint32_t j = t; j < n_lex; j += 1024)
+        s_flag[j] = 0;
+    __syncthreads();
+    for (uint32_t j = t; j < n_lex; j += 1024) {
+        const uint32_t row = lrow[j];
+        if (row == 0xFFFFFFFFu)
+            continue;
+        uint32_t h = (row * 2654435761u) >> 20; // 12 bits
+        for (;;) {
+            const uint32_t old = atomicCAS(&s_hrow[h], 0u, row + 1);
+            if (old == 0u) {
+                s_hidx[h] = j;
+                break;
+            }
+            h = (h + 1) & (kHybridHash - 1); // rows are unique: never the same key twice
+        }
+    }
+    __syncthreads();
+    const bool overflow = packed[0] == ~0ull;
+    const uint32_t total = fetch + n_lex;
+    for (uint32_t i = t; i < fetch; i += 1024) {
+        const uint64_t p = overflow ? 0ull : packed[i];
+        uint64_t key = 0;
+        if (p != 0) { // valid entries are a prefix: (cosine desc, row asc), padding zeros behind
+            const uint32_t row = 0xFFFFFFFFu - static_cast<uint32_t>(p & 0xFFFFFFFFull);
+            const float e = key_score(static_cast<uint32_t>(p >> 32));
+            float l = 0.0f;
+            uint32_t h = (row * 2654435761u) >> 20;
+            for (;;) {
+                const uint32_t hr = s_hrow[h];
+                if (hr == 0u)
+                    break;
+                if (hr == row + 1) {
+                    const uint32_t j = s_hidx[h];
+                    l = lscore[j] / max_lex;
+                    s_flag[j] = 1;
+                    break;
+                }
+                h = (h + 1) & (kHybridHash - 1);
+            }
+            const float t0 = w_e * e;
+            const float t1 = w_l * l;
+            const float c = t0 + t1;
+            cc[i] = c;
+            ce[i] = e;
+            cl[i] = l;
+            key = (static_cast<uint64_t>(score_key(c == 0.0f ? 0.0f : c)) << 32) | (p & 0xFFFFFFFFull); // -0 ties with +0
+            atomicAdd(&s_got, 1u);
+        }
+        s_key[i] = key;
+    }
+    __syncthreads();
+    for (uint32_t j = t; j < n_lex; j += 1024) {
+        uint64_t key = 0;
+        const uint32_t slot = fetch + j;
+        const uint32_t row = lrow[j];
+        if (row != 0xFFFFFFFFu && !s_flag[j]) { // a lexical row the fetch did not reach
+            const float e = lcos[j];
+            const float l = lscore[j] / max_lex;
+            const float t0 = w_e * e;
+            const float t1 = w_l * l;
+            const float c = t0 + t1;
+            cc[slot] = c;
+            ce[slot] = e;
+            cl[slot] = l;
+            key = (static_cast<uint64_t>(score_key(c == 0.0f ? 0.0f : c)) << 32) | (0xFFFFFFFFu - row);
+            atomicAdd(&s_cand, 1u);
+        }
+        s_key[slot] = key;
+    }
+    __syncthreads();
+    const uint32_t got = s_got, n_cand = got + s_cand, n_pool = min(n_cand, need);
+    // the need-th largest 32-bit score, then everything at or above it (ties included) is ranked by the full key
+    uint32_t key_lo = 0;
+    if (n_cand > need)
+        key_lo = lds_kth_key(s_key, total, need, s_hist, s_pick, 1024);
+    for (uint32_t i = t; i < total; i += 1024) {
+        const uint64_t v = s_key[i];
+        if (v != 0 && static_cast<uint32_t>(v >> 32) >= key_lo) {
+            const uint32_t at = atomicAdd(&s_nsel, 1u);
+            if (at < kHybridSelMax) {
+                s_sel[at] = v;
+                s_slot[at] = i;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_sel = s_nsel;
+    const bool flood = n_sel > kHybridSelMax; // thousands of candidates share the need-th score: the host path sorts them
+    if (!flood)
+        for (uint32_t i = t; i < n_sel; i += 1024) {
+            const uint64_t mine = s_sel[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n_sel; ++j) // keys are unique (the row is part of the key)
+                rank += s_sel[j] > mine;
+            if (rank < n_pool) {
+                const uint32_t slot = s_slot[i];
+                list[rank] = 0xFFFFFFFFu - static_cast<uint32_t>(mine & 0xFFFFFFFFull);
+                comb[rank] = cc[slot];
+                cosv[rank] = ce[slot];
+                lexv[rank] = cl[slot];
+                if (rank == need - 1)
+                    s_cneed = cc[slot];
+            }
+        }
+    for (uint32_t r = n_pool + t; r < need; r += 1024) { // unused slots: a valid row, never read by the greedy kernel
+        list[r] = 0;
+        comb[r] = 0.0f;
+        cosv[r] = 0.0f;
+        lexv[r] = 0.0f;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t status = overflow ? 1u : flood ? 2u : 0u;
+        if (!status && got < n_rows && got > 0) {
+            const float t0 = w_e * ce[got - 1]; // the smallest fetched cosine bounds every unfetched (non-lexical) row
+            const float t1 = w_l * 0.0f;
+            const float c_tail = t0 + t1;
+            const bool ok = n_cand >= need && (c_tail != c_tail || s_cneed > c_tail);
+            if (!ok)
+                status = 2u;
+        }
+        info[0] = status ? 0u : n_pool;
+        info[1] = status;
+    }
+}
+
+// results -> pinned host memory: [row u32 | cos f32 | combined f32 | lexical f32] x k_cap, then n, status.
+// order == null: the candidates in their sorted order (no diversification).
+__global__ __launch_bounds__(256) void hybrid_emit_kernel(const uint32_t *__restrict__ list, const float *__restrict__ comb,
+                                                          const float *__restrict__ cosv, const float *__restrict__ lexv,
+                                                          const uint32_t *__restrict__ order, const uint32_t *__restrict__ n_sel,
+                                                          const uint32_t *__restrict__ info, uint32_t k_cap,
+                                                          uint32_t *__restrict__ h_out)
+{
+    const uint32_t n = info[1] ? 0u : min(order ? *n_sel : info[0], k_cap);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t o = order ? order[i] : i;
+        h_out[i] = list[o];
+        h_out[k_cap + i] = __builtin_bit_cast(uint32_t, cosv[o]);
+        h_out[2 * k_cap + i] = __builtin_bit_cast(uint32_t, comb[o]);
+        h_out[3 * k_cap + i] = __builtin_bit_cast(uint32_t, lexv[o]);
+    }
+    if (threadIdx.x == 0) {
+        h_out[4 * k_cap] = n;
+        h_out[4 * k_cap + 1] = info[1];
     }
 }
 } // namespace rlr
@@ -2053,6 +2281,175 @@ int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uin
     return RLR_OK;
 }
 
+// where the lexical pairs of a hybrid search come from
+struct HybridLexSrc {
+    const uint64_t *h_rows = nullptr; // host pairs: ascending unique rows inside the index ...
+    const float *h_scores = nullptr;
+    uint32_t n_host = 0;
+    float max_lex = 0.0f;
+    const rlr::LexPending *dev = nullptr; // ... or a BM25 call's result still on the device
+};
+
+static int32_t search_hybrid_impl(rlr_index *ix, const float *query, uint32_t need_in, uint32_t k, float lambda, int32_t diversify,
+                                  float w_embedding, float w_lexical, const HybridLexSrc &src, float guard_eps,
+                                  uint64_t *rows_out, float *cos_out, float *score_out, float *lex_out, uint32_t *n_out,
+                                  int32_t *fallback)
+{
+    RLR_TRY(check_handle(ix));
+    if (!n_out || !fallback)
+        return fail(RLR_E_INVALID, "n_out / fallback is null");
+    *n_out = 0;
+    *fallback = 0;
+    if (ix->n_rows == 0 || need_in == 0)
+        return RLR_OK;
+    const uint32_t n_lex = src.dev ? src.dev->limit : src.n_host; // (an upper bound when the pairs are on the device)
+    if (!query || !rows_out || !cos_out || !score_out || !lex_out || (!src.dev && n_lex && (!src.h_rows || !src.h_scores)))
+        return fail(RLR_E_INVALID, "null argument");
+    const uint32_t n = static_cast<uint32_t>(ix->n_rows);
+    const uint32_t need = std::min<uint32_t>(n, need_in);
+    const uint64_t fetch64 = std::min<uint64_t>(n, static_cast<uint64_t>(need) + n_lex + 8);
+    if (need > rlr::kPoolMax || n_lex > rlr::kHybridLexMax || fetch64 + n_lex > rlr::kHybridSlots || !(w_embedding > 0.0f) ||
+        !std::isfinite(w_embedding) || !std::isfinite(w_lexical)) {
+        *fallback = 1; // outside what the fused kernels cover: the caller's host path handles it
+        return RLR_OK;
+    }
+    if (!src.dev)
+        for (uint32_t i = 0; i < n_lex; ++i)
+            if (src.h_rows[i] >= n || (i && src.h_rows[i] <= src.h_rows[i - 1]))
+                return fail(RLR_E_INVALID, "lex_rows must be ascending, unique and inside the index");
+    const uint32_t fetch = static_cast<uint32_t>(fetch64);
+    RLR_TRY(use_device(ix));
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    hipStream_t s = c->stream;
+    SearchPlan p;
+    p.k = fetch;
+    p.scale = band_scale(ix, query, 1);
+    const float eps = (guard_eps >= 0.0f ? guard_eps : rlr_default_guard_eps(ix->dim)) * p.scale;
+    p.two_eps = 2.0f * eps;
+    p.two_eps_img = image_two_eps(ix, eps);
+    p.cap = kLdsSortCap;
+    RLR_TRY(ctx_prepare(ix, c, 1, p));
+    const uint32_t P = need;
+    const uint32_t k_cap = diversify ? std::max<uint32_t>(std::min<uint32_t>(std::max<uint32_t>(k, 1u), P), 1u) : P;
+    // workspace (4-byte words): gram P x P | combined P | cos P | lex P | order P | mmr P | n_sel, info[2], pad |
+    //                           header[2] | lexical rows | scores | cosines (n_lex each) | candidate combined / cos / lex
+    const uint64_t words = static_cast<uint64_t>(P) * P + 5ull * P + 8 + 2 + 3ull * n_lex + 3ull * rlr::kHybridSlots;
+    RLR_TRY(grow(&c->d_pool, &c->pool_cap, words));
+    if (c->list_cap < P || !c->d_list) {
+        const uint64_t zero = 0;
+        RLR_TRY(upload_list(ix, c, &zero, 1)); // (allocates the list for >= 1024 rows)
+    }
+    float *d_gram = c->d_pool;
+    float *d_comb = d_gram + static_cast<uint64_t>(P) * P;
+    float *d_cos = d_comb + P;
+    float *d_lexv = d_cos + P;
+    uint32_t *d_order = reinterpret_cast<uint32_t *>(d_lexv + P);
+    float *d_mmr = d_lexv + 2ull * P;
+    uint32_t *d_nsel = reinterpret_cast<uint32_t *>(d_lexv + 3ull * P);
+    uint32_t *d_info = d_nsel + 1;
+    rlr::HybridLexHeader *d_hdr = reinterpret_cast<rlr::HybridLexHeader *>(d_nsel + 8);
+    uint32_t *d_lrow = d_nsel + 10;
+    float *d_lscore = reinterpret_cast<float *>(d_lrow + n_lex);
+    float *d_lcos = d_lscore + n_lex;
+    float *d_cand = d_lcos + n_lex;
+    const size_t q_bytes = static_cast<size_t>(ix->q_pitch) * sizeof(float);
+    const size_t lex_bytes = src.dev ? 0 : 8 + static_cast<size_t>(n_lex) * 8; // header | rows | scores, one copy
+    const size_t out_words = 4ull * k_cap + 2;
+    RLR_TRY(pin_reserve(c, q_bytes + lex_bytes + out_words * 4 + 64));
+    float *h_q = static_cast<float *>(c->h_pin);
+    uint32_t *h_lex = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + q_bytes);
+    uint32_t *h_out = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + q_bytes + lex_bytes);
+    std::memset(h_q, 0, q_bytes);
+    std::memcpy(h_q, query, ix->dim * sizeof(float));
+    if (!src.dev) {
+        h_lex[0] = n_lex;
+        h_lex[1] = __builtin_bit_cast(uint32_t, src.max_lex);
+        for (uint32_t i = 0; i < n_lex; ++i)
+            h_lex[2 + i] = static_cast<uint32_t>(src.h_rows[i]);
+        if (n_lex)
+            std::memcpy(h_lex + 2 + n_lex, src.h_scores, static_cast<size_t>(n_lex) * sizeof(float));
+    }
+    stage_query_norms(ix, c, query, 1);
+    c->hist_dirty = true;
+    const bool timed = ix->profiling;
+    RLR_HIP(hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s));
+    if (!src.dev)
+        RLR_HIP(hipMemcpyAsync(d_hdr, h_lex, lex_bytes, hipMemcpyHostToDevice, s)); // header, rows, scores are adjacent
+    uint64_t *d_meta = c->d_out + fetch;
+    RLR_HIP(enqueue_query(ix, c, 0, p, c->d_out, d_meta, timed));
+    if (timed) RLR_HIP(hipEventRecord(c->bev[0], s));
+    if (src.dev) { // the BM25 kernels ran beside the scan on their own stream: join, then unpack their result
+        RLR_HIP(hipStreamWaitEvent(s, static_cast<hipEvent_t>(src.dev->ready), 0));
+        hipLaunchKernelGGL(rlr::lex_unpack_kernel, dim3((n_lex + 255) / 256), dim3(256), 0, s, src.dev->d_packed, src.dev->d_count,
+                           n_lex, n, d_lrow, d_lscore, d_hdr);
+        RLR_HIP(hipGetLastError());
+    }
+    RLR_HIP(rlr::launch_score_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_query, d_lrow, n_lex, d_lcos, s,
+                                   src.dev ? &d_hdr->n_lex : nullptr, n));
+    hipLaunchKernelGGL(rlr::hybrid_pool_kernel, dim3(1), dim3(1024), 0, s, c->d_out, fetch, need, n, w_embedding, w_lexical, d_lrow,
+                       d_lscore, d_lcos, d_hdr, d_cand, c->d_list, d_comb, d_cos, d_lexv, d_info);
+    RLR_HIP(hipGetLastError());
+    if (diversify) {
+        RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
+        RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, k, lambda, d_order, d_mmr, d_nsel, d_info, 1, s));
+    }
+    hipLaunchKernelGGL(rlr::hybrid_emit_kernel, dim3(1), dim3(256), 0, s, c->d_list, d_comb, d_cos, d_lexv,
+                       diversify ? d_order : nullptr, diversify ? d_nsel : nullptr, d_info, k_cap, h_out);
+    RLR_HIP(hipGetLastError());
+    if (timed) RLR_HIP(hipEventRecord(c->bev[1], s));
+    RLR_HIP(hipStreamSynchronize(s));
+    RLR_TRY(check_hist_assert(c));
+    c->hist_dirty = false;
+    const uint32_t n_sel = h_out[4 * k_cap], status = h_out[4 * k_cap + 1];
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        ix->prof.n_searches += 1;
+        if (timed) {
+            float a = 0, b = 0, d = 0, m = 0;
+            (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+            (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+            (void)hipEventElapsedTime(&d, c->ev[2], c->ev[3]);
+            (void)hipEventElapsedTime(&m, c->bev[0], c->bev[1]);
+            ix->prof.n_scan_launches += 1;
+            ix->prof.scan_ms += a;
+            ix->prof.select_ms += b;
+            ix->prof.rescore_ms += d;
+            ix->prof.total_ms += a + b + d + m;
+            ix->prof.scan_bytes += ix->n_rows * ix->dim * (scan_over_q8(ix) ? 1 : (ix->dtype == RLR_F16 || scan_over_image(ix)) ? 2 : 4);
+            ix->prof.n_mmr += 1;
+            ix->prof.mmr_ms += m;
+        }
+    }
+    if (status != 0) {
+        *fallback = static_cast<int32_t>(status);
+        return RLR_OK;
+    }
+    for (uint32_t i = 0; i < n_sel; ++i) {
+        rows_out[i] = h_out[i];
+        cos_out[i] = __builtin_bit_cast(float, h_out[k_cap + i]);
+        score_out[i] = __builtin_bit_cast(float, h_out[2 * k_cap + i]);
+        lex_out[i] = __builtin_bit_cast(float, h_out[3 * k_cap + i]);
+    }
+    *n_out = n_sel;
+    return RLR_OK;
+}
+
+int32_t rlr_search_hybrid(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
+                          float w_embedding, float w_lexical, const uint64_t *lex_rows, const float *lex_scores, uint32_t n_lex,
+                          float max_lex, float guard_eps, uint64_t *rows_out, float *cos_out, float *score_out, float *lex_out,
+                          uint32_t *n_out, int32_t *fallback)
+{
+    HybridLexSrc src;
+    src.h_rows = lex_rows;
+    src.h_scores = lex_scores;
+    src.n_host = n_lex;
+    src.max_lex = max_lex;
+    return search_hybrid_impl(ix, query, need, k, lambda, diversify, w_embedding, w_lexical, src, guard_eps, rows_out, cos_out,
+                              score_out, lex_out, n_out, fallback);
+}
+
 // Batched MMR over P-strided pools.  The pool rows either live in the index (pool_rows != null:
 // gathered to f32 here) or are already in device memory as n_queries x P x dim f32 values
 // (d_values != null: the sharded path, after the winner-row exchange).
@@ -2203,3 +2600,19 @@ int32_t rlr_profile_read(rlr_index *ix, rlr_profile *out, int32_t reset)
 }
 
 } // extern "C"
+
+namespace rlr {
+
+// rlr_search_hybrid with the lexical pairs taken from a BM25 scoring call that is still in flight on its own stream
+// (lexical_enqueue): this search's stream joins it by event after the scan, so the two run side by side on the device.
+int32_t search_hybrid_device(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
+                             float w_embedding, float w_lexical, const LexPending *lex, float guard_eps, uint64_t *rows_out,
+                             float *cos_out, float *score_out, float *lex_out, uint32_t *n_out, int32_t *fallback)
+{
+    HybridLexSrc src;
+    src.dev = lex;
+    return search_hybrid_impl(ix, query, need, k, lambda, diversify, w_embedding, w_lexical, src, guard_eps, rows_out, cos_out,
+                              score_out, lex_out, n_out, fallback);
+}
+
+} // namespace rlr

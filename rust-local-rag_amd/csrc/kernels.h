@@ -110,9 +110,10 @@ bool launch_rescore_staged(const void *rows, uint32_t pitch16, uint32_t dim, int
                            const uint32_t *cand, const SelectState *st, uint64_t *packed_out, uint32_t n_max,
                            uint32_t *hist_clear, hipStream_t s, hipError_t *err);
 // cos_out[i] = dot_ref(query, row[list[i]]) for an explicit row list.
-hipError_t launch_score_rows(const void *rows, uint32_t pitch16, uint32_t dim, int dtype,
-                             const float *query, const uint32_t *list, uint32_t n, float *cos_out,
-                             hipStream_t s);
+// n_dev != null: the list length is min(*n_dev, n) (known only on the device); rows >= n_rows_clamp (markers) score row 0
+hipError_t launch_score_rows(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *query,
+                             const uint32_t *list, uint32_t n, float *cos_out, hipStream_t s,
+                             const uint32_t *n_dev = nullptr, uint32_t n_rows_clamp = 0xFFFFFFFFu);
 // Reference normalize() of n rows of f32 staging data (in place), then store as dtype.
 hipError_t launch_normalize_store(float *staging, uint32_t n, uint32_t dim, int do_normalize,
                                   void *rows_out, uint32_t pitch16, int dtype, float *norm_tmp,

@@ -22,6 +22,7 @@
 #include "../../include/rlr_lexical.h"
 #include "common.h"
 #include "kernels.h"
+#include "lexical_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -307,6 +308,7 @@ void split_tokens(const char *s, size_t len, std::vector<std::string> *out)
 // threads run side by side (the reference's engine sits behind a tokio RwLock and serves reads concurrently).
 struct LexWorkspace {
     hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr; // recorded behind a call's last kernel (consumers on other streams wait on it)
     float *d_scores = nullptr; // one f32 per row, all zero between calls
     uint64_t scores_cap = 0;
     uint32_t *d_touched = nullptr;
@@ -383,6 +385,8 @@ void workspace_destroy(LexWorkspace *ws)
         (void)hipStreamSynchronize(ws->stream);
         (void)hipStreamDestroy(ws->stream);
     }
+    if (ws->ready)
+        (void)hipEventDestroy(ws->ready);
     void *dev[] = {ws->d_scores, ws->d_touched, ws->d_keys, ws->d_sel, ws->d_ctl, ws->d_out};
     for (void *p : dev)
         if (p)
@@ -398,6 +402,8 @@ int32_t workspace_create(LexWorkspace **out)
     if (!ws)
         return set_error(RLR_E_OOM, "host allocation failed");
     hipError_t e = hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&ws->ready, hipEventDisableTiming);
     if (e == hipSuccess)
         e = rlr::dev_malloc(reinterpret_cast<void **>(&ws->d_ctl), sizeof(LexControl));
     if (e == hipSuccess)
@@ -744,123 +750,17 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     *n_out = 0;
     if (len && !query_tokens)
         return set_error(RLR_E_INVALID, "query_tokens is null");
-    std::vector<std::string> toks;
-    split_tokens(query_tokens, len, &toks);
-    if (toks.empty()) // :2175-2177
+    rlr::LexPending p;
+    LEX_TRY(rlr::lexical_enqueue(lx, query_tokens, len, limit, &p));
+    if (p.limit == 0) // empty index, no tokens, or no term of the query is known (:2170-2177, :2196)
         return RLR_OK;
-    const uint32_t lim = limit == 0 ? kMaxLimit : std::min(limit, kMaxLimit);
-    // Scoring calls share the index; only rebuilding the device postings after a mutation needs it alone.
-    std::shared_lock<std::shared_mutex> rd(lx->mu);
-    if (lx->total_docs == 0) // :2170-2172
-        return RLR_OK;
+    int32_t st = RLR_OK;
     if (!rows_out || !scores_out)
-        return set_error(RLR_E_INVALID, "rows_out / scores_out is null");
-    LEX_HIP(hipSetDevice(lx->device));
-    while (lx->full_dirty || lx->delta_dirty) {
-        rd.unlock();
-        {
-            std::unique_lock<std::shared_mutex> wr(lx->mu);
-            if (lx->full_dirty || lx->delta_dirty)
-                LEX_TRY(commit(lx));
-        }
-        rd.lock();
-    }
-    if (lx->total_docs == 0) // emptied by another thread while the lock was released
-        return RLR_OK;
-
-    // unique query terms in order of first occurrence (:2179-2182 uses a HashSet: order unspecified there)
-    std::vector<uint32_t> terms;
-    for (const auto &t : toks) {
-        auto it = lx->term_id.find(t);
-        if (it == lx->term_id.end() || lx->df[it->second] == 0)
-            continue; // `if let Some(postings) = self.term_postings.get(&term)` :2196
-        if (std::find(terms.begin(), terms.end(), it->second) == terms.end())
-            terms.push_back(it->second);
-    }
-    uint64_t upper = 0;
-    for (uint32_t t : terms)
-        upper += lx->df[t];
-    if (upper == 0)
-        return RLR_OK;
-    upper = std::min<uint64_t>(upper, lx->doc_terms.size()); // at most one touched entry per row
-    WorkspaceLease lease(lx); // back to the pool on every return path
-    LEX_TRY(workspace_acquire(lx, &lease.ws));
-    LexWorkspace *ws = lease.ws;
-    const uint64_t n_rows = lx->doc_terms.size();
-    if (ws->scores_cap < n_rows || !ws->d_scores) { // the index grew since this workspace last ran
-        LEX_HIP(hipStreamSynchronize(ws->stream));
-        LEX_TRY(dev_grow(&ws->d_scores, &ws->scores_cap, n_rows + n_rows / 4, /*zero=*/true));
-        ws->dirty = false;
-        LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), ws->stream));
-    }
-    if (ws->dirty) { // restore the all-zero invariant a failed call may have broken
-        LEX_HIP(hipStreamSynchronize(ws->stream));
-        LEX_HIP(hipMemsetAsync(ws->d_scores, 0, ws->scores_cap * sizeof(float), ws->stream));
-        LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), ws->stream));
-        ws->dirty = false;
-    }
-    LEX_TRY(dev_grow(&ws->d_touched, &ws->touched_cap, upper));
-
-    const float n_docs = static_cast<float>(lx->total_docs);
-    const float avg = static_cast<float>(lx->total_length) / n_docs; // :2184-2188
-    hipStream_t s = ws->stream;
-    ws->dirty = true; // cleared below once the whole pipeline has run
-    const uint32_t max_blocks = static_cast<uint32_t>(lx->n_cu) * 8;
-    for (uint32_t t : terms) {
-        const float df = static_cast<float>(lx->df[t]);
-        float idf = std::log((n_docs - df + 0.5f) / (df + 0.5f)); // f32 ln (:2198-2200)
-        idf = idf > 0.0f ? idf : 0.0f;                            // f32::max(0.0): NaN -> 0
-        // the term's postings in the main segment, then in the appended one (a row is in exactly one of them)
-        const uint32_t cnt_m = t < lx->main_df.size() ? lx->main_df[t] : 0u;
-        if (cnt_m) {
-            const uint64_t off = lx->term_off[t];
-            const uint32_t blocks = std::min<uint32_t>((cnt_m + 255) / 256, max_blocks);
-            hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_post_row + off, lx->d_post_tf + off, cnt_m,
-                               lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
-        }
-        const uint32_t cnt_d = lx->dterm_off.empty() ? 0u : static_cast<uint32_t>(lx->dterm_off[t + 1] - lx->dterm_off[t]);
-        if (cnt_d) {
-            const uint64_t off = lx->dterm_off[t];
-            const uint32_t blocks = std::min<uint32_t>((cnt_d + 255) / 256, max_blocks);
-            hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_dpost_row + off, lx->d_dpost_tf + off,
-                               cnt_d, lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
-        }
-    }
-    LEX_HIP(hipGetLastError());
-    uint32_t *d_out_n = reinterpret_cast<uint32_t *>(ws->d_out + kMaxLimit);
-    const uint32_t blocks_u = std::min<uint32_t>(static_cast<uint32_t>((upper + 255) / 256), max_blocks);
-    if (upper <= kMaxLimit) {
-        hipLaunchKernelGGL(lex_sort_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, nullptr, ws->d_ctl,
-                           lim, ws->d_out, d_out_n);
-    } else {
-        LEX_TRY(dev_grow(&ws->d_keys, &ws->keys_cap, upper));
-        hipLaunchKernelGGL(lex_pack_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl,
-                           ws->d_keys);
-        for (int p = 0; p < kPasses; ++p)
-            hipLaunchKernelGGL(lex_select_pass_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, p);
-        hipLaunchKernelGGL(lex_collect_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, ws->d_sel);
-        hipLaunchKernelGGL(lex_sort_kernel<false>, dim3(1), dim3(1024), 0, s, nullptr, nullptr, ws->d_sel, ws->d_ctl, lim,
-                           ws->d_out, d_out_n);
-    }
-    LEX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(lex_clear_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl);
-    LEX_HIP(hipGetLastError());
-    LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), s));
-    // one copy: the count sits right behind the keys; only `lim` keys can be valid
-    LEX_HIP(hipMemcpyAsync(ws->h_out + kMaxLimit, ws->d_out + kMaxLimit, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    LEX_HIP(hipMemcpyAsync(ws->h_out, ws->d_out, static_cast<size_t>(lim) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    LEX_HIP(hipStreamSynchronize(s));
-    ws->dirty = false;
-    const uint32_t n = std::min<uint32_t>(*reinterpret_cast<const uint32_t *>(ws->h_out + kMaxLimit), lim);
-    for (uint32_t i = 0; i < n; ++i) {
-        float sc;
-        uint32_t row;
-        unpack_result(ws->h_out[i], &sc, &row);
-        rows_out[i] = row;
-        scores_out[i] = sc;
-    }
-    *n_out = n;
-    return RLR_OK;
+        st = set_error(RLR_E_INVALID, "rows_out / scores_out is null");
+    else
+        st = rlr::lexical_fetch(&p, rows_out, scores_out, n_out);
+    rlr::lexical_finish(&p, st == RLR_OK);
+    return st;
 }
 
 int32_t rlr_tokenize_ascii(const char *text, size_t len, char *out, size_t cap, size_t *out_len)
@@ -900,3 +800,185 @@ int32_t rlr_tokenize_ascii(const char *text, size_t len, char *out, size_t cap, 
 }
 
 } // extern "C"
+
+namespace rlr {
+
+namespace {
+struct PendingGuard { // releases whatever lexical_enqueue had taken when it fails half way
+    LexPending *p;
+    bool armed = true;
+    ~PendingGuard()
+    {
+        if (armed)
+            lexical_finish(p, false);
+    }
+};
+} // namespace
+
+int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, LexPending *out)
+{
+    *out = LexPending{};
+    out->lx = lx;
+    std::vector<std::string> toks;
+    split_tokens(query_tokens, len, &toks);
+    if (toks.empty()) // :2175-2177
+        return RLR_OK;
+    const uint32_t lim = limit == 0 ? kMaxLimit : std::min(limit, kMaxLimit);
+    // Scoring calls share the index; only rebuilding the device postings after a mutation needs it alone.
+    lx->mu.lock_shared();
+    out->locked = true;
+    PendingGuard guard{out};
+    if (lx->total_docs == 0) { // :2170-2172
+        lexical_finish(out, true);
+        guard.armed = false;
+        return RLR_OK;
+    }
+    LEX_HIP(hipSetDevice(lx->device));
+    while (lx->full_dirty || lx->delta_dirty) {
+        lx->mu.unlock_shared();
+        out->locked = false;
+        {
+            std::unique_lock<std::shared_mutex> wr(lx->mu);
+            if (lx->full_dirty || lx->delta_dirty)
+                LEX_TRY(commit(lx));
+        }
+        lx->mu.lock_shared();
+        out->locked = true;
+    }
+    // unique query terms in order of first occurrence (:2179-2182 uses a HashSet: order unspecified there)
+    std::vector<uint32_t> terms;
+    for (const auto &t : toks) {
+        auto it = lx->term_id.find(t);
+        if (it == lx->term_id.end() || lx->df[it->second] == 0)
+            continue; // `if let Some(postings) = self.term_postings.get(&term)` :2196
+        if (std::find(terms.begin(), terms.end(), it->second) == terms.end())
+            terms.push_back(it->second);
+    }
+    uint64_t upper = 0;
+    for (uint32_t t : terms)
+        upper += lx->df[t];
+    if (upper == 0 || lx->total_docs == 0) { // (or emptied by another thread while the lock was released)
+        lexical_finish(out, true);
+        guard.armed = false;
+        return RLR_OK;
+    }
+    upper = std::min<uint64_t>(upper, lx->doc_terms.size()); // at most one touched entry per row
+    LexWorkspace *ws = nullptr;
+    LEX_TRY(workspace_acquire(lx, &ws));
+    out->ws = ws;
+    const uint64_t n_rows = lx->doc_terms.size();
+    if (ws->scores_cap < n_rows || !ws->d_scores) { // the index grew since this workspace last ran
+        LEX_HIP(hipStreamSynchronize(ws->stream));
+        LEX_TRY(dev_grow(&ws->d_scores, &ws->scores_cap, n_rows + n_rows / 4, /*zero=*/true));
+        ws->dirty = false;
+        LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), ws->stream));
+    }
+    if (ws->dirty) { // restore the all-zero invariant a failed call may have broken
+        LEX_HIP(hipStreamSynchronize(ws->stream));
+        LEX_HIP(hipMemsetAsync(ws->d_scores, 0, ws->scores_cap * sizeof(float), ws->stream));
+        LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), ws->stream));
+        ws->dirty = false;
+    }
+    LEX_TRY(dev_grow(&ws->d_touched, &ws->touched_cap, upper));
+
+    const float n_docs = static_cast<float>(lx->total_docs);
+    const float avg = static_cast<float>(lx->total_length) / n_docs; // :2184-2188
+    hipStream_t s = ws->stream;
+    ws->dirty = true; // cleared by lexical_finish(ok) once the whole pipeline has run
+    const uint32_t max_blocks = static_cast<uint32_t>(lx->n_cu) * 8;
+    for (uint32_t t : terms) {
+        const float df = static_cast<float>(lx->df[t]);
+        float idf = std::log((n_docs - df + 0.5f) / (df + 0.5f)); // f32 ln (:2198-2200)
+        idf = idf > 0.0f ? idf : 0.0f;                            // f32::max(0.0): NaN -> 0
+        // the term's postings in the main segment, then in the appended one (a row is in exactly one of them)
+        const uint32_t cnt_m = t < lx->main_df.size() ? lx->main_df[t] : 0u;
+        if (cnt_m) {
+            const uint64_t off = lx->term_off[t];
+            const uint32_t blocks = std::min<uint32_t>((cnt_m + 255) / 256, max_blocks);
+            hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_post_row + off, lx->d_post_tf + off, cnt_m,
+                               lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
+        }
+        const uint32_t cnt_d = lx->dterm_off.empty() ? 0u : static_cast<uint32_t>(lx->dterm_off[t + 1] - lx->dterm_off[t]);
+        if (cnt_d) {
+            const uint64_t off = lx->dterm_off[t];
+            const uint32_t blocks = std::min<uint32_t>((cnt_d + 255) / 256, max_blocks);
+            hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_dpost_row + off, lx->d_dpost_tf + off,
+                               cnt_d, lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
+        }
+    }
+    LEX_HIP(hipGetLastError());
+    uint32_t *d_out_n = reinterpret_cast<uint32_t *>(ws->d_out + kMaxLimit);
+    const uint32_t blocks_u = std::min<uint32_t>(static_cast<uint32_t>((upper + 255) / 256), max_blocks);
+    if (upper <= kMaxLimit) {
+        hipLaunchKernelGGL(lex_sort_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, nullptr, ws->d_ctl,
+                           lim, ws->d_out, d_out_n);
+    } else {
+        LEX_TRY(dev_grow(&ws->d_keys, &ws->keys_cap, upper));
+        hipLaunchKernelGGL(lex_pack_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl,
+                           ws->d_keys);
+        for (int p = 0; p < kPasses; ++p)
+            hipLaunchKernelGGL(lex_select_pass_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, p);
+        hipLaunchKernelGGL(lex_collect_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, ws->d_sel);
+        hipLaunchKernelGGL(lex_sort_kernel<false>, dim3(1), dim3(1024), 0, s, nullptr, nullptr, ws->d_sel, ws->d_ctl, lim,
+                           ws->d_out, d_out_n);
+    }
+    LEX_HIP(hipGetLastError());
+    LEX_HIP(hipEventRecord(ws->ready, s)); // the result list is complete here; the clean-up below runs behind it
+    hipLaunchKernelGGL(lex_clear_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl);
+    LEX_HIP(hipGetLastError());
+    LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), s));
+    out->stream = s;
+    out->ready = ws->ready;
+    out->d_packed = ws->d_out;
+    out->d_count = d_out_n;
+    out->limit = lim;
+    guard.armed = false;
+    return RLR_OK;
+}
+
+int32_t lexical_fetch(LexPending *p, uint64_t *rows_out, float *scores_out, uint32_t *n_out)
+{
+    *n_out = 0;
+    if (p->limit == 0 || !p->ws)
+        return RLR_OK;
+    LexWorkspace *ws = static_cast<LexWorkspace *>(p->ws);
+    hipStream_t s = ws->stream;
+    // one copy: the count sits right behind the keys; only `limit` keys can be valid
+    LEX_HIP(hipMemcpyAsync(ws->h_out + kMaxLimit, ws->d_out + kMaxLimit, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    LEX_HIP(hipMemcpyAsync(ws->h_out, ws->d_out, static_cast<size_t>(p->limit) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    LEX_HIP(hipStreamSynchronize(s));
+    const uint32_t n = std::min<uint32_t>(*reinterpret_cast<const uint32_t *>(ws->h_out + kMaxLimit), p->limit);
+    for (uint32_t i = 0; i < n; ++i) {
+        float sc;
+        uint32_t row;
+        unpack_result(ws->h_out[i], &sc, &row);
+        rows_out[i] = row;
+        scores_out[i] = sc;
+    }
+    *n_out = n;
+    return RLR_OK;
+}
+
+void lexical_finish(LexPending *p, bool ok)
+{
+    rlr_lexical *lx = p->lx;
+    if (p->ws) {
+        LexWorkspace *ws = static_cast<LexWorkspace *>(p->ws);
+        if (ok) // the clean-up kernels behind `ready` restore the all-zero accumulators; wait for them before reuse
+            ok = hipStreamSynchronize(ws->stream) == hipSuccess;
+        if (ok)
+            ws->dirty = false;
+        {
+            std::lock_guard<std::mutex> lk(lx->ws_mu);
+            lx->ws_free.push_back(ws);
+        }
+        lx->ws_cv.notify_one();
+        p->ws = nullptr;
+    }
+    if (p->locked) {
+        lx->mu.unlock_shared();
+        p->locked = false;
+    }
+}
+
+} // namespace rlr

@@ -1,0 +1,39 @@
+// lexical_internal.h -- library-internal view of a BM25 scoring call that leaves its result on the device, so the hybrid
+// search (csrc/engine.cpp: rlr_engine_search_text) can run it beside the cosine scan and blend without a host round trip.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+struct rlr_lexical;
+struct rlr_index;
+
+namespace rlr {
+
+// An enqueued scoring call.  From lexical_enqueue to lexical_finish the caller holds one of the index' workspaces and
+// its readers' lock: mutators wait, other scoring calls do not.
+struct LexPending {
+    rlr_lexical *lx = nullptr;
+    void *ws = nullptr;                 // the leased workspace
+    void *stream = nullptr;             // hipStream_t: its stream; `ready` is recorded there behind the last kernel
+    void *ready = nullptr;              // hipEvent_t (opaque here: csrc/engine.cpp is built without the HIP headers)
+    const uint64_t *d_packed = nullptr; // pack_result(score, row), (score desc, row asc); RLR_LEXICAL_MAX_LIMIT entries
+    const uint32_t *d_count = nullptr;  // how many of them are valid (<= limit)
+    uint32_t limit = 0;                 // 0: no document can match (empty index / unknown terms) -- nothing was enqueued
+    bool locked = false;
+};
+
+// LexicalIndex::score (rag_engine.rs:2169-2225) up to the ordered result list in device memory.  No synchronisation.
+int32_t lexical_enqueue(rlr_lexical *lx, const char *tokens, size_t len, uint32_t limit, LexPending *out);
+// copy the result to the host (synchronises the scoring stream); valid between enqueue and finish
+int32_t lexical_fetch(LexPending *p, uint64_t *rows_out, float *scores_out, uint32_t *n_out);
+// hand the workspace back once every consumer of d_packed has finished (the caller synchronised them);
+// ok = false: something failed after the enqueue -- the workspace is re-zeroed before its next use
+void lexical_finish(LexPending *p, bool ok);
+
+// index.hip: rlr_search_hybrid (include/rlr_gpu.h) with the lexical pairs of `lex` instead of host arrays
+int32_t search_hybrid_device(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
+                             float w_embedding, float w_lexical, const LexPending *lex, float guard_eps, uint64_t *rows_out,
+                             float *cos_out, float *score_out, float *lex_out, uint32_t *n_out, int32_t *fallback);
+
+} // namespace rlr

@@ -22,7 +22,7 @@ import numpy as np
 
 from . import _native as N
 from .index import GpuIndex, _f32
-from .lexical import LexicalIndex
+from .lexical import LexicalIndex, tokenize
 
 
 @dataclass
@@ -206,8 +206,15 @@ class RagEngine:
         cap = max(3 * max(top_k, 1), 1)
         hits = (N.SearchHitC * cap)()
         n = C.c_uint32()
-        lr, ls, nl = self._lex(lexical, query_text, 5 * max(top_k, 1))   # top_k.max(1) then saturating_mul(5) :490, :505
         wc = weights.to_c() if weights is not None else None
+        if query_text is not None:
+            # BM25 of the text beside the scan, blended on the device: one enqueue, one synchronisation
+            tok = " ".join(tokenize(query_text)).encode("utf-8")
+            N.check(N.lib().rlr_engine_search_text(self.index.handle, self.lexical._h, q.ctypes.data_as(N.f32p), q.size, tok,
+                                                   len(tok), top_k, 0.0, stage, C.byref(wc) if wc is not None else None, hits,
+                                                   cap, C.byref(n)))
+            return self._results(hits, n.value)
+        lr, ls, nl = self._lex(lexical, None, 5 * max(top_k, 1))   # top_k.max(1) then saturating_mul(5) :490, :505
         N.check(N.lib().rlr_engine_search(self.index.handle, q.ctypes.data_as(N.f32p), q.size, top_k,
                                           C.byref(wc) if wc is not None else None, lr.ctypes.data_as(N.u64p),
                                           ls.ctypes.data_as(N.f32p), nl, stage, hits, cap, C.byref(n)))
@@ -224,8 +231,14 @@ class RagEngine:
         n = C.c_uint32()
         lam = min(max(float(diversity_factor), 0.0), 1.0)
         k_eff = top_k if lam == 0.0 else max(3 * top_k, top_k + 10)  # the top_k `search` sees (:728-735)
-        lr, ls, nl = self._lex(lexical, query_text, 5 * max(k_eff, 1))    # search() treats 0 as 1 (:490) before * 5 (:505)
         wc = weights.to_c() if weights is not None else None
+        if query_text is not None:
+            tok = " ".join(tokenize(query_text)).encode("utf-8")
+            N.check(N.lib().rlr_engine_search_text(self.index.handle, self.lexical._h, q.ctypes.data_as(N.f32p), q.size, tok,
+                                                   len(tok), top_k, float(diversity_factor), 0,
+                                                   C.byref(wc) if wc is not None else None, hits, cap, C.byref(n)))
+            return self._results(hits, n.value)
+        lr, ls, nl = self._lex(lexical, None, 5 * max(k_eff, 1))    # search() treats 0 as 1 (:490) before * 5 (:505)
         N.check(N.lib().rlr_engine_search_with_diversity(
             self.index.handle, q.ctypes.data_as(N.f32p), q.size, top_k, float(diversity_factor),
             C.byref(wc) if wc is not None else None, lr.ctypes.data_as(N.u64p), ls.ctypes.data_as(N.f32p), nl,

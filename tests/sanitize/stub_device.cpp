@@ -147,4 +147,36 @@ int32_t rlr_search_diverse(rlr_index *, const float *, uint32_t, uint32_t, float
     return RLR_OK;
 }
 
+int32_t rlr_search_hybrid(rlr_index *, const float *, uint32_t, uint32_t, float, int32_t, float, float, const uint64_t *,
+                          const float *, uint32_t, float, float, uint64_t *, float *, float *, float *, uint32_t *n_out,
+                          int32_t *fallback)
+{
+    *n_out = 0;
+    *fallback = 1; // the host blend of csrc/engine.cpp is what the sanitizers are here to exercise
+    return RLR_OK;
+}
+
 } // extern "C"
+
+// the GPU lexical index and the fused text search do not exist in the host build either
+#include "../../rust-local-rag_amd/csrc/lexical_internal.h"
+namespace rlr {
+int32_t lexical_enqueue(rlr_lexical *, const char *, size_t, uint32_t, LexPending *out)
+{
+    *out = LexPending{};
+    return RLR_OK; // limit == 0: "no lexical candidate"
+}
+int32_t lexical_fetch(LexPending *, uint64_t *, float *, uint32_t *n_out)
+{
+    *n_out = 0;
+    return RLR_OK;
+}
+void lexical_finish(LexPending *, bool) {}
+int32_t search_hybrid_device(rlr_index *, const float *, uint32_t, uint32_t, float, int32_t, float, float, const LexPending *, float,
+                             uint64_t *, float *, float *, float *, uint32_t *n_out, int32_t *fallback)
+{
+    *n_out = 0;
+    *fallback = 1;
+    return RLR_OK;
+}
+} // namespace rlr
