@@ -248,6 +248,52 @@ def config_c3(rlr, ix, args, torch):
             "fallback_queries": p.n_batch_fallbacks, "roofline": batched_roofline(p, args.dim, nq, True)}
 
 
+def c2_hybrid_leg(rlr, torch, ix, qs, n, dim, k, lam, steps):
+    """C2 the way the reference's search_documents runs it: with the query TEXT, whose BM25 scores (`LexicalIndex::score`,
+    5 x pool of them, rag_engine.rs:505) are blended into the pool before MMR.  rlr_engine_search_text at the C ABI: BM25
+    on its own stream beside the scan, blend + cut + MMR in the same enqueue.  Synthetic chunk texts: 40 Zipf-distributed
+    words of a 20 000-word vocabulary per chunk, 6-word queries."""
+    import ctypes as C
+
+    N = rlr._native
+    lex_mod = importlib.import_module("rust-local-rag_amd.lexical")
+    rng = np.random.default_rng(0x5EED0012)
+    V = 20000
+    vocab = np.array([f"t{i:05d}" for i in range(V)])
+    zipf = 1.0 / np.arange(1, V + 1)
+    zipf /= zipf.sum()
+    lx = lex_mod.LexicalIndex(0)
+    try:
+        for b0 in range(0, n, 10000):
+            words = rng.choice(V, size=(min(10000, n - b0), 40), p=zipf)
+            for i in range(words.shape[0]):
+                lx.add_tokens(b0 + i, vocab[words[i]])
+        toks = [" ".join(vocab[rng.choice(V, size=6, p=zipf)]).encode() for _ in range(steps + 20)]
+        cap = max(3 * k, k + 10)
+        hits = (N.SearchHitC * cap)()
+        nn = C.c_uint32()
+        L = N.lib()
+
+        def call(i):
+            q = qs[i]
+            N.check(L.rlr_engine_search_text(ix.handle, lx._h, q.ctypes.data_as(N.f32p), dim, toks[i], len(toks[i]), k, lam, 0,
+                                             None, hits, cap, C.byref(nn)))
+
+        for i in range(20):
+            call(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            call(20 + i)
+        el = time.perf_counter() - t0
+        n_lex = sum(1 for j in range(nn.value) if hits[j].lexical_score != 0.0)
+    finally:
+        lx.close()
+    return {"what": "rlr_engine_search_text: the same search with the query text (GPU BM25 beside the scan, hybrid blend, "
+                    "MMR; one synchronisation)", "value": steps / el, "unit": "queries/s", "ms_per_query": el / steps * 1e3,
+            "results_of_the_last_query": int(nn.value), "of_them_with_a_lexical_score": n_lex}
+
+
 def config_c2(rlr, torch):
     """C2: 100 k x 768 f32, single query, top-100, MMR lambda 0.3: rlr_engine_search_with_diversity timed at the C ABI
     (what a Rust host calls; the Python veneer's per-result objects are not part of the path)."""
@@ -282,6 +328,7 @@ def config_c2(rlr, torch):
             call(qs[20 + i])
         ix.profile_enable(False)
         p = ix.profile_read()
+        hybrid = c2_hybrid_leg(rlr, torch, ix, qs, n, dim, k, lam, steps)
     finally:
         ix.close()
     ns = max(p.n_scan_launches, 1)
@@ -294,6 +341,7 @@ def config_c2(rlr, torch):
                         f"rlr_engine_search_with_diversity at the C ABI (search -> MMR fused on the device)",
             "value": steps / el, "unit": "queries/s", "ms_per_query": el / steps * 1e3,
             "kernels_ms": kern, "kernel_sum_ms": sum(kern.values()), "results_per_query": int(nn.value),
+            "with_query_text": hybrid,
             "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": gbps / HBM_PEAK_GBPS, "traffic": None, "kernel": "scan_fixed_kernel",
                          "kernel_ms": scan_ms, "bytes_per_launch": b,

@@ -451,56 +451,58 @@ int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *qu
     const uint32_t k_seen = std::max<uint32_t>(diversify ? pool_size : top_k, 1u); // the top_k `search` works with (:490)
     const uint32_t limit = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(k_seen) * 5, 0xFFFFFFFFull)); // :505
 
-    // BM25 on its own stream; nothing below waits for it on the host unless the fused path is not taken
-    rlr::LexPending lp;
-    int32_t st = rlr::lexical_enqueue(lex, query_tokens, tokens_len, limit, &lp);
-    if (st != RLR_OK)
-        return st;
-    if (lp.limit == 0) { // no lexical candidate at all: the embedding-only paths
-        rlr::lexical_finish(&lp, true);
-        return diversify ? rlr_engine_search_with_diversity(idx, query_raw, dq, top_k, diversity_factor, weights, nullptr, nullptr, 0,
-                                                             out, cap, n_out)
-                         : rlr_engine_search(idx, query_raw, dq, top_k, weights, nullptr, nullptr, 0, stage, out, cap, n_out);
-    }
     uint64_t N = 0;
     uint32_t dim = 0;
-    st = rlr_index_info(idx, &N, &dim, nullptr, nullptr);
-    if (st != RLR_OK || N == 0) { // :476-478
-        rlr::lexical_finish(&lp, st == RLR_OK);
+    int32_t st = rlr_index_info(idx, &N, &dim, nullptr, nullptr);
+    if (st != RLR_OK || N == 0) // :476-478
         return st;
-    }
     const uint64_t want3 = static_cast<uint64_t>(k_seen) * 3;
     const uint64_t initial_k = std::min<uint64_t>(N, want3);                                            // :544
     const uint64_t need = (diversify || !stage) ? std::min<uint64_t>(initial_k, k_seen) : initial_k;    // :667-698
     if (w.embedding > 0.0f && need <= 1024) {
+        // 1. the cosine scan .. sort goes onto the index' stream; 2. the BM25 kernels onto the lexical index' own stream
+        // -- the device runs them side by side, and the host's launch calls for the second batch overlap the scan;
+        // 3. blend .. results behind an event join.  One host synchronisation.
         const std::vector<float> q = prepare_query(query_raw, dq, dim);
         const uint32_t nd = static_cast<uint32_t>(need);
-        const uint32_t n_res = diversify ? static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(top_k, 1u), nd)) : nd;
-        std::vector<uint64_t> rows(n_res);
-        std::vector<float> cosv(n_res), sc(n_res), lx(n_res);
-        uint32_t got = 0;
+        rlr::HybridTicket *ticket = nullptr;
         int32_t fb = 0;
-        st = rlr::search_hybrid_device(idx, q.data(), nd, top_k, diversity_factor, diversify ? 1 : 0, w.embedding, w.lexical, &lp,
-                                       -1.0f, rows.data(), cosv.data(), sc.data(), lx.data(), &got, &fb);
-        if (st != RLR_OK || !fb) {
+        st = rlr::search_hybrid_begin(idx, q.data(), nd, top_k, diversity_factor, diversify ? 1 : 0, w.embedding, w.lexical,
+                                      std::min<uint32_t>(limit, RLR_LEXICAL_MAX_LIMIT), -1.0f, &ticket, &fb);
+        if (st != RLR_OK)
+            return st;
+        if (!fb) {
+            rlr::LexPending lp;
+            st = rlr::lexical_enqueue(lex, query_tokens, tokens_len, limit, &lp);
+            if (st != RLR_OK) {
+                rlr::search_hybrid_abort(ticket);
+                return st;
+            }
+            const uint32_t n_res = diversify ? static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(top_k, 1u), nd)) : nd;
+            std::vector<uint64_t> rows(n_res);
+            std::vector<float> cosv(n_res), sc(n_res), lx(n_res);
+            uint32_t got = 0;
+            st = rlr::search_hybrid_finish(ticket, &lp, rows.data(), cosv.data(), sc.data(), lx.data(), &got, &fb);
             rlr::lexical_finish(&lp, st == RLR_OK);
             if (st != RLR_OK)
                 return st;
-            if (got && !out)
-                return RLR_E_INVALID;
-            std::vector<Cand> res(got);
-            for (uint32_t i = 0; i < got; ++i)
-                res[i] = {rows[i], sc[i], cosv[i], lx[i]};
-            emit(res, out, cap, n_out);
-            return RLR_OK;
+            if (!fb) {
+                if (got && !out)
+                    return RLR_E_INVALID;
+                std::vector<Cand> res(got);
+                for (uint32_t i = 0; i < got; ++i)
+                    res[i] = {rows[i], sc[i], cosv[i], lx[i]};
+                emit(res, out, cap, n_out);
+                return RLR_OK;
+            }
         }
     }
-    // the pairs on the host, then the entry points that take them
-    std::vector<uint64_t> lrows(lp.limit);
-    std::vector<float> lscores(lp.limit);
+    // not covered by the fused kernels (or handed back): the pairs on the host, then the entry points that take them
+    const uint32_t lcap = limit == 0 ? RLR_LEXICAL_MAX_LIMIT : std::min<uint32_t>(limit, RLR_LEXICAL_MAX_LIMIT);
+    std::vector<uint64_t> lrows(lcap);
+    std::vector<float> lscores(lcap);
     uint32_t n_lex = 0;
-    st = rlr::lexical_fetch(&lp, lrows.data(), lscores.data(), &n_lex);
-    rlr::lexical_finish(&lp, st == RLR_OK);
+    st = rlr_lexical_score(lex, query_tokens, tokens_len, limit, lrows.data(), lscores.data(), &n_lex);
     if (st != RLR_OK)
         return st;
     return diversify ? rlr_engine_search_with_diversity(idx, query_raw, dq, top_k, diversity_factor, weights, lrows.data(),

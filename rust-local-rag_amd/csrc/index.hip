@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -2286,42 +2287,53 @@ struct HybridLexSrc {
     const uint64_t *h_rows = nullptr; // host pairs: ascending unique rows inside the index ...
     const float *h_scores = nullptr;
     uint32_t n_host = 0;
-    float max_lex = 0.0f;
-    const rlr::LexPending *dev = nullptr; // ... or a BM25 call's result still on the device
+    float max_lex = 1.1920929e-07f;
+    const rlr::LexPending *dev = nullptr; // ... or a BM25 call's result still on the device (null + n_host 0: no pairs)
 };
 
-static int32_t search_hybrid_impl(rlr_index *ix, const float *query, uint32_t need_in, uint32_t k, float lambda, int32_t diversify,
-                                  float w_embedding, float w_lexical, const HybridLexSrc &src, float guard_eps,
-                                  uint64_t *rows_out, float *cos_out, float *score_out, float *lex_out, uint32_t *n_out,
-                                  int32_t *fallback)
+} // extern "C"
+
+namespace rlr {
+
+// A hybrid search between its two enqueues: the scan / select / re-score / sort part is on the stream (it does not
+// depend on the lexical pairs, only on an upper bound of their number), the blend and everything behind it follows in
+// search_hybrid_finish.  In between the caller enqueues the BM25 kernels on their own stream: the device runs them
+// beside the scan, and the host's launch calls for both overlap the scan instead of preceding it.
+struct HybridTicket {
+    rlr_index *ix;
+    CtxLease lease;
+    uint32_t n, need, fetch, n_lex_bound, k, k_cap;
+    float lambda, w_e, w_l;
+    int32_t diversify;
+    bool timed;
+    size_t q_bytes, lex_bytes_cap;
+    explicit HybridTicket(rlr_index *i) : ix(i), lease(i) {}
+};
+
+static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t need_in, uint32_t k, float lambda, int32_t diversify,
+                                 float w_embedding, float w_lexical, uint32_t n_lex_bound, float guard_eps, HybridTicket **out,
+                                 int32_t *fallback)
 {
-    RLR_TRY(check_handle(ix));
-    if (!n_out || !fallback)
-        return fail(RLR_E_INVALID, "n_out / fallback is null");
-    *n_out = 0;
+    *out = nullptr;
     *fallback = 0;
-    if (ix->n_rows == 0 || need_in == 0)
-        return RLR_OK;
-    const uint32_t n_lex = src.dev ? src.dev->limit : src.n_host; // (an upper bound when the pairs are on the device)
-    if (!query || !rows_out || !cos_out || !score_out || !lex_out || (!src.dev && n_lex && (!src.h_rows || !src.h_scores)))
+    RLR_TRY(check_handle(ix));
+    if (!query)
         return fail(RLR_E_INVALID, "null argument");
     const uint32_t n = static_cast<uint32_t>(ix->n_rows);
     const uint32_t need = std::min<uint32_t>(n, need_in);
-    const uint64_t fetch64 = std::min<uint64_t>(n, static_cast<uint64_t>(need) + n_lex + 8);
-    if (need > rlr::kPoolMax || n_lex > rlr::kHybridLexMax || fetch64 + n_lex > rlr::kHybridSlots || !(w_embedding > 0.0f) ||
-        !std::isfinite(w_embedding) || !std::isfinite(w_lexical)) {
+    const uint64_t fetch64 = std::min<uint64_t>(n, static_cast<uint64_t>(need) + n_lex_bound + 8);
+    if (n == 0 || need == 0 || need > kPoolMax || n_lex_bound > kHybridLexMax || fetch64 + n_lex_bound > kHybridSlots ||
+        !(w_embedding > 0.0f) || !std::isfinite(w_embedding) || !std::isfinite(w_lexical)) {
         *fallback = 1; // outside what the fused kernels cover: the caller's host path handles it
         return RLR_OK;
     }
-    if (!src.dev)
-        for (uint32_t i = 0; i < n_lex; ++i)
-            if (src.h_rows[i] >= n || (i && src.h_rows[i] <= src.h_rows[i - 1]))
-                return fail(RLR_E_INVALID, "lex_rows must be ascending, unique and inside the index");
     const uint32_t fetch = static_cast<uint32_t>(fetch64);
     RLR_TRY(use_device(ix));
-    CtxLease lease(ix);
-    RLR_TRY(ctx_acquire(ix, &lease.c));
-    Ctx *c = lease.c;
+    std::unique_ptr<HybridTicket> t(new (std::nothrow) HybridTicket(ix));
+    if (!t)
+        return fail(RLR_E_OOM, "host allocation failed");
+    RLR_TRY(ctx_acquire(ix, &t->lease.c));
+    Ctx *c = t->lease.c;
     hipStream_t s = c->stream;
     SearchPlan p;
     p.k = fetch;
@@ -2334,13 +2346,64 @@ static int32_t search_hybrid_impl(rlr_index *ix, const float *query, uint32_t ne
     const uint32_t P = need;
     const uint32_t k_cap = diversify ? std::max<uint32_t>(std::min<uint32_t>(std::max<uint32_t>(k, 1u), P), 1u) : P;
     // workspace (4-byte words): gram P x P | combined P | cos P | lex P | order P | mmr P | n_sel, info[2], pad |
-    //                           header[2] | lexical rows | scores | cosines (n_lex each) | candidate combined / cos / lex
-    const uint64_t words = static_cast<uint64_t>(P) * P + 5ull * P + 8 + 2 + 3ull * n_lex + 3ull * rlr::kHybridSlots;
+    //                           header[2] | lexical rows | scores | cosines (bound each) | candidate combined / cos / lex
+    const uint64_t words = static_cast<uint64_t>(P) * P + 5ull * P + 8 + 2 + 3ull * n_lex_bound + 3ull * kHybridSlots;
     RLR_TRY(grow(&c->d_pool, &c->pool_cap, words));
     if (c->list_cap < P || !c->d_list) {
         const uint64_t zero = 0;
         RLR_TRY(upload_list(ix, c, &zero, 1)); // (allocates the list for >= 1024 rows)
     }
+    t->n = n;
+    t->need = need;
+    t->fetch = fetch;
+    t->n_lex_bound = n_lex_bound;
+    t->k = k;
+    t->k_cap = k_cap;
+    t->lambda = lambda;
+    t->w_e = w_embedding;
+    t->w_l = w_lexical;
+    t->diversify = diversify;
+    t->timed = ix->profiling;
+    t->q_bytes = static_cast<size_t>(ix->q_pitch) * sizeof(float);
+    t->lex_bytes_cap = 8 + static_cast<size_t>(n_lex_bound) * 8; // header | rows | scores, one copy
+    RLR_TRY(pin_reserve(c, t->q_bytes + t->lex_bytes_cap + (4ull * k_cap + 2) * 4 + 64));
+    float *h_q = static_cast<float *>(c->h_pin);
+    std::memset(h_q, 0, t->q_bytes);
+    std::memcpy(h_q, query, ix->dim * sizeof(float));
+    stage_query_norms(ix, c, query, 1);
+    c->hist_dirty = true;
+    RLR_HIP(hipMemcpyAsync(c->d_query, h_q, t->q_bytes, hipMemcpyHostToDevice, s));
+    uint64_t *d_meta = c->d_out + fetch;
+    RLR_HIP(enqueue_query(ix, c, 0, p, c->d_out, d_meta, t->timed));
+    if (t->timed) RLR_HIP(hipEventRecord(c->bev[0], s));
+    *out = t.release();
+    return RLR_OK;
+}
+
+// always consumes the ticket
+static int32_t hybrid_finish_impl(HybridTicket *ticket, const HybridLexSrc &src, uint64_t *rows_out, float *cos_out,
+                                  float *score_out, float *lex_out, uint32_t *n_out, int32_t *fallback)
+{
+    std::unique_ptr<HybridTicket> t(ticket);
+    rlr_index *ix = t->ix;
+    Ctx *c = t->lease.c;
+    hipStream_t s = c->stream;
+    *n_out = 0;
+    *fallback = 0;
+    // whatever goes wrong from here on: the enqueued work may still be running on `s` when the context goes back
+    struct Drain {
+        hipStream_t s;
+        bool armed = true;
+        ~Drain()
+        {
+            if (armed)
+                (void)hipStreamSynchronize(s);
+        }
+    } drain{s};
+    const uint32_t n_lex = src.dev ? t->n_lex_bound : src.n_host;
+    if (n_lex > t->n_lex_bound || !rows_out || !cos_out || !score_out || !lex_out)
+        return fail(RLR_E_INVALID, "hybrid search: bad arguments");
+    const uint32_t P = t->need, k_cap = t->k_cap, n = t->n;
     float *d_gram = c->d_pool;
     float *d_comb = d_gram + static_cast<uint64_t>(P) * P;
     float *d_cos = d_comb + P;
@@ -2349,56 +2412,45 @@ static int32_t search_hybrid_impl(rlr_index *ix, const float *query, uint32_t ne
     float *d_mmr = d_lexv + 2ull * P;
     uint32_t *d_nsel = reinterpret_cast<uint32_t *>(d_lexv + 3ull * P);
     uint32_t *d_info = d_nsel + 1;
-    rlr::HybridLexHeader *d_hdr = reinterpret_cast<rlr::HybridLexHeader *>(d_nsel + 8);
+    HybridLexHeader *d_hdr = reinterpret_cast<HybridLexHeader *>(d_nsel + 8);
     uint32_t *d_lrow = d_nsel + 10;
     float *d_lscore = reinterpret_cast<float *>(d_lrow + n_lex);
-    float *d_lcos = d_lscore + n_lex;
-    float *d_cand = d_lcos + n_lex;
-    const size_t q_bytes = static_cast<size_t>(ix->q_pitch) * sizeof(float);
-    const size_t lex_bytes = src.dev ? 0 : 8 + static_cast<size_t>(n_lex) * 8; // header | rows | scores, one copy
-    const size_t out_words = 4ull * k_cap + 2;
-    RLR_TRY(pin_reserve(c, q_bytes + lex_bytes + out_words * 4 + 64));
-    float *h_q = static_cast<float *>(c->h_pin);
-    uint32_t *h_lex = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + q_bytes);
-    uint32_t *h_out = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + q_bytes + lex_bytes);
-    std::memset(h_q, 0, q_bytes);
-    std::memcpy(h_q, query, ix->dim * sizeof(float));
-    if (!src.dev) {
+    float *d_lcos = d_lscore + t->n_lex_bound;
+    float *d_cand = d_lcos + t->n_lex_bound;
+    uint32_t *h_lex = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + t->q_bytes);
+    uint32_t *h_out = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + t->q_bytes + t->lex_bytes_cap);
+    if (src.dev) { // the BM25 kernels ran beside the scan on their own stream: join, then unpack their result
+        RLR_HIP(hipStreamWaitEvent(s, static_cast<hipEvent_t>(src.dev->ready), 0));
+        hipLaunchKernelGGL(lex_unpack_kernel, dim3((n_lex + 255) / 256), dim3(256), 0, s, src.dev->d_packed, src.dev->d_count,
+                           std::min(n_lex, src.dev->limit), n, d_lrow, d_lscore, d_hdr);
+        RLR_HIP(hipGetLastError());
+    } else {
+        for (uint32_t i = 0; i < n_lex; ++i)
+            if (src.h_rows[i] >= n || (i && src.h_rows[i] <= src.h_rows[i - 1]))
+                return fail(RLR_E_INVALID, "lex_rows must be ascending, unique and inside the index");
         h_lex[0] = n_lex;
         h_lex[1] = __builtin_bit_cast(uint32_t, src.max_lex);
         for (uint32_t i = 0; i < n_lex; ++i)
             h_lex[2 + i] = static_cast<uint32_t>(src.h_rows[i]);
         if (n_lex)
             std::memcpy(h_lex + 2 + n_lex, src.h_scores, static_cast<size_t>(n_lex) * sizeof(float));
+        // header, rows, scores are adjacent on both sides
+        RLR_HIP(hipMemcpyAsync(d_hdr, h_lex, 8 + static_cast<size_t>(n_lex) * 8, hipMemcpyHostToDevice, s));
     }
-    stage_query_norms(ix, c, query, 1);
-    c->hist_dirty = true;
-    const bool timed = ix->profiling;
-    RLR_HIP(hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s));
-    if (!src.dev)
-        RLR_HIP(hipMemcpyAsync(d_hdr, h_lex, lex_bytes, hipMemcpyHostToDevice, s)); // header, rows, scores are adjacent
-    uint64_t *d_meta = c->d_out + fetch;
-    RLR_HIP(enqueue_query(ix, c, 0, p, c->d_out, d_meta, timed));
-    if (timed) RLR_HIP(hipEventRecord(c->bev[0], s));
-    if (src.dev) { // the BM25 kernels ran beside the scan on their own stream: join, then unpack their result
-        RLR_HIP(hipStreamWaitEvent(s, static_cast<hipEvent_t>(src.dev->ready), 0));
-        hipLaunchKernelGGL(rlr::lex_unpack_kernel, dim3((n_lex + 255) / 256), dim3(256), 0, s, src.dev->d_packed, src.dev->d_count,
-                           n_lex, n, d_lrow, d_lscore, d_hdr);
-        RLR_HIP(hipGetLastError());
-    }
-    RLR_HIP(rlr::launch_score_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_query, d_lrow, n_lex, d_lcos, s,
-                                   src.dev ? &d_hdr->n_lex : nullptr, n));
-    hipLaunchKernelGGL(rlr::hybrid_pool_kernel, dim3(1), dim3(1024), 0, s, c->d_out, fetch, need, n, w_embedding, w_lexical, d_lrow,
+    RLR_HIP(launch_score_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_query, d_lrow, n_lex, d_lcos, s,
+                              src.dev ? &d_hdr->n_lex : nullptr, n));
+    hipLaunchKernelGGL(hybrid_pool_kernel, dim3(1), dim3(1024), 0, s, c->d_out, t->fetch, t->need, n, t->w_e, t->w_l, d_lrow,
                        d_lscore, d_lcos, d_hdr, d_cand, c->d_list, d_comb, d_cos, d_lexv, d_info);
     RLR_HIP(hipGetLastError());
-    if (diversify) {
+    if (t->diversify) {
         RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
-        RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, k, lambda, d_order, d_mmr, d_nsel, d_info, 1, s));
+        RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, t->k, t->lambda, d_order, d_mmr, d_nsel, d_info, 1, s));
     }
-    hipLaunchKernelGGL(rlr::hybrid_emit_kernel, dim3(1), dim3(256), 0, s, c->d_list, d_comb, d_cos, d_lexv,
-                       diversify ? d_order : nullptr, diversify ? d_nsel : nullptr, d_info, k_cap, h_out);
+    hipLaunchKernelGGL(hybrid_emit_kernel, dim3(1), dim3(256), 0, s, c->d_list, d_comb, d_cos, d_lexv,
+                       t->diversify ? d_order : nullptr, t->diversify ? d_nsel : nullptr, d_info, k_cap, h_out);
     RLR_HIP(hipGetLastError());
-    if (timed) RLR_HIP(hipEventRecord(c->bev[1], s));
+    if (t->timed) RLR_HIP(hipEventRecord(c->bev[1], s));
+    drain.armed = false;
     RLR_HIP(hipStreamSynchronize(s));
     RLR_TRY(check_hist_assert(c));
     c->hist_dirty = false;
@@ -2406,7 +2458,7 @@ static int32_t search_hybrid_impl(rlr_index *ix, const float *query, uint32_t ne
     {
         std::lock_guard<std::mutex> lk(ix->mu);
         ix->prof.n_searches += 1;
-        if (timed) {
+        if (t->timed) {
             float a = 0, b = 0, d = 0, m = 0;
             (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
             (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
@@ -2436,18 +2488,59 @@ static int32_t search_hybrid_impl(rlr_index *ix, const float *query, uint32_t ne
     return RLR_OK;
 }
 
+int32_t search_hybrid_begin(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
+                            float w_embedding, float w_lexical, uint32_t n_lex_bound, float guard_eps, HybridTicket **ticket,
+                            int32_t *fallback)
+{
+    return hybrid_begin_impl(ix, query, need, k, lambda, diversify, w_embedding, w_lexical, n_lex_bound, guard_eps, ticket,
+                             fallback);
+}
+
+int32_t search_hybrid_finish(HybridTicket *ticket, const LexPending *lex, uint64_t *rows_out, float *cos_out, float *score_out,
+                             float *lex_out, uint32_t *n_out, int32_t *fallback)
+{
+    HybridLexSrc src;
+    if (lex && lex->limit)
+        src.dev = lex; // else: no lexical pair at all -- the blend degenerates to w_e * cos + w_l * 0
+    return hybrid_finish_impl(ticket, src, rows_out, cos_out, score_out, lex_out, n_out, fallback);
+}
+
+void search_hybrid_abort(HybridTicket *ticket)
+{
+    if (!ticket)
+        return;
+    (void)hipStreamSynchronize(ticket->lease.c->stream);
+    delete ticket;
+}
+
+} // namespace rlr
+
+extern "C" {
+
 int32_t rlr_search_hybrid(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
                           float w_embedding, float w_lexical, const uint64_t *lex_rows, const float *lex_scores, uint32_t n_lex,
                           float max_lex, float guard_eps, uint64_t *rows_out, float *cos_out, float *score_out, float *lex_out,
                           uint32_t *n_out, int32_t *fallback)
 {
+    RLR_TRY(check_handle(ix));
+    if (!n_out || !fallback)
+        return fail(RLR_E_INVALID, "n_out / fallback is null");
+    *n_out = 0;
+    *fallback = 0;
+    if (ix->n_rows == 0 || need == 0)
+        return RLR_OK;
+    if (!query || !rows_out || !cos_out || !score_out || !lex_out || (n_lex && (!lex_rows || !lex_scores)))
+        return fail(RLR_E_INVALID, "null argument");
+    rlr::HybridTicket *t = nullptr;
+    RLR_TRY(rlr::hybrid_begin_impl(ix, query, need, k, lambda, diversify, w_embedding, w_lexical, n_lex, guard_eps, &t, fallback));
+    if (*fallback)
+        return RLR_OK;
     HybridLexSrc src;
     src.h_rows = lex_rows;
     src.h_scores = lex_scores;
     src.n_host = n_lex;
     src.max_lex = max_lex;
-    return search_hybrid_impl(ix, query, need, k, lambda, diversify, w_embedding, w_lexical, src, guard_eps, rows_out, cos_out,
-                              score_out, lex_out, n_out, fallback);
+    return rlr::hybrid_finish_impl(t, src, rows_out, cos_out, score_out, lex_out, n_out, fallback);
 }
 
 // Batched MMR over P-strided pools.  The pool rows either live in the index (pool_rows != null:
@@ -2600,19 +2693,3 @@ int32_t rlr_profile_read(rlr_index *ix, rlr_profile *out, int32_t reset)
 }
 
 } // extern "C"
-
-namespace rlr {
-
-// rlr_search_hybrid with the lexical pairs taken from a BM25 scoring call that is still in flight on its own stream
-// (lexical_enqueue): this search's stream joins it by event after the scan, so the two run side by side on the device.
-int32_t search_hybrid_device(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
-                             float w_embedding, float w_lexical, const LexPending *lex, float guard_eps, uint64_t *rows_out,
-                             float *cos_out, float *score_out, float *lex_out, uint32_t *n_out, int32_t *fallback)
-{
-    HybridLexSrc src;
-    src.dev = lex;
-    return search_hybrid_impl(ix, query, need, k, lambda, diversify, w_embedding, w_lexical, src, guard_eps, rows_out, cos_out,
-                              score_out, lex_out, n_out, fallback);
-}
-
-} // namespace rlr

@@ -31,9 +31,16 @@ int32_t lexical_fetch(LexPending *p, uint64_t *rows_out, float *scores_out, uint
 // ok = false: something failed after the enqueue -- the workspace is re-zeroed before its next use
 void lexical_finish(LexPending *p, bool ok);
 
-// index.hip: rlr_search_hybrid (include/rlr_gpu.h) with the lexical pairs of `lex` instead of host arrays
-int32_t search_hybrid_device(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
-                             float w_embedding, float w_lexical, const LexPending *lex, float guard_eps, uint64_t *rows_out,
-                             float *cos_out, float *score_out, float *lex_out, uint32_t *n_out, int32_t *fallback);
+// index.hip: rlr_search_hybrid (include/rlr_gpu.h) in two enqueues, so that the BM25 kernels can be launched in between:
+// begin puts the scan .. sort of the need + n_lex_bound + 8 best rows by cosine on the index' stream (*fallback != 0: not
+// covered by the fused kernels, no ticket); finish joins `lex` (null or limit 0: no lexical pair) by event, enqueues
+// blend .. results, synchronises and consumes the ticket; abort drains and frees a ticket that will not be finished.
+struct HybridTicket;
+int32_t search_hybrid_begin(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
+                            float w_embedding, float w_lexical, uint32_t n_lex_bound, float guard_eps, HybridTicket **ticket,
+                            int32_t *fallback);
+int32_t search_hybrid_finish(HybridTicket *ticket, const LexPending *lex, uint64_t *rows_out, float *cos_out, float *score_out,
+                             float *lex_out, uint32_t *n_out, int32_t *fallback);
+void search_hybrid_abort(HybridTicket *ticket);
 
 } // namespace rlr

@@ -159,6 +159,12 @@ int32_t rlr_search_hybrid(rlr_index *, const float *, uint32_t, uint32_t, float,
 } // extern "C"
 
 // the GPU lexical index and the fused text search do not exist in the host build either
+extern "C" int32_t rlr_lexical_score(rlr_lexical *, const char *, size_t, uint32_t, uint64_t *, float *, uint32_t *n_out)
+{
+    *n_out = 0; // "no document matches": rlr_engine_search_text then runs the embedding-only host path
+    return RLR_OK;
+}
+
 #include "../../rust-local-rag_amd/csrc/lexical_internal.h"
 namespace rlr {
 int32_t lexical_enqueue(rlr_lexical *, const char *, size_t, uint32_t, LexPending *out)
@@ -172,11 +178,19 @@ int32_t lexical_fetch(LexPending *, uint64_t *, float *, uint32_t *n_out)
     return RLR_OK;
 }
 void lexical_finish(LexPending *, bool) {}
-int32_t search_hybrid_device(rlr_index *, const float *, uint32_t, uint32_t, float, int32_t, float, float, const LexPending *, float,
-                             uint64_t *, float *, float *, float *, uint32_t *n_out, int32_t *fallback)
+int32_t search_hybrid_begin(rlr_index *, const float *, uint32_t, uint32_t, float, int32_t, float, float, uint32_t, float,
+                            HybridTicket **ticket, int32_t *fallback)
+{
+    *ticket = nullptr;
+    *fallback = 1;
+    return RLR_OK;
+}
+int32_t search_hybrid_finish(HybridTicket *, const LexPending *, uint64_t *, float *, float *, float *, uint32_t *n_out,
+                             int32_t *fallback)
 {
     *n_out = 0;
     *fallback = 1;
     return RLR_OK;
 }
+void search_hybrid_abort(HybridTicket *) {}
 } // namespace rlr

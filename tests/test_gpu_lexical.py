@@ -270,3 +270,67 @@ def test_bm25_appends_rebuild_only_the_appended_segment(rlr):
     seg = g.segments()
     assert seg["full_rebuilds"] == 4 and seg["appended_postings"] == 0
     g.close()
+
+
+def test_engine_search_text_fused_and_fallback_paths(rlr, oracle):
+    """rlr_engine_search_text (RagEngine.search / search_with_diversity with the query text): BM25 beside the scan, blend,
+    cut and MMR on the device.  Against the oracle's search given the oracle's BM25 pairs, over plain / stage-1 /
+    diversified searches, weight overrides (w_embedding = 0 takes the host path), a top_k whose pool exceeds the fused
+    kernels (host path), unknown words (embedding-only), duplicated rows (exact cosine ties) and NaN rows."""
+    n, dim = 5000, 128
+    texts = make_texts(n, seed=31, lo=4, hi=25)
+    rows = oracle.synth_rows(n, dim, seed=32)
+    rows[100:140] = rows[7]                      # exact duplicates: cosine ties across lexical and non-lexical rows
+    rows[2000, 5] = np.nan                       # a NaN row scores NaN and orders last
+    eng = rlr.RagEngine(dim)
+    eng.add_document("d", texts, rows)
+    stored = eng.index.fetch_rows(np.arange(n))
+    o = OL.LexicalIndex()
+    for r, t in enumerate(texts):
+        o.add_chunk(r, t, rank=r)
+    qs = [oracle.synth_query(dim, seed=33 + i) for i in range(3)] + [rows[7].copy()]
+    cases = [
+        # (text, top_k, diversity, stage, weights)
+        ("w000x w001x common", 10, 0.0, 0, None),
+        ("w000x w001x common", 10, 0.0, 1, None),
+        ("w017x frequent", 25, 0.3, 0, None),
+        ("the of w002x w003x w004x", 100, 0.7, 0, None),
+        ("w005x", 7, 1.0, 0, None),
+        ("nothing known here", 10, 0.5, 0, None),                                  # no lexical candidate at all
+        ("", 10, 0.0, 0, None),
+        ("w000x w010x", 10, 0.4, 0, dict(embedding=0.0, lexical=1.0)),             # w_e = 0: host path
+        ("w000x w010x", 10, 0.0, 0, dict(embedding=1.0, lexical=0.0)),
+        ("w000x w010x", 12, 0.2, 0, dict(embedding=0.25, lexical=0.75)),
+        ("w001x w002x", 400, 0.5, 0, None),                                        # pool 1200 > 1024: host path
+        ("w001x w002x", 0, 0.0, 0, None),                                          # top_k 0 is served as 1 (:490)
+    ]
+    for ci, (text, k, div, stage, wts) in enumerate(cases):
+        q = qs[ci % len(qs)]
+        w = rlr.QueryWeights(**wts) if wts else None
+        w_e, w_l = (wts["embedding"], wts["lexical"]) if wts else (0.7, 0.3)
+        lam = min(max(div, 0.0), 1.0)
+        k_eff = k if lam == 0.0 else max(3 * k, k + 10)
+        pairs = [(c, float(s)) for c, s in o.score(text, 5 * max(k_eff, 1), keep_zero=False)]
+        if lam == 0.0:
+            got = eng.search(q, k, weights=w, stage=stage, query_text=text)
+            wr, wc, we, wl = oracle.search(stored, q, k, w_e, w_l, lex=pairs, stage=stage)
+        else:
+            got = eng.search_with_diversity(q, k, div, weights=w, query_text=text)
+            wr, wc, we, wl = oracle.search_with_diversity(stored, q, k, div, w_e, w_l, lex=pairs)
+        ctx = (ci, text, k, div, stage, wts)
+        assert [g_.row for g_ in got] == list(wr), ctx
+        assert np.array_equal(bits([g_.score for g_ in got]), bits(wc)), ctx
+        assert np.array_equal(bits([g_.embedding_score for g_ in got]), bits(we)), ctx
+        assert np.array_equal(bits([g_.lexical_score for g_ in got]), bits(wl)), ctx
+    # the lexical index may run ahead of the embedding matrix (a chunk whose embedding is not stored yet): its rows
+    # still count for max_lexical (:515-519) and never become candidates
+    eng.lexical.add_chunk(n + 3, "zzzrare zzzrare zzzrare w399x")
+    o.add_chunk(n + 3, "zzzrare zzzrare zzzrare w399x", rank=n + 3)
+    pairs = [(c, float(s)) for c, s in o.score("zzzrare w399x", 50, keep_zero=False)]
+    assert pairs[0][0] == n + 3 and len(pairs) > 1          # the chunk without an embedding holds the largest BM25 score
+    got = eng.search(qs[0], 10, query_text="zzzrare w399x")
+    wr, wc, we, wl = oracle.search(stored, qs[0], 10, lex=pairs)
+    assert [g_.row for g_ in got] == list(wr)
+    assert np.array_equal(bits([g_.score for g_ in got]), bits(wc))
+    assert np.array_equal(bits([g_.lexical_score for g_ in got]), bits(wl))
+    eng.close()
