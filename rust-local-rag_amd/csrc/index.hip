@@ -803,31 +803,33 @@ struct HybridLexHeader {
     float max_lex; // max(lexical scores, f32::EPSILON) (rag_engine.rs:515-519)
 };
 
-// A scoring call's result list (pack_result(score, row), score desc) -> rows, scores, header.  Rows outside the index
+// A scoring call's result (pack_result(score, row) keys, in any order) -> rows, scores, header.  Rows outside the index
 // (a lexical index that ran ahead of the embedding matrix) keep their place but are marked: they still count for
-// max_lexical, as in the reference, and never become candidates.
-__global__ __launch_bounds__(256) void lex_unpack_kernel(const uint64_t *__restrict__ packed, const uint32_t *__restrict__ count,
-                                                         uint32_t limit, uint32_t n_rows, uint32_t *__restrict__ lrow,
-                                                         float *__restrict__ lscore, HybridLexHeader *__restrict__ hdr)
+// max_lexical, as in the reference, and never become candidates.  One workgroup (<= kHybridLexMax pairs).
+__global__ __launch_bounds__(1024) void lex_unpack_kernel(const uint64_t *__restrict__ packed, const uint32_t *__restrict__ count,
+                                                          uint32_t limit, uint32_t n_rows, uint32_t *__restrict__ lrow,
+                                                          float *__restrict__ lscore, HybridLexHeader *__restrict__ hdr)
 {
+    __shared__ uint32_t s_max;
+    if (threadIdx.x == 0)
+        s_max = 0;
+    __syncthreads();
     const uint32_t n = min(*count, limit);
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    uint32_t mx = 0; // largest ordered score key: fold(0.0, f32::max) over the scores (:515-519)
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         float sc;
         uint32_t row;
         unpack_result(packed[i], &sc, &row);
         lrow[i] = row < n_rows ? row : 0xFFFFFFFFu;
         lscore[i] = sc;
+        mx = max(mx, static_cast<uint32_t>(packed[i] >> 32));
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {
         hdr->n_lex = n;
-        float mx = 0.0f; // fold(0.0, f32::max) over a list that is sorted descending: its first entry
-        if (n) {
-            float sc;
-            uint32_t row;
-            unpack_result(packed[0], &sc, &row);
-            mx = fmaxf(mx, sc);
-        }
-        hdr->max_lex = mx >= 1.1920929e-07f ? mx : 1.1920929e-07f;
+        const float m = s_max ? fmaxf(0.0f, key_score(s_max)) : 0.0f; // NaN scores (key 0) are ignored like f32::max does
+        hdr->max_lex = m >= 1.1920929e-07f ? m : 1.1920929e-07f;
     }
 }
 
@@ -2421,7 +2423,7 @@ static int32_t hybrid_finish_impl(HybridTicket *ticket, const HybridLexSrc &src,
     uint32_t *h_out = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + t->q_bytes + t->lex_bytes_cap);
     if (src.dev) { // the BM25 kernels ran beside the scan on their own stream: join, then unpack their result
         RLR_HIP(hipStreamWaitEvent(s, static_cast<hipEvent_t>(src.dev->ready), 0));
-        hipLaunchKernelGGL(lex_unpack_kernel, dim3((n_lex + 255) / 256), dim3(256), 0, s, src.dev->d_packed, src.dev->d_count,
+        hipLaunchKernelGGL(lex_unpack_kernel, dim3(1), dim3(1024), 0, s, src.dev->d_packed, src.dev->d_count,
                            std::min(n_lex, src.dev->limit), n, d_lrow, d_lscore, d_hdr);
         RLR_HIP(hipGetLastError());
     } else {

@@ -117,17 +117,6 @@ __global__ __launch_bounds__(256) void bm25_term_kernel(const uint32_t *__restri
     }
 }
 
-__global__ __launch_bounds__(256) void lex_pack_kernel(const float *__restrict__ scores,
-                                                       const uint32_t *__restrict__ touched,
-                                                       const LexControl *__restrict__ ctl, uint64_t *__restrict__ keys)
-{
-    const uint32_t n = ctl->n_touched;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t row = touched[i];
-        keys[i] = pack_result(scores[row], row);
-    }
-}
-
 // bitonic sort (descending) of n_pad keys in LDS, n_pad a power of two <= kMaxLimit
 __device__ inline void lds_sort_desc(uint64_t *s, uint32_t n_pad)
 {
@@ -215,8 +204,12 @@ __device__ inline void lex_derive_state(const LexControl *ctl, uint32_t limit, i
     *k_rem = s_k;
 }
 
-__global__ __launch_bounds__(256) void lex_select_pass_kernel(const uint64_t *__restrict__ keys, LexControl *__restrict__ ctl,
-                                                              uint32_t limit, int pass)
+// PACK (pass 0 only): the keys do not exist yet -- build them from the accumulators on the way (this used to be a
+// launch of its own in front of the eight passes).
+template <bool PACK>
+__global__ __launch_bounds__(256) void lex_select_pass_kernel(uint64_t *__restrict__ keys, LexControl *__restrict__ ctl,
+                                                              uint32_t limit, int pass, const float *__restrict__ scores,
+                                                              const uint32_t *__restrict__ touched)
 {
     __shared__ uint32_t s_h[256];
     uint64_t prefix;
@@ -231,7 +224,14 @@ __global__ __launch_bounds__(256) void lex_select_pass_kernel(const uint64_t *__
     const uint32_t n = ctl->n_touched;
     const int shift = 56 - 8 * pass;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint64_t key = keys[i];
+        uint64_t key;
+        if constexpr (PACK) {
+            const uint32_t row = touched[i];
+            key = pack_result(scores[row], row);
+            keys[i] = key;
+        } else {
+            key = keys[i];
+        }
         const bool match = pass == 0 || (key >> (shift + 8)) == prefix;
         if (match)
             atomicAdd(&s_h[(key >> shift) & 0xFF], 1u);
@@ -751,7 +751,7 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     if (len && !query_tokens)
         return set_error(RLR_E_INVALID, "query_tokens is null");
     rlr::LexPending p;
-    LEX_TRY(rlr::lexical_enqueue(lx, query_tokens, len, limit, &p));
+    LEX_TRY(rlr::lexical_enqueue(lx, query_tokens, len, limit, &p, /*need_sorted=*/true));
     if (p.limit == 0) // empty index, no tokens, or no term of the query is known (:2170-2177, :2196)
         return RLR_OK;
     int32_t st = RLR_OK;
@@ -815,7 +815,8 @@ struct PendingGuard { // releases whatever lexical_enqueue had taken when it fai
 };
 } // namespace
 
-int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, LexPending *out)
+int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, LexPending *out,
+                        bool need_sorted)
 {
     *out = LexPending{};
     out->lx = lx;
@@ -885,6 +886,9 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     const float avg = static_cast<float>(lx->total_length) / n_docs; // :2184-2188
     hipStream_t s = ws->stream;
     ws->dirty = true; // cleared by lexical_finish(ok) once the whole pipeline has run
+    // the control block (counters, histograms) is zeroed in front of a call, not behind it: its counts stay readable
+    // for a consumer on another stream until the workspace is handed back
+    LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), s));
     const uint32_t max_blocks = static_cast<uint32_t>(lx->n_cu) * 8;
     for (uint32_t t : terms) {
         const float df = static_cast<float>(lx->df[t]);
@@ -909,28 +913,35 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     LEX_HIP(hipGetLastError());
     uint32_t *d_out_n = reinterpret_cast<uint32_t *>(ws->d_out + kMaxLimit);
     const uint32_t blocks_u = std::min<uint32_t>(static_cast<uint32_t>((upper + 255) / 256), max_blocks);
+    const uint64_t *d_result = ws->d_out;
+    const uint32_t *d_result_n = d_out_n;
     if (upper <= kMaxLimit) {
         hipLaunchKernelGGL(lex_sort_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, nullptr, ws->d_ctl,
                            lim, ws->d_out, d_out_n);
     } else {
         LEX_TRY(dev_grow(&ws->d_keys, &ws->keys_cap, upper));
-        hipLaunchKernelGGL(lex_pack_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl,
-                           ws->d_keys);
-        for (int p = 0; p < kPasses; ++p)
-            hipLaunchKernelGGL(lex_select_pass_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, p);
+        hipLaunchKernelGGL(lex_select_pass_kernel<true>, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, 0,
+                           ws->d_scores, ws->d_touched);
+        for (int p = 1; p < kPasses; ++p)
+            hipLaunchKernelGGL(lex_select_pass_kernel<false>, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, p,
+                               nullptr, nullptr);
         hipLaunchKernelGGL(lex_collect_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, ws->d_sel);
-        hipLaunchKernelGGL(lex_sort_kernel<false>, dim3(1), dim3(1024), 0, s, nullptr, nullptr, ws->d_sel, ws->d_ctl, lim,
-                           ws->d_out, d_out_n);
+        if (need_sorted) {
+            hipLaunchKernelGGL(lex_sort_kernel<false>, dim3(1), dim3(1024), 0, s, nullptr, nullptr, ws->d_sel, ws->d_ctl, lim,
+                               ws->d_out, d_out_n);
+        } else { // the consumer (the hybrid blend) wants the set, not its order: one LDS sort less on the critical path
+            d_result = ws->d_sel;
+            d_result_n = &ws->d_ctl->n_sel;
+        }
     }
     LEX_HIP(hipGetLastError());
     LEX_HIP(hipEventRecord(ws->ready, s)); // the result list is complete here; the clean-up below runs behind it
     hipLaunchKernelGGL(lex_clear_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl);
     LEX_HIP(hipGetLastError());
-    LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), s));
     out->stream = s;
     out->ready = ws->ready;
-    out->d_packed = ws->d_out;
-    out->d_count = d_out_n;
+    out->d_packed = d_result;
+    out->d_count = d_result_n;
     out->limit = lim;
     guard.armed = false;
     return RLR_OK;

@@ -17,14 +17,16 @@ struct LexPending {
     void *ws = nullptr;                 // the leased workspace
     void *stream = nullptr;             // hipStream_t: its stream; `ready` is recorded there behind the last kernel
     void *ready = nullptr;              // hipEvent_t (opaque here: csrc/engine.cpp is built without the HIP headers)
-    const uint64_t *d_packed = nullptr; // pack_result(score, row), (score desc, row asc); RLR_LEXICAL_MAX_LIMIT entries
+    const uint64_t *d_packed = nullptr; // pack_result(score, row) keys, the best `*d_count` by (score desc, row asc)
     const uint32_t *d_count = nullptr;  // how many of them are valid (<= limit)
     uint32_t limit = 0;                 // 0: no document can match (empty index / unknown terms) -- nothing was enqueued
     bool locked = false;
 };
 
 // LexicalIndex::score (rag_engine.rs:2169-2225) up to the ordered result list in device memory.  No synchronisation.
-int32_t lexical_enqueue(rlr_lexical *lx, const char *tokens, size_t len, uint32_t limit, LexPending *out);
+// need_sorted = false: d_packed holds the same set in no particular order (saves the final LDS sort; lexical_fetch
+// needs the sorted form)
+int32_t lexical_enqueue(rlr_lexical *lx, const char *tokens, size_t len, uint32_t limit, LexPending *out, bool need_sorted);
 // copy the result to the host (synchronises the scoring stream); valid between enqueue and finish
 int32_t lexical_fetch(LexPending *p, uint64_t *rows_out, float *scores_out, uint32_t *n_out);
 // hand the workspace back once every consumer of d_packed has finished (the caller synchronised them);
