@@ -373,6 +373,35 @@ def test_mmr_select_values_bit_exact(rlr, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("P", [129, 200, 256, 257, 300, 512, 513, 700, 768, 769, 1000, 1024])
+def test_mmr_single_pool_sizes_and_awkward_relevance(rlr, oracle, P):
+    """pool sizes around every per-lane slot count of the register-resident greedy kernel, relevance with ties / zeros of
+    both signs / non-finite values, duplicated rows (similarity ties), every lambda regime -- bit-equal picks and logged MMR
+    values, single call and batch entry point alike"""
+    dim = 96
+    rows = oracle.synth_rows(P + 50, dim, seed=7000 + P, n_clusters=6)
+    rows[10:20] = rows[3]                                   # exact duplicates inside the pool
+    ix = make_index(rlr, rows)
+    rng = np.random.default_rng(P)
+    pool = rng.permutation(P + 50)[:P].astype(np.uint64)
+    for lam, kk in ((0.3, 100), (0.0, 40), (1.0, 25), (0.7, P)):
+        sc = (rng.standard_normal(P) * 0.2).astype(np.float32)
+        sc[rng.integers(0, P, 12)] = sc[0]                  # relevance ties
+        sc[rng.integers(0, P, 3)] = 0.0
+        sc[rng.integers(0, P, 3)] = -0.0
+        if lam != 0.7:
+            sc[rng.integers(1, P, 2)] = np.nan              # non-finite relevance is never picked ...
+            sc[rng.integers(1, P, 1)] = np.inf
+            sc[rng.integers(1, P, 1)] = -np.inf
+        o, m = ix.mmr_select(pool, sc, kk, lam)
+        wo, wm = oracle.mmr(rows[pool.astype(np.int64)], sc, kk, lam)
+        assert np.array_equal(o, wo), (P, lam, kk)
+        assert np.array_equal(bits(m[1:]), bits(wm[1:])), (P, lam, kk)
+        ob, mb, nb = ix.mmr_select_batch(np.tile(pool, (8, 1)), np.tile(sc, (8, 1)), np.full(8, P, np.uint32), kk, lam)
+        assert nb[5] == len(o) and np.array_equal(ob[5][: nb[5]], o) and np.array_equal(bits(mb[5][1: nb[5]]), bits(m[1:]))
+    ix.close()
+
+
 def test_search_documents_defaults_and_caps(rlr, oracle):
     rows = oracle.synth_rows(2000, 768, seed=95)
     eng, _ = build_engine(rlr, rows)
