@@ -502,22 +502,21 @@ __global__ __launch_bounds__(64) void gram_kernel(const float *__restrict__ pool
 // chunks in ascending k, so each sum is still the reference's strict left-to-right chain.  Reads
 // each pool row 2 x ceil(P/32) times from L2 instead of P times: 27 -> ~8 us per 300-row pool and
 // ~5x on the batched MMR.
-constexpr int kGK = 64;      // columns per staged chunk
-constexpr int kGPitch = 68;  // floats
 
 // R = side of the per-thread register tile of pairs: a workgroup (16 x 16 threads) owns a (16 R) x (16 R) block.
-// R = 2 (32 x 32 blocks, 55 of them for a 300-row pool) keeps many CUs busy for a single query; R = 4 (64 x 64)
-// halves the LDS reads per multiply (8 float4 per 64 products instead of 4 per 16) and is used for batches, where
-// there are thousands of blocks anyway: 3.7 -> see DESIGN.md for 1024 pools of 300 x 1024-d.
+// R = 1 (16 x 16 blocks, 210 of them for a 300-row pool) fills the chip for a single query; R = 2 (32 x 32) for larger
+// single pools; R = 4 (64 x 64) halves the LDS reads per multiply (8 float4 per 64 products instead of 4 per 16) and is
+// used for batches, where there are thousands of blocks anyway (launch_gram_src picks).  GK = columns per staged chunk.
 // SRC 0: `pool` is a dense P x dim f32 matrix per query.  SRC 1 / 2: the pool rows are read straight from the index
 // (f32 / binary16 rows, widened exactly) through the query's row list -- no gathered f32 copy in between: config 5's
 // share used to write and re-read 1.26 GB of it per 1024 pools.
-template <int R, int SRC>
+template <int R, int SRC, int GK>
 __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict__ pool, uint32_t P, uint32_t dim,
                                                          float *__restrict__ gram, const void *__restrict__ rows,
                                                          uint32_t pitch16, const uint32_t *__restrict__ list)
 {
     constexpr int kGT = 16 * R; // pairs per block side
+    constexpr int kGK = GK, kGPitch = GK + 4; // columns per staged chunk; row pitch in floats (pad: no bank conflicts)
     __shared__ __attribute__((aligned(16))) float sa[kGT * kGPitch];
     __shared__ __attribute__((aligned(16))) float sb[kGT * kGPitch];
     if constexpr (SRC == 0)
@@ -1071,12 +1070,22 @@ static hipError_t launch_gram_src(const float *pool, uint32_t P, uint32_t dim, f
 {
     if (n_queries >= 8) {
         const uint32_t nb = (P + 63) / 64;
-        hipLaunchKernelGGL((gram_tiled_kernel<4, SRC>), dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim,
+        hipLaunchKernelGGL((gram_tiled_kernel<4, SRC, 64>), dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim,
                            gram, rows, pitch16, list);
     } else {
-        const uint32_t nb = (P + 31) / 32;
-        hipLaunchKernelGGL((gram_tiled_kernel<2, SRC>), dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim,
-                           gram, rows, pitch16, list);
+        // a single pool (or a few): the tile size that keeps the most CUs busy.  A 300-row pool is 55 blocks of 32 x 32
+        // pairs -- 55 of 256 CUs, one wave per SIMD, every k-step waiting for its LDS fragments -- or 210 blocks of
+        // 16 x 16 (one pair per thread): 31 -> 17 us at 768-d.  The small tile wins until its blocks outnumber the
+        // CUs about six times (measured: 800-row pools still, 1024-row pools no longer; 7 pools of 300 still).
+        const uint32_t nb1 = (P + 15) / 16;
+        if (static_cast<uint64_t>(nb1) * (nb1 + 1) / 2 * n_queries <= 1536) {
+            hipLaunchKernelGGL((gram_tiled_kernel<1, SRC, 128>), dim3(nb1 * (nb1 + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P,
+                               dim, gram, rows, pitch16, list);
+        } else {
+            const uint32_t nb = (P + 31) / 32;
+            hipLaunchKernelGGL((gram_tiled_kernel<2, SRC, 64>), dim3(nb * (nb + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P, dim,
+                               gram, rows, pitch16, list);
+        }
     }
     return hipGetLastError();
 }
