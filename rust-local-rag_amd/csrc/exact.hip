@@ -789,35 +789,31 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
     if (threadIdx.x >= 64)
         return;
     const uint32_t lane = threadIdx.x;
-    // The loop body is written branch-free (selects on per-candidate flags): with `continue`s hipcc builds a
-    // saveexec / branch ladder per candidate, and one wave alone on its SIMD pays every one of those at ~5 cycles per
-    // instruction -- the chain took 1.07 us per pick, about two thirds of it control flow.
-    float t0[J], ms[J];          // (1 - lambda) * relevance (loop invariant), running max similarity
-    uint32_t pos[J], idx[J];     // position in the reference's `remaining`; clamped Gram column of the candidate
-    bool alive[J], rel_ok[J];
+    // The loop body is written branch-free (selects, no `continue`): with branches hipcc builds a saveexec / branch
+    // ladder per candidate, and one wave alone on its SIMD pays every one of those at ~5 cycles per instruction -- the
+    // chain took 1.07 us per pick, about two thirds of it control flow.  There are no per-candidate flags either
+    // (hipcc packs bool arrays into bytes and unpacks them every pick): a slot that is empty or already picked carries
+    // t0 = NaN, so its MMR value is never finite and never a candidate, and position ~0, which no live position
+    // equals; a relevance that is not finite makes t0, hence the MMR value, non-finite by itself (`rel.is_finite()`).
+    float t0[J], ms[J];          // (1 - lambda) * relevance (loop invariant; NaN = not selectable), running max similarity
+    uint32_t pos[J], idx[J];     // position in the reference's `remaining` (~0 = gone); clamped Gram column of the candidate
     const float one_minus = 1.0f - lambda;
+    const float nan_f = __builtin_bit_cast(float, 0x7FC00000u);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const uint32_t c = lane + 64 * j;
-        alive[j] = c < P;
         idx[j] = min(c, P - 1);
         const float r = scores[idx[j]];
-        rel_ok[j] = finite_f(r);
-        t0[j] = one_minus * r;
+        // selected.push(remaining.swap_remove(0)): candidate 0 goes first, the last one takes slot 0
+        const bool usable = (c < P) & (c != 0);
+        t0[j] = usable ? one_minus * r : nan_f;
         ms[j] = 0.0f;
-        pos[j] = c;
+        pos[j] = usable ? ((c == P - 1) ? 0u : c) : 0xFFFFFFFFu;
     }
-    // selected.push(remaining.swap_remove(0)): candidate 0 goes first, the last one takes slot 0
     uint32_t n_rem = P - 1, n_sel = 1, last = 0;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const uint32_t c = lane + 64 * j;
-        pos[j] = (alive[j] & (pos[j] == P - 1) & (c != 0)) ? 0u : pos[j];
-        alive[j] = alive[j] & (c != 0);
-    }
     if (lane == 0) {
         out_order[0] = 0;
-        out_mmr[0] = __builtin_bit_cast(float, 0x7FC00000u);
+        out_mmr[0] = nan_f;
     }
     const float neg_inf = -__builtin_inff();
     while (n_sel < k && n_rem > 0) {
@@ -825,21 +821,20 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
         float sim[J];
 #pragma unroll
         for (int j = 0; j < J; ++j)
-            sim[j] = g_last[idx[j]]; // dead candidates load a valid (clamped) column and ignore it
+            sim[j] = g_last[idx[j]]; // empty slots load a valid (clamped) column and ignore it
         float best_m = neg_inf;
         uint32_t best_pos = 0xFFFFFFFFu;
         float raw[J];
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const float up = fmaxf(ms[j], sim[j]);
-            ms[j] = finite_f(sim[j]) ? up : ms[j];
+            // `if sim.is_finite() { max_sim = max_sim.max(sim) }` on a max_sim that starts at +0.0 and is never NaN
+            const bool raise = finite_f(sim[j]) & (sim[j] > ms[j]);
+            ms[j] = raise ? sim[j] : ms[j];
             const float t1 = lambda * ms[j];
             const float m0 = t0[j] - t1;
-            const bool live = alive[j] & rel_ok[j];
-            raw[j] = live ? m0 : 0.0f;            // what the reference logs (sign of zero included)
+            raw[j] = m0;                            // what the reference logs for the winner (sign of zero included)
             const float m = m0 == 0.0f ? 0.0f : m0; // -0 and +0 compare equal in the reference
-            const bool cand = live & finite_f(m0);
-            const bool better = cand & ((m > best_m) | ((m == best_m) & (pos[j] < best_pos)));
+            const bool better = finite_f(m0) & ((m > best_m) | ((m == best_m) & (pos[j] < best_pos)));
             best_m = better ? m : best_m;
             best_pos = better ? pos[j] : best_pos;
         }
@@ -851,19 +846,17 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
         float win_raw = 0.0f;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const bool hit = alive[j] & (pos[j] == wp);
+            const bool hit = pos[j] == wp;
             win = hit ? lane + 64 * j + 1 : win;
             win_raw = hit ? raw[j] : win_raw;
-            alive[j] = alive[j] & !hit;
+            t0[j] = hit ? nan_f : t0[j];
+            // swap_remove(best_idx): the winner leaves, the candidate in the last slot moves into the freed one
+            pos[j] = hit ? 0xFFFFFFFFu : (pos[j] == n_rem - 1 ? wp : pos[j]);
         }
         // exactly one lane holds the winner: broadcast its candidate index
         const unsigned long long ball = __ballot(win != 0);
         const int src = __builtin_ctzll(ball);
         last = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(win), src)) - 1;
-        // swap_remove(best_idx): the candidate in the last slot moves into the freed one
-#pragma unroll
-        for (int j = 0; j < J; ++j)
-            pos[j] = (alive[j] & (pos[j] == n_rem - 1)) ? wp : pos[j];
         const float wm_raw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, win_raw), src));
         if (lane == 0) {
             out_order[n_sel] = last;
