@@ -92,6 +92,22 @@ __device__ inline float wave_max_f32(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// The same maximum for values that are never NaN: v_max_f32 with the DPP modifier on its own operand, one instruction per
+// step (the builtin form above is a v_mov_b32_dpp plus a canonicalising v_max_f32 pair, because fmaxf must quiet NaNs).
+// A lane whose DPP source is out of range is not written, i.e. keeps its value -- the identity of a maximum.
+__device__ inline float wave_max_f32_no_nan(float v)
+{
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ inline uint32_t dpp_umin(uint32_t v)
 {

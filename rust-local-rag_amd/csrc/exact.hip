@@ -833,12 +833,12 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
             const float t1 = lambda * ms[j];
             const float m0 = t0[j] - t1;
             raw[j] = m0;                            // what the reference logs for the winner (sign of zero included)
-            const float m = m0 == 0.0f ? 0.0f : m0; // -0 and +0 compare equal in the reference
-            const bool better = finite_f(m0) & ((m > best_m) | ((m == best_m) & (pos[j] < best_pos)));
-            best_m = better ? m : best_m;
+            // (-0 and +0 compare equal in the reference, and so they do in the float compares below)
+            const bool better = finite_f(m0) & ((m0 > best_m) | ((m0 == best_m) & (pos[j] < best_pos)));
+            best_m = better ? m0 : best_m;
             best_pos = better ? pos[j] : best_pos;
         }
-        const float wm = wave_max_f32(best_m);
+        const float wm = wave_max_f32_no_nan(best_m); // best_m is -inf or a finite MMR value
         if (wm == neg_inf) // no finite candidate left
             break;
         const uint32_t wp = wave_min_u32(best_m == wm ? best_pos : 0xFFFFFFFFu);
