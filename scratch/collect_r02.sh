@@ -22,6 +22,7 @@ run b256_sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 run b256_sq2 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/${TAG}_b256_sq2 -- $B256
 run b256_fetch --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_b256_fetch -- $B256
 run c2_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_c2_kt -- python3 $R/scratch/time_c2_abi.py
+run hyb_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_hyb_kt -- python3 $R/scratch/time_c2_hybrid.py hybrid-only
 run c5_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_c5_kt -- python3 $R/scratch/time_c5_shard.py --image
 run lex_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_lex_kt -- python3 $R/scratch/time_lexical.py 200000
 run multi8_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_multi8_kt -- python3 $R/bench.py --batch 8 --steps 20 --warmup 3 --no-cpu --settle-ms 0
