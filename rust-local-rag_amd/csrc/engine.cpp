@@ -473,7 +473,7 @@ int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *qu
             return st;
         if (!fb) {
             rlr::LexPending lp;
-            st = rlr::lexical_enqueue(lex, query_tokens, tokens_len, limit, &lp, /*need_sorted=*/false);
+            st = rlr::lexical_enqueue(lex, query_tokens, tokens_len, limit, &lp, /*need_sorted=*/false, /*exact_passes=*/false);
             if (st != RLR_OK) {
                 rlr::search_hybrid_abort(ticket);
                 return st;

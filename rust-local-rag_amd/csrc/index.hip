@@ -814,6 +814,13 @@ __global__ __launch_bounds__(1024) void lex_unpack_kernel(const uint64_t *__rest
     if (threadIdx.x == 0)
         s_max = 0;
     __syncthreads();
+    if (*count == kLexicalRetry) { // the BM25 selection handed the query back: so does the blend (info[1] = 3)
+        if (threadIdx.x == 0) {
+            hdr->n_lex = kLexicalRetry;
+            hdr->max_lex = 1.0f;
+        }
+        return;
+    }
     const uint32_t n = min(*count, limit);
     uint32_t mx = 0; // largest ordered score key: fold(0.0, f32::max) over the scores (:515-519)
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
@@ -855,6 +862,13 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
     __shared__ float s_cneed;
     const uint32_t t = threadIdx.x;
     float *cc = cand, *ce = cand + kHybridSlots, *cl = cand + 2 * kHybridSlots;
+    if (hdr->n_lex == kLexicalRetry) { // (uniform) no usable lexical pairs: the host path repeats the BM25 query exactly
+        if (threadIdx.x == 0) {
+            info[0] = 0;
+            info[1] = 3;
+        }
+        return;
+    }
     const uint32_t n_lex = min(hdr->n_lex, kHybridLexMax);
     const float max_lex = hdr->max_lex;
     if (t == 0) {

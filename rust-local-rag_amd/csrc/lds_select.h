@@ -63,4 +63,59 @@ __device__ inline uint32_t lds_kth_key(const uint64_t *s_c, uint32_t n, uint32_t
     return prefix;
 }
 
+// k-th largest full 64-bit key of s_c[0, n) (keys are unique where the caller needs exactly k winners): six radix
+// passes over LDS (11 x 5 + 9 bits), same structure as lds_kth_key.  All threads must call it.
+__device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32_t k, uint32_t *s_hist, uint32_t *s_sel,
+                                         uint32_t nthreads)
+{
+    uint64_t prefix = 0, mask = 0;
+    uint32_t rank = k;
+#pragma unroll 1
+    for (int pass = 0; pass < 6; ++pass) {
+        const uint32_t shift = pass < 5 ? 53u - 11u * pass : 0u;
+        const uint32_t nb = pass < 5 ? 2048u : 512u;
+        for (uint32_t i = threadIdx.x; i < nb; i += nthreads)
+            s_hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += nthreads) {
+            const uint64_t key = s_c[i];
+            if ((key & mask) == prefix)
+                atomicAdd(&s_hist[static_cast<uint32_t>(key >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t W = nb / 64, lane = threadIdx.x;
+            uint32_t mine = 0;
+            for (uint32_t b = 0; b < W; ++b)
+                mine += s_hist[lane * W + b];
+            uint32_t incl = mine; // sum over lanes >= lane
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_down(incl, d);
+                if (lane + d < 64)
+                    incl += o;
+            }
+            const uint32_t above = incl - mine;
+            if (above < rank && rank <= incl) {
+                uint32_t acc = above;
+                for (int b = static_cast<int>(W) - 1; b >= 0; --b) {
+                    const uint32_t h = s_hist[lane * W + b];
+                    if (rank <= acc + h) {
+                        s_sel[0] = lane * W + b;
+                        s_sel[1] = rank - acc;
+                        break;
+                    }
+                    acc += h;
+                }
+            }
+        }
+        __syncthreads();
+        prefix |= static_cast<uint64_t>(s_sel[0]) << shift;
+        mask |= static_cast<uint64_t>(nb - 1) << shift;
+        rank = s_sel[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
 } // namespace rlr

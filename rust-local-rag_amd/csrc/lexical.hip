@@ -11,17 +11,21 @@
 //                      launch, so the f32 sum order is the term order -- deterministic); rows
 //                      whose sum becomes positive are appended to a compact "touched" list
 //                      (wave-aggregated atomics);
-//   <= 8192 postings   lex_sort_touched_kernel: packed (score, row) keys sorted in LDS;
-//   more               lex_pack_kernel + 8 x lex_select_pass_kernel (MSD radix select, 8-bit
-//                      digits over the unique 64-bit keys -- exact under massive score ties,
-//                      which BM25 produces whenever tf and document length repeat) +
-//                      lex_collect_kernel + lex_sort_sel_kernel;
+//   <= 8192 postings   lex_sort_kernel: packed (score, row) keys sorted in LDS;
+//   more, limit <= 4096  sampled selection, 3 launches: lex_sample_kernel (threshold key from a strided sample),
+//                      lex_filter_kernel (one pass, ~1.5 limit candidates), lex_final_kernel (exact limit-th key
+//                      among them by an LDS radix select); hands the query to the exact path when the candidate
+//                      list overflows or comes out short (< 1e-5 per query);
+//   otherwise / retry  8 x lex_select_pass_kernel (MSD radix select, 8-bit digits over the unique 64-bit keys --
+//                      exact under massive score ties, which BM25 produces whenever tf and document length
+//                      repeat; the first pass packs the keys) + lex_collect_kernel + lex_sort_kernel;
 //   lex_clear_kernel   restores the all-zero accumulator by visiting only the touched rows.
 // All of it is integer/f32 work bounded by HBM latency, not bandwidth: a query touches
 // sum(df) postings x 8 B.
 #include "../../include/rlr_lexical.h"
 #include "common.h"
 #include "kernels.h"
+#include "lds_select.h"
 #include "lexical_internal.h"
 
 #include <algorithm>
@@ -61,10 +65,12 @@ constexpr float kK1 = 1.5f, kB = 0.75f;               // rag_engine.rs:2191-2192
 struct LexControl {
     uint32_t n_touched;
     uint32_t n_sel;
-    uint32_t pad[2];
+    uint32_t n_cand;  // sampled selection: candidates at or above `thr`
+    uint32_t pad;
     uint64_t prefix[kPasses + 1]; // prefix[p]: the top 8*p key bits of the k-th largest key
     uint32_t k_rem[kPasses + 1];  // rank still wanted inside that prefix (1-based)
-    uint32_t pad2[3];
+    uint32_t pad2;
+    uint64_t thr;     // sampled selection: the (score, row) key every candidate reaches
     uint32_t hist[kPasses][256];
 };
 
@@ -258,6 +264,119 @@ __global__ __launch_bounds__(256) void lex_collect_kernel(const uint64_t *__rest
         if (take && slot < kMaxLimit)
             sel[slot] = key;
     }
+}
+
+// ---- sampled selection: 3 launches instead of 8 radix passes + collect ------------------------------------------
+// The `limit` best of n_touched documents by (score desc, row asc), for limit << n_touched:
+//   lex_sample_kernel   one workgroup reads a strided sample of <= 8192 (score, row) keys and takes, by an LDS radix
+//                       select, the sample's r-th largest key as threshold, r = mu + 4.5 sqrt(mu) + 8 with mu =
+//                       limit * s / n the expected number of sample members among the true top `limit`: the threshold
+//                       lies at or below the true limit-th key unless the sample holds > r of them (< 1e-5).  Full
+//                       64-bit keys, not scores: chunks of equal length make BM25 scores tie by the thousand, and a
+//                       threshold on the score alone would let all of a tie class through;
+//   lex_filter_kernel   one pass over the touched documents: everything at or above the threshold is appended to a
+//                       candidate list (~1.5 limit entries expected, capacity 8192);
+//   lex_final_kernel    one workgroup: the exact limit-th largest 64-bit (score, row) key among the candidates (radix
+//                       select in LDS) and everything at or above it -- exactly `limit` keys, unordered or sorted.
+// When the list overflowed or came out short (the unlucky sample), the count
+// word is set to kLexRetry and the caller repeats the query on the exact eight-pass path.
+constexpr uint32_t kLexRetry = 0xFFFFFFFFu;
+constexpr uint32_t kSampleMax = 8192, kFastLimitMax = 4096;
+
+__global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restrict__ scores, const uint32_t *__restrict__ touched,
+                                                          LexControl *__restrict__ ctl, uint32_t limit)
+{
+    __shared__ uint64_t s_k[kSampleMax];
+    __shared__ uint32_t s_hist[2048];
+    __shared__ uint32_t s_pick[2];
+    const uint32_t n = ctl->n_touched;
+    const uint32_t s = min(n, kSampleMax);
+    if (limit >= n || s == 0) { // everything is wanted
+        if (threadIdx.x == 0)
+            ctl->thr = 0;
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < s; i += 1024) {
+        const uint32_t at = static_cast<uint32_t>(static_cast<uint64_t>(i) * n / s); // strided: every part of the list
+        const uint32_t row = touched[at];
+        s_k[i] = pack_result(scores[row], row);
+    }
+    __syncthreads();
+    const float mu = static_cast<float>(limit) * static_cast<float>(s) / static_cast<float>(n);
+    const uint32_t r = min(s, static_cast<uint32_t>(mu + 4.5f * sqrtf(mu)) + 8u);
+    const uint64_t thr = lds_kth_key64(s_k, s, r, s_hist, s_pick, 1024);
+    if (threadIdx.x == 0)
+        ctl->thr = thr;
+}
+
+__global__ __launch_bounds__(256) void lex_filter_kernel(const float *__restrict__ scores, const uint32_t *__restrict__ touched,
+                                                         LexControl *__restrict__ ctl, uint64_t *__restrict__ cand)
+{
+    const uint32_t n = ctl->n_touched;
+    const uint64_t thr = ctl->thr;
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i0 = blockIdx.x * 256; i0 < n; i0 += stride) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint64_t key = 0;
+        bool take = false;
+        if (i < n) {
+            const uint32_t row = touched[i];
+            key = pack_result(scores[row], row);
+            take = key >= thr;
+        }
+        const uint32_t slot = wave_append_slot(take, &ctl->n_cand);
+        if (take && slot < kMaxLimit)
+            cand[slot] = key;
+    }
+}
+
+template <bool SORTED>
+__global__ __launch_bounds__(1024) void lex_final_kernel(const uint64_t *__restrict__ cand, const LexControl *__restrict__ ctl,
+                                                         uint32_t limit, uint64_t *__restrict__ out_keys,
+                                                         uint32_t *__restrict__ out_n)
+{
+    __shared__ uint64_t s[kMaxLimit];
+    __shared__ uint64_t s_win[SORTED ? kFastLimitMax : 1]; // the winners, to be sorted (the unordered form writes them out directly)
+    __shared__ uint32_t s_hist[2048];
+    __shared__ uint32_t s_pick[2];
+    __shared__ uint32_t s_out;
+    const uint32_t m = ctl->n_cand, want = min(limit, ctl->n_touched);
+    if (m > kMaxLimit || m < want) { // overflow or a short list (the sample misjudged)
+        if (threadIdx.x == 0)
+            *out_n = kLexRetry;
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < m; i += 1024)
+        s[i] = cand[i];
+    if (threadIdx.x == 0)
+        s_out = 0;
+    __syncthreads();
+    uint64_t kth = 0;
+    if (m > want)
+        kth = lds_kth_key64(s, m, want, s_hist, s_pick, 1024); // keys are unique: exactly `want` of them are >= kth
+    for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+        const uint64_t v = s[i];
+        if (v >= kth) {
+            const uint32_t at = atomicAdd(&s_out, 1u);
+            if constexpr (SORTED)
+                s_win[at] = v;
+            else
+                out_keys[at] = v;
+        }
+    }
+    if constexpr (SORTED) {
+        uint32_t n_pad = 1;
+        while (n_pad < want)
+            n_pad <<= 1;
+        for (uint32_t i = want + threadIdx.x; i < n_pad; i += 1024)
+            s_win[i] = 0;
+        __syncthreads();
+        lds_sort_desc(s_win, n_pad);
+        for (uint32_t i = threadIdx.x; i < want; i += 1024)
+            out_keys[i] = s_win[i];
+    }
+    if (threadIdx.x == 0)
+        *out_n = want;
 }
 
 __global__ __launch_bounds__(256) void lex_clear_kernel(float *__restrict__ scores, const uint32_t *__restrict__ touched,
@@ -750,17 +869,22 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     *n_out = 0;
     if (len && !query_tokens)
         return set_error(RLR_E_INVALID, "query_tokens is null");
-    rlr::LexPending p;
-    LEX_TRY(rlr::lexical_enqueue(lx, query_tokens, len, limit, &p, /*need_sorted=*/true));
-    if (p.limit == 0) // empty index, no tokens, or no term of the query is known (:2170-2177, :2196)
-        return RLR_OK;
-    int32_t st = RLR_OK;
-    if (!rows_out || !scores_out)
-        st = set_error(RLR_E_INVALID, "rows_out / scores_out is null");
-    else
-        st = rlr::lexical_fetch(&p, rows_out, scores_out, n_out);
-    rlr::lexical_finish(&p, st == RLR_OK);
-    return st;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rlr::LexPending p;
+        LEX_TRY(rlr::lexical_enqueue(lx, query_tokens, len, limit, &p, /*need_sorted=*/true, /*exact_passes=*/attempt == 1));
+        if (p.limit == 0) // empty index, no tokens, or no term of the query is known (:2170-2177, :2196)
+            return RLR_OK;
+        int32_t st = RLR_OK;
+        if (!rows_out || !scores_out)
+            st = set_error(RLR_E_INVALID, "rows_out / scores_out is null");
+        else
+            st = rlr::lexical_fetch(&p, rows_out, scores_out, n_out);
+        rlr::lexical_finish(&p, st == RLR_OK);
+        if (st != RLR_OK || *n_out != kLexRetry)
+            return st;
+        *n_out = 0; // the sampled selection handed the query back: once more with the exact radix passes
+    }
+    return set_error(RLR_E_HIP, "lexical selection did not converge");
 }
 
 int32_t rlr_tokenize_ascii(const char *text, size_t len, char *out, size_t cap, size_t *out_len)
@@ -816,7 +940,7 @@ struct PendingGuard { // releases whatever lexical_enqueue had taken when it fai
 } // namespace
 
 int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, LexPending *out,
-                        bool need_sorted)
+                        bool need_sorted, bool exact_passes)
 {
     *out = LexPending{};
     out->lx = lx;
@@ -918,6 +1042,16 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     if (upper <= kMaxLimit) {
         hipLaunchKernelGGL(lex_sort_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, nullptr, ws->d_ctl,
                            lim, ws->d_out, d_out_n);
+    } else if (!exact_passes && lim <= kFastLimitMax) {
+        // sampled threshold -> one filter pass -> exact finish among the ~1.5 lim candidates (3 launches); the count word
+        // says kLexRetry when that list overflowed or came out short
+        hipLaunchKernelGGL(lex_sample_kernel, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl, lim);
+        hipLaunchKernelGGL(lex_filter_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl, ws->d_sel);
+        if (need_sorted)
+            hipLaunchKernelGGL(lex_final_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_sel, ws->d_ctl, lim, ws->d_out, d_out_n);
+        else
+            hipLaunchKernelGGL(lex_final_kernel<false>, dim3(1), dim3(1024), 0, s, ws->d_sel, ws->d_ctl, lim, ws->d_out, d_out_n);
+        out->may_retry = true;
     } else {
         LEX_TRY(dev_grow(&ws->d_keys, &ws->keys_cap, upper));
         hipLaunchKernelGGL(lex_select_pass_kernel<true>, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, 0,
@@ -958,7 +1092,12 @@ int32_t lexical_fetch(LexPending *p, uint64_t *rows_out, float *scores_out, uint
     LEX_HIP(hipMemcpyAsync(ws->h_out + kMaxLimit, ws->d_out + kMaxLimit, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     LEX_HIP(hipMemcpyAsync(ws->h_out, ws->d_out, static_cast<size_t>(p->limit) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     LEX_HIP(hipStreamSynchronize(s));
-    const uint32_t n = std::min<uint32_t>(*reinterpret_cast<const uint32_t *>(ws->h_out + kMaxLimit), p->limit);
+    const uint32_t n_dev = *reinterpret_cast<const uint32_t *>(ws->h_out + kMaxLimit);
+    if (n_dev == kLexRetry) { // the sampled selection gave up: the caller repeats the query on the exact path
+        *n_out = kLexRetry;
+        return RLR_OK;
+    }
+    const uint32_t n = std::min<uint32_t>(n_dev, p->limit);
     for (uint32_t i = 0; i < n; ++i) {
         float sc;
         uint32_t row;

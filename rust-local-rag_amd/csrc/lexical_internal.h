@@ -21,12 +21,17 @@ struct LexPending {
     const uint32_t *d_count = nullptr;  // how many of them are valid (<= limit)
     uint32_t limit = 0;                 // 0: no document can match (empty index / unknown terms) -- nothing was enqueued
     bool locked = false;
+    bool may_retry = false; // the sampled selection was used: the count may read kLexicalRetry
 };
 
 // LexicalIndex::score (rag_engine.rs:2169-2225) up to the ordered result list in device memory.  No synchronisation.
 // need_sorted = false: d_packed holds the same set in no particular order (saves the final LDS sort; lexical_fetch
 // needs the sorted form)
-int32_t lexical_enqueue(rlr_lexical *lx, const char *tokens, size_t len, uint32_t limit, LexPending *out, bool need_sorted);
+// exact_passes = false lets large candidate sets go through the sampled 3-launch selection: *d_count (and lexical_fetch's
+// *n_out) may then read kLexicalRetry -- repeat the call with exact_passes = true
+int32_t lexical_enqueue(rlr_lexical *lx, const char *tokens, size_t len, uint32_t limit, LexPending *out, bool need_sorted,
+                        bool exact_passes);
+constexpr uint32_t kLexicalRetry = 0xFFFFFFFFu;
 // copy the result to the host (synchronises the scoring stream); valid between enqueue and finish
 int32_t lexical_fetch(LexPending *p, uint64_t *rows_out, float *scores_out, uint32_t *n_out);
 // hand the workspace back once every consumer of d_packed has finished (the caller synchronised them);

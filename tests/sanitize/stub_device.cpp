@@ -167,7 +167,7 @@ extern "C" int32_t rlr_lexical_score(rlr_lexical *, const char *, size_t, uint32
 
 #include "../../rust-local-rag_amd/csrc/lexical_internal.h"
 namespace rlr {
-int32_t lexical_enqueue(rlr_lexical *, const char *, size_t, uint32_t, LexPending *out, bool)
+int32_t lexical_enqueue(rlr_lexical *, const char *, size_t, uint32_t, LexPending *out, bool, bool)
 {
     *out = LexPending{};
     return RLR_OK; // limit == 0: "no lexical candidate"
