@@ -75,9 +75,11 @@ int32_t rlr_lexical_info(rlr_lexical *lex, uint64_t *total_docs, uint64_t *total
 
 /* How the postings sit on the device (no reference counterpart: the reference's HashMap needs no rebuild).  The
  * main segment holds the rows present at the last full rebuild, the appended segment the rows added since; a commit
- * that finds only appends rebuilds the appended segment alone.  Any pointer may be null. */
+ * that finds only appends rebuilds the appended segment alone.  select_retries: score calls whose sampled top-`limit`
+ * selection handed the query back to the exact radix passes (expected: fewer than one in 10^5).  Any pointer may be
+ * null. */
 int32_t rlr_lexical_segments(rlr_lexical *lex, uint64_t *main_postings, uint64_t *appended_postings,
-                             uint64_t *full_rebuilds, uint64_t *append_rebuilds);
+                             uint64_t *full_rebuilds, uint64_t *append_rebuilds, uint64_t *select_retries);
 
 /* LexicalIndex::score (:2169-2225).  `query_tokens` like `tokens` above.  Writes at most
  * min(limit, RLR_LEXICAL_MAX_LIMIT) pairs, ordered (score desc, row asc); limit == 0 means

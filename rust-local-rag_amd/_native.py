@@ -144,7 +144,7 @@ PROTOTYPES = [
     ("rlr_lexical_clear", C.c_int32, [_H]),
     ("rlr_lexical_contains", C.c_int32, [_H, C.c_uint64]),
     ("rlr_lexical_info", C.c_int32, [_H, u64p, u64p, u64p, u64p]),
-    ("rlr_lexical_segments", C.c_int32, [_H, u64p, u64p, u64p, u64p]),
+    ("rlr_lexical_segments", C.c_int32, [_H, u64p, u64p, u64p, u64p, u64p]),
     ("rlr_lexical_score", C.c_int32, [_H, C.c_char_p, C.c_size_t, C.c_uint32, u64p, f32p, u32p]),
     ("rlr_tokenize_ascii", C.c_int32, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
 ]

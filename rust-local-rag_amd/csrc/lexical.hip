@@ -29,8 +29,10 @@
 #include "lexical_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <shared_mutex>
@@ -284,7 +286,7 @@ constexpr uint32_t kLexRetry = 0xFFFFFFFFu;
 constexpr uint32_t kSampleMax = 8192, kFastLimitMax = 4096;
 
 __global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restrict__ scores, const uint32_t *__restrict__ touched,
-                                                          LexControl *__restrict__ ctl, uint32_t limit)
+                                                          LexControl *__restrict__ ctl, uint32_t limit, uint32_t r_forced)
 {
     __shared__ uint64_t s_k[kSampleMax];
     __shared__ uint32_t s_hist[2048];
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restric
     }
     __syncthreads();
     const float mu = static_cast<float>(limit) * static_cast<float>(s) / static_cast<float>(n);
-    const uint32_t r = min(s, static_cast<uint32_t>(mu + 4.5f * sqrtf(mu)) + 8u);
+    const uint32_t r = r_forced ? min(s, r_forced) : min(s, static_cast<uint32_t>(mu + 4.5f * sqrtf(mu)) + 8u);
     const uint64_t thr = lds_kth_key64(s_k, s, r, s_hist, s_pick, 1024);
     if (threadIdx.x == 0)
         ctl->thr = thr;
@@ -461,6 +463,7 @@ struct rlr_lexical {
     bool full_dirty = true;   // a row of MAIN changed (replace / remove / clear), or nothing was built yet
     bool delta_dirty = false; // only rows >= main_rows changed since the last commit
     uint64_t main_rows = 0, main_postings = 0, delta_postings = 0, n_full_commits = 0, n_delta_commits = 0;
+    std::atomic<uint64_t> n_select_retries{0}; // queries the sampled selection handed back to the exact path
     std::vector<uint32_t> main_df; // documents per term inside MAIN (terms born later: beyond its end, 0)
     // ---- device CSR
     std::vector<uint64_t> term_off, dterm_off; // MAIN / DELTA offsets by term
@@ -847,7 +850,7 @@ int32_t rlr_lexical_info(rlr_lexical *lx, uint64_t *total_docs, uint64_t *total_
 }
 
 int32_t rlr_lexical_segments(rlr_lexical *lx, uint64_t *main_postings, uint64_t *appended_postings, uint64_t *full_rebuilds,
-                             uint64_t *append_rebuilds)
+                             uint64_t *append_rebuilds, uint64_t *select_retries)
 {
     if (!lx)
         return set_error(RLR_E_INVALID, "lexical handle is null");
@@ -856,6 +859,7 @@ int32_t rlr_lexical_segments(rlr_lexical *lx, uint64_t *main_postings, uint64_t 
     if (appended_postings) *appended_postings = lx->delta_postings;
     if (full_rebuilds) *full_rebuilds = lx->n_full_commits;
     if (append_rebuilds) *append_rebuilds = lx->n_delta_commits;
+    if (select_retries) *select_retries = lx->n_select_retries.load();
     return RLR_OK;
 }
 
@@ -883,6 +887,7 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
         if (st != RLR_OK || *n_out != kLexRetry)
             return st;
         *n_out = 0; // the sampled selection handed the query back: once more with the exact radix passes
+        lx->n_select_retries++;
     }
     return set_error(RLR_E_HIP, "lexical selection did not converge");
 }
@@ -1045,7 +1050,10 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     } else if (!exact_passes && lim <= kFastLimitMax) {
         // sampled threshold -> one filter pass -> exact finish among the ~1.5 lim candidates (3 launches); the count word
         // says kLexRetry when that list overflowed or came out short
-        hipLaunchKernelGGL(lex_sample_kernel, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl, lim);
+        // RLR_LEX_SAMPLE_RANK (a test switch): the sample rank to use instead of mu + 4.5 sqrt(mu) + 8 -- 1 makes the
+        // threshold the largest sample key, the candidate list short, and every such query take the retry
+        static const uint32_t r_forced = getenv("RLR_LEX_SAMPLE_RANK") ? static_cast<uint32_t>(atoi(getenv("RLR_LEX_SAMPLE_RANK"))) : 0u;
+        hipLaunchKernelGGL(lex_sample_kernel, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl, lim, r_forced);
         hipLaunchKernelGGL(lex_filter_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl, ws->d_sel);
         if (need_sorted)
             hipLaunchKernelGGL(lex_final_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_sel, ws->d_ctl, lim, ws->d_out, d_out_n);

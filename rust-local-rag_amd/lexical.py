@@ -86,9 +86,10 @@ class LexicalIndex:
 
     def segments(self) -> dict:
         """device posting segments: what the last commits rebuilt (appends rebuild only the appended segment)"""
-        v = [C.c_uint64() for _ in range(4)]
+        v = [C.c_uint64() for _ in range(5)]
         N.check(self._L.rlr_lexical_segments(self._h, *[C.byref(x) for x in v]))
-        return dict(zip(("main_postings", "appended_postings", "full_rebuilds", "append_rebuilds"), (x.value for x in v)))
+        return dict(zip(("main_postings", "appended_postings", "full_rebuilds", "append_rebuilds", "select_retries"),
+                        (x.value for x in v)))
 
     def score(self, query: str, limit: int) -> Tuple[np.ndarray, np.ndarray]:
         """LexicalIndex::score :2169-2225 -> (rows u64, scores f32), (score desc, row asc)"""

@@ -330,6 +330,26 @@ def test_poisoned_allocations():
     assert "multi-shard fuzz ok" in out.stdout
 
 
+def test_lexical_sampled_selection_retry_path():
+    """RLR_LEX_SAMPLE_RANK=1 in a child process: the sampled BM25 selection takes the largest sample key as threshold, its
+    candidate list comes out short, and every large query goes through the retry -- host API (rlr_lexical_score repeats
+    the query on the exact radix path) and fused hybrid search (the blend hands the query back, status 3) alike.  Same
+    differential tests, same answers."""
+    import os
+    import subprocess
+
+    env = dict(os.environ, RLR_LEX_SAMPLE_RANK="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, 'tests'); import test_gpu_fuzz as F; "
+            "print('lexical fuzz ok: %d' % F.fuzz_lexical(12, 77)); print('engine fuzz ok: %d' % F.fuzz_engine(6, 78)); "
+            "import test_gpu_lexical as L, importlib, conftest; rlr = conftest.load_pkg(); from oracle import oracle as O; O.lib(); "
+            "L.test_bm25_select_path_many_postings_and_ties(rlr); L.test_engine_search_text_fused_and_fallback_paths(rlr, O); L.test_engine_search_text_with_more_candidates_than_one_workgroup_sorts(rlr, O); "
+            "print('retry path ok')")
+    out = subprocess.run([sys.executable, "-u", "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "retry path ok" in out.stdout
+
+
 def test_mmr_logged_value_keeps_the_sign_of_zero(rlr, oracle):
     """lambda = 1: (1 - lambda) * rel is -0.0 for a negative relevance and the reference logs -0.0 - 0.0 = -0.0"""
     rows = oracle.synth_rows(17, 1152, seed=470119562, f16=True)

@@ -334,3 +334,35 @@ def test_engine_search_text_fused_and_fallback_paths(rlr, oracle):
     assert np.array_equal(bits([g_.score for g_ in got]), bits(wc))
     assert np.array_equal(bits([g_.lexical_score for g_ in got]), bits(wl))
     eng.close()
+
+
+def test_engine_search_text_with_more_candidates_than_one_workgroup_sorts(rlr, oracle):
+    """> 8192 documents hold the query's terms: BM25 goes through the sampled selection (and, in the retry test's child
+    process, through its hand-back: the blend reports status 3 and the engine repeats the query on the exact path)"""
+    n, dim = 12000, 64
+    texts = make_texts(n, seed=41, lo=3, hi=12, common_every=1)      # every chunk holds "ubiquitous"
+    rows = oracle.synth_rows(n, dim, seed=42)
+    eng = rlr.RagEngine(dim)
+    eng.add_document("d", texts, rows)
+    stored = eng.index.fetch_rows(np.arange(n))
+    o = OL.LexicalIndex()
+    for r, t in enumerate(texts):
+        o.add_chunk(r, t, rank=r)
+    for qi, (text, k, div) in enumerate([("ubiquitous w000x w001x", 20, 0.3), ("w002x ubiquitous", 100, 0.0), ("w000x", 10, 0.7)]):
+        q = oracle.synth_query(dim, seed=43 + qi)
+        k_eff = k if div == 0.0 else max(3 * k, k + 10)
+        pairs = [(c, float(s)) for c, s in o.score(text, 5 * k_eff, keep_zero=False)]
+        got = eng.search_with_diversity(q, k, div, query_text=text)
+        wr, wc, we, wl = oracle.search_with_diversity(stored, q, k, div, lex=pairs)
+        assert [g_.row for g_ in got] == list(wr), (text, k, div)
+        assert np.array_equal(bits([g_.score for g_ in got]), bits(wc)), (text, k, div)
+        assert np.array_equal(bits([g_.lexical_score for g_ in got]), bits(wl)), (text, k, div)
+        lr, ls = eng.lexical.score(text, 5 * k_eff)
+        assert [int(r) for r in lr] == [c for c, _ in pairs] and np.array_equal(bits(ls), bits([s for _, s in pairs]))
+    import os
+    retries = eng.lexical.segments()["select_retries"]
+    if os.environ.get("RLR_LEX_SAMPLE_RANK") == "1":
+        assert retries >= 4, retries          # the forced short list: every large query came back through the exact path
+    else:
+        assert retries == 0, retries
+    eng.close()
