@@ -65,8 +65,13 @@ __device__ inline uint32_t lds_kth_key(const uint64_t *s_c, uint32_t n, uint32_t
 
 // k-th largest full 64-bit key of s_c[0, n) (keys are unique where the caller needs exactly k winners): six radix
 // passes over LDS (11 x 5 + 9 bits), same structure as lds_kth_key.  All threads must call it.
+//
+// `slack`: the passes stop as soon as the bin holding the k-th key has at most `slack` keys ranked BELOW it (bin
+// population - rank inside the bin <= slack); the bin's lower edge is returned then, so between k and k + slack keys are
+// >= the result.  slack = 0 still yields exactly k keys (it stops when the whole bin belongs to the top k -- with unique
+// keys usually after three of the six passes); a threshold that may admit a few more uses a larger slack.
 __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32_t k, uint32_t *s_hist, uint32_t *s_sel,
-                                         uint32_t nthreads)
+                                         uint32_t nthreads, uint32_t slack = 0)
 {
     uint64_t prefix = 0, mask = 0;
     uint32_t rank = k;
@@ -103,6 +108,7 @@ __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32
                     if (rank <= acc + h) {
                         s_sel[0] = lane * W + b;
                         s_sel[1] = rank - acc;
+                        s_sel[2] = h;
                         break;
                     }
                     acc += h;
@@ -113,7 +119,10 @@ __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32
         prefix |= static_cast<uint64_t>(s_sel[0]) << shift;
         mask |= static_cast<uint64_t>(nb - 1) << shift;
         rank = s_sel[1];
+        const bool done = s_sel[2] - rank <= slack; // (uniform) everything the bin holds below the k-th key is tolerated
         __syncthreads();
+        if (done)
+            break;
     }
     return prefix;
 }

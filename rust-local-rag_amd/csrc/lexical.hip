@@ -290,7 +290,7 @@ __global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restric
 {
     __shared__ uint64_t s_k[kSampleMax];
     __shared__ uint32_t s_hist[2048];
-    __shared__ uint32_t s_pick[2];
+    __shared__ uint32_t s_pick[3];
     const uint32_t n = ctl->n_touched;
     const uint32_t s = min(n, kSampleMax);
     if (limit >= n || s == 0) { // everything is wanted
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restric
     __syncthreads();
     const float mu = static_cast<float>(limit) * static_cast<float>(s) / static_cast<float>(n);
     const uint32_t r = r_forced ? min(s, r_forced) : min(s, static_cast<uint32_t>(mu + 4.5f * sqrtf(mu)) + 8u);
-    const uint64_t thr = lds_kth_key64(s_k, s, r, s_hist, s_pick, 1024);
+    const uint64_t thr = lds_kth_key64(s_k, s, r, s_hist, s_pick, 1024, /*slack=*/8); // a few sample keys more: harmless
     if (threadIdx.x == 0)
         ctl->thr = thr;
 }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(1024) void lex_final_kernel(const uint64_t *__restr
     __shared__ uint64_t s[kMaxLimit];
     __shared__ uint64_t s_win[SORTED ? kFastLimitMax : 1]; // the winners, to be sorted (the unordered form writes them out directly)
     __shared__ uint32_t s_hist[2048];
-    __shared__ uint32_t s_pick[2];
+    __shared__ uint32_t s_pick[3];
     __shared__ uint32_t s_out;
     const uint32_t m = ctl->n_cand, want = min(limit, ctl->n_touched);
     if (m > kMaxLimit || m < want) { // overflow or a short list (the sample misjudged)
@@ -1047,7 +1047,11 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     if (upper <= kMaxLimit) {
         hipLaunchKernelGGL(lex_sort_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, nullptr, ws->d_ctl,
                            lim, ws->d_out, d_out_n);
-    } else if (!exact_passes && lim <= kFastLimitMax) {
+    } else if (!exact_passes && lim <= kFastLimitMax &&
+               // expected candidates of the sampled selection: (mu + 4.5 sqrt(mu) + 8) n / s with mu = lim s / n, s = 8192;
+               // beyond ~3 M touched documents the 8192-entry sample is too coarse for the 8192-entry candidate list
+               static_cast<double>(lim) + 4.5 * std::sqrt(static_cast<double>(lim) * upper / kSampleMax) +
+                       8.0 * static_cast<double>(upper) / kSampleMax <= 6000.0) {
         // sampled threshold -> one filter pass -> exact finish among the ~1.5 lim candidates (3 launches); the count word
         // says kLexRetry when that list overflowed or came out short
         // RLR_LEX_SAMPLE_RANK (a test switch): the sample rank to use instead of mu + 4.5 sqrt(mu) + 8 -- 1 makes the
