@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
                                                              const float *__restrict__ scores, uint32_t P, uint32_t k,
                                                              float lambda, uint32_t *__restrict__ out_order,
                                                              float *__restrict__ out_mmr, uint32_t *__restrict__ out_n,
-                                                             const uint32_t *__restrict__ sizes)
+                                                             const uint32_t *__restrict__ sizes, MmrEmit emit)
 {
     // batch: blockIdx.x = query; arrays are strided by the launch-wide P, the pool size is sizes[q]
     {
@@ -769,8 +769,13 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
     if (sizes)
         P = sizes[blockIdx.x];
     if (P == 0) {
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             *out_n = 0;
+            if (emit.h_out) { // (an unusable pool arrives here as size 0 with its status in info[1])
+                emit.h_out[4 * emit.k_cap] = 0;
+                emit.h_out[4 * emit.k_cap + 1] = emit.info[1];
+            }
+        }
         return;
     }
     // The Gram matrix was just written by other CUs (possibly other XCDs): its first touch from
@@ -867,6 +872,22 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
     }
     if (lane == 0)
         *out_n = n_sel;
+    if (emit.h_out) { // the picks straight into the caller's (pinned) result block
+        __threadfence(); // lane 0's out_order stores, read back by all lanes
+        const uint32_t status = emit.info[1];
+        const uint32_t n = status ? 0u : min(n_sel, emit.k_cap);
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t o = out_order[i];
+            emit.h_out[i] = emit.list[o];
+            emit.h_out[emit.k_cap + i] = __builtin_bit_cast(uint32_t, emit.cosv[o]);
+            emit.h_out[2 * emit.k_cap + i] = __builtin_bit_cast(uint32_t, emit.comb[o]);
+            emit.h_out[3 * emit.k_cap + i] = emit.lexv ? __builtin_bit_cast(uint32_t, emit.lexv[o]) : 0u;
+        }
+        if (lane == 0) {
+            emit.h_out[4 * emit.k_cap] = n;
+            emit.h_out[4 * emit.k_cap + 1] = status;
+        }
+    }
 }
 
 uint32_t ew_blocks(size_t total)
@@ -1109,12 +1130,15 @@ hipError_t launch_gram_rows(const void *rows, uint32_t pitch16, uint32_t dim, in
 // n_queries > 1 (or sizes != null): per-query arrays strided by P, pool sizes in sizes[q] (<= P <= 1024)
 hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P, uint32_t k, float lambda,
                              uint32_t *out_order, float *out_mmr, uint32_t *out_n, const uint32_t *sizes,
-                             uint32_t n_queries, hipStream_t s)
+                             uint32_t n_queries, hipStream_t s, const MmrEmit *emit_in)
 {
     const size_t lds = static_cast<size_t>(P ? P : 1) * 12;
+    const MmrEmit emit = emit_in ? *emit_in : MmrEmit{};
+    if (emit.h_out && (n_queries != 1 || P == 0 || P > 1024))
+        return hipErrorInvalidValue; // the emit tail exists in the register-resident single-pool kernel only
 #define RLR_MMR_REG(JV)                                                                                          \
     hipLaunchKernelGGL(mmr_greedy_reg_kernel<JV>, dim3(n_queries), dim3(256), 0, s, gram, scores, P, k, lambda,   \
-                       out_order, out_mmr, out_n, sizes)
+                       out_order, out_mmr, out_n, sizes, emit)
     if (P == 0 || (P > 1024 && n_queries == 1 && !sizes))
         hipLaunchKernelGGL(mmr_greedy_kernel, dim3(1), dim3(64), lds, s, gram, scores, P, k, lambda, out_order, out_mmr,
                            out_n);

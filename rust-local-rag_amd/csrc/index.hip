@@ -767,24 +767,6 @@ __global__ __launch_bounds__(1024) void pool_prepare_kernel(const uint64_t *__re
     }
 }
 
-// picks -> pinned host memory: [row u32 | cos f32 | combined f32] x k, then n_picks, status
-__global__ __launch_bounds__(256) void diverse_emit_kernel(const uint32_t *__restrict__ list, const float *__restrict__ comb,
-                                                           const float *__restrict__ cosv, const uint32_t *__restrict__ order,
-                                                           const uint32_t *__restrict__ n_sel, const uint32_t *__restrict__ info,
-                                                           uint32_t k_cap, uint32_t *__restrict__ h_out)
-{
-    const uint32_t n = info[1] ? 0u : min(*n_sel, k_cap);
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint32_t o = order[i];
-        h_out[i] = list[o];
-        h_out[k_cap + i] = __builtin_bit_cast(uint32_t, cosv[o]);
-        h_out[2 * k_cap + i] = __builtin_bit_cast(uint32_t, comb[o]);
-    }
-    if (threadIdx.x == 0) {
-        h_out[3 * k_cap] = n;
-        h_out[3 * k_cap + 1] = info[1];
-    }
-}
 
 // ---- hybrid search without host round trips (rlr_search_hybrid) -------------------------------------------
 // The device twin of search_impl's candidate list when lexical (BM25) candidates exist (csrc/engine.cpp;
@@ -1006,21 +988,19 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
     }
 }
 
-// results -> pinned host memory: [row u32 | cos f32 | combined f32 | lexical f32] x k_cap, then n, status.
-// order == null: the candidates in their sorted order (no diversification).
+// the first info[0] candidates in their sorted order (no diversification) -> pinned host memory:
+// [row u32 | cos f32 | combined f32 | lexical f32] x k_cap, then n, status (the layout the greedy kernel's emit tail writes)
 __global__ __launch_bounds__(256) void hybrid_emit_kernel(const uint32_t *__restrict__ list, const float *__restrict__ comb,
                                                           const float *__restrict__ cosv, const float *__restrict__ lexv,
-                                                          const uint32_t *__restrict__ order, const uint32_t *__restrict__ n_sel,
                                                           const uint32_t *__restrict__ info, uint32_t k_cap,
                                                           uint32_t *__restrict__ h_out)
 {
-    const uint32_t n = info[1] ? 0u : min(order ? *n_sel : info[0], k_cap);
+    const uint32_t n = info[1] ? 0u : min(info[0], k_cap);
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint32_t o = order ? order[i] : i;
-        h_out[i] = list[o];
-        h_out[k_cap + i] = __builtin_bit_cast(uint32_t, cosv[o]);
-        h_out[2 * k_cap + i] = __builtin_bit_cast(uint32_t, comb[o]);
-        h_out[3 * k_cap + i] = __builtin_bit_cast(uint32_t, lexv[o]);
+        h_out[i] = list[i];
+        h_out[k_cap + i] = __builtin_bit_cast(uint32_t, cosv[i]);
+        h_out[2 * k_cap + i] = __builtin_bit_cast(uint32_t, comb[i]);
+        h_out[3 * k_cap + i] = __builtin_bit_cast(uint32_t, lexv[i]);
     }
     if (threadIdx.x == 0) {
         h_out[4 * k_cap] = n;
@@ -2240,7 +2220,7 @@ int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uin
     uint32_t *d_nsel = reinterpret_cast<uint32_t *>(d_cos + 3ull * P);
     uint32_t *d_info = d_nsel + 1;
     const size_t q_bytes = static_cast<size_t>(ix->q_pitch) * sizeof(float);
-    const size_t out_words = 3ull * k_cap + 2;
+    const size_t out_words = 4ull * k_cap + 2;
     RLR_TRY(pin_reserve(c, q_bytes + out_words * 4 + 64));
     float *h_q = static_cast<float *>(c->h_pin);
     uint32_t *h_out = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + q_bytes);
@@ -2257,15 +2237,19 @@ int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uin
                        c->d_list, d_comb, d_cos, d_info);
     RLR_HIP(hipGetLastError());
     RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
-    RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, k, lambda, d_order, d_mmr, d_nsel, d_info, 1, s));
-    hipLaunchKernelGGL(rlr::diverse_emit_kernel, dim3(1), dim3(256), 0, s, c->d_list, d_comb, d_cos, d_order, d_nsel, d_info,
-                       k_cap, h_out);
-    RLR_HIP(hipGetLastError());
+    rlr::MmrEmit emit; // the greedy kernel writes the picks into the pinned block itself
+    emit.list = c->d_list;
+    emit.comb = d_comb;
+    emit.cosv = d_cos;
+    emit.info = d_info;
+    emit.k_cap = k_cap;
+    emit.h_out = h_out;
+    RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, k, lambda, d_order, d_mmr, d_nsel, d_info, 1, s, &emit));
     if (timed) RLR_HIP(hipEventRecord(c->bev[1], s));
     RLR_HIP(hipStreamSynchronize(s));
     RLR_TRY(check_hist_assert(c));
     c->hist_dirty = false;
-    const uint32_t n_sel = h_out[3 * k_cap], status = h_out[3 * k_cap + 1];
+    const uint32_t n_sel = h_out[4 * k_cap], status = h_out[4 * k_cap + 1];
     {
         std::lock_guard<std::mutex> lk(ix->mu);
         ix->prof.n_searches += 1;
@@ -2460,11 +2444,19 @@ static int32_t hybrid_finish_impl(HybridTicket *ticket, const HybridLexSrc &src,
     RLR_HIP(hipGetLastError());
     if (t->diversify) {
         RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
-        RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, t->k, t->lambda, d_order, d_mmr, d_nsel, d_info, 1, s));
+        MmrEmit emit; // the greedy kernel writes the picks into the pinned block itself
+        emit.list = c->d_list;
+        emit.comb = d_comb;
+        emit.cosv = d_cos;
+        emit.lexv = d_lexv;
+        emit.info = d_info;
+        emit.k_cap = k_cap;
+        emit.h_out = h_out;
+        RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, t->k, t->lambda, d_order, d_mmr, d_nsel, d_info, 1, s, &emit));
+    } else {
+        hipLaunchKernelGGL(hybrid_emit_kernel, dim3(1), dim3(256), 0, s, c->d_list, d_comb, d_cos, d_lexv, d_info, k_cap, h_out);
+        RLR_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(hybrid_emit_kernel, dim3(1), dim3(256), 0, s, c->d_list, d_comb, d_cos, d_lexv,
-                       t->diversify ? d_order : nullptr, t->diversify ? d_nsel : nullptr, d_info, k_cap, h_out);
-    RLR_HIP(hipGetLastError());
     if (t->timed) RLR_HIP(hipEventRecord(c->bev[1], s));
     drain.armed = false;
     RLR_HIP(hipStreamSynchronize(s));

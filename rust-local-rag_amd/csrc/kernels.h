@@ -132,10 +132,19 @@ hipError_t launch_gram(const float *pool, uint32_t P, uint32_t dim, float *gram,
 // the same with the pool rows read straight from the index through list[q * P + i] (no gathered f32 copy)
 hipError_t launch_gram_rows(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const uint32_t *list, uint32_t P,
                             float *gram, uint32_t n_queries, hipStream_t s);
+// Optional tail of the greedy kernel for a single pool (the fused search paths): the picks go straight to (pinned)
+// memory as [row | cos | combined | lexical] x k_cap, then n, status -- no separate emit launch.
+struct MmrEmit {
+    const uint32_t *list = nullptr; // pool slot -> row
+    const float *comb = nullptr, *cosv = nullptr, *lexv = nullptr; // per pool slot (lexv may be null: zeros)
+    const uint32_t *info = nullptr; // info[1] != 0: the pool is not usable, n = 0
+    uint32_t k_cap = 0;
+    uint32_t *h_out = nullptr;      // null: no emit
+};
 // greedy MMR over the gram matrix; out_order/out_mmr/out_n on the device.
 hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P, uint32_t k,
                              float lambda, uint32_t *out_order, float *out_mmr, uint32_t *out_n,
-                             const uint32_t *sizes, uint32_t n_queries, hipStream_t s);
+                             const uint32_t *sizes, uint32_t n_queries, hipStream_t s, const MmrEmit *emit = nullptr);
 
 // ---- q8.hip : optional 8-bit nomination copy of f32 rows (single-query scans at a quarter of the bytes) ----
 hipError_t launch_q8_build(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin, uint32_t n_rows,
