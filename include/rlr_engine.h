@@ -91,7 +91,7 @@ int32_t rlr_engine_search_with_diversity(rlr_index *idx, const float *query_raw,
  * rlr_engine_search; otherwise search_with_diversity (stage ignored).  Same results as rlr_lexical_score followed by
  * rlr_engine_search / rlr_engine_search_with_diversity with its pairs -- but the BM25 kernels run on their own stream
  * beside the cosine scan, their result never leaves the device, and blend, ordering, cut and MMR follow in the same
- * enqueue: one host synchronisation per query (0.85 -> 0.32 ms at 100 k chunks).  Falls back to exactly those
+ * enqueue: one host synchronisation per query (0.85 -> 0.31 ms at 100 k chunks).  Falls back to exactly those
  * two calls when the fused kernels do not cover the request (w_embedding == 0, more than 1024 candidates kept or
  * 2048 lexical pairs, a rounding-tie chain at the fetch boundary). */
 int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *query_raw, uint32_t dq,
