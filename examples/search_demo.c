@@ -5,12 +5,15 @@
  *   ./search_demo [rows] [dim] [k]
  *
  * Fills an index with the deterministic synthetic corpus, runs one top-k search and one MMR
- * selection through rlr_engine_*, and prints the results as "row score" lines (the GPU test
- * compares them with the Python binding's results for the same inputs).
+ * selection through rlr_engine_*, then the same with a query TEXT against a small GPU BM25 index
+ * (rlr_lexical_* + rlr_engine_search_text: the hybrid search of search_documents), and prints the
+ * results as "row score" lines (the GPU test compares them with the Python binding's results for
+ * the same inputs).
  */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "rlr_engine.h"
 
@@ -52,6 +55,26 @@ int main(int argc, char **argv)
     printf("search_with_diversity lambda=0.3 -> %u hits\n", n_hits);
     for (uint32_t i = 0; i < n_hits; ++i)
         printf("D %llu %.9g %.9g\n", (unsigned long long)hits[i].row, hits[i].score, hits[i].embedding_score);
+
+    /* hybrid: every 3rd of the first 3000 chunks carries words; the query text names two of them */
+    rlr_lexical *lex = NULL;
+    CHECK(rlr_lexical_create(0, &lex));
+    char text[128], toks[128];
+    for (uint64_t r = 0; r < 3000 && r < n; r += 3) {
+        snprintf(text, sizeof text, "Chunk number %llu, about topic%llu and Theme%llu!", (unsigned long long)r,
+                 (unsigned long long)(r % 7), (unsigned long long)(r % 11));
+        size_t len = 0;
+        CHECK(rlr_tokenize_ascii(text, strlen(text), toks, sizeof toks, &len)); /* lower-case, >= 3 bytes, split */
+        CHECK(rlr_lexical_add_chunk(lex, r, toks, len));
+    }
+    const char *query_tokens = "topic3 theme5";
+    CHECK(rlr_engine_search_text(ix, lex, q, dim, query_tokens, strlen(query_tokens), k, 0.3f, 0, NULL, hits, 3 * k + 10,
+                                 &n_hits));
+    printf("search_with_diversity + query text -> %u hits\n", n_hits);
+    for (uint32_t i = 0; i < n_hits; ++i)
+        printf("T %llu %.9g %.9g %.9g\n", (unsigned long long)hits[i].row, hits[i].score, hits[i].embedding_score,
+               hits[i].lexical_score);
+    rlr_lexical_destroy(lex);
 
     free(hits);
     free(q);

@@ -44,4 +44,13 @@ def test_demo_output_matches_python_binding(rlr, tmp_path):
     assert [r for r, _ in s_rows] == [g.row for g in got_s]
     assert [r for r, _ in d_rows] == [g.row for g in got_d]
     assert np.allclose([s for _, s in s_rows], [g.score for g in got_s], atol=1e-6)
+    # the hybrid part: the same little BM25 index through the Python binding (its tokenizer agrees on ASCII)
+    t_rows = [(int(l.split()[1]), np.float32(l.split()[2]), np.float32(l.split()[4])) for l in out.splitlines() if l.startswith("T ")]
+    for r in range(0, 3000, 3):
+        eng.lexical.add_chunk(r, f"Chunk number {r}, about topic{r % 7} and Theme{r % 11}!")
+    got_t = eng.search_with_diversity(q, k, 0.3, query_text="topic3 theme5")
+    assert len(t_rows) == len(got_t) == k
+    assert [r for r, _, _ in t_rows] == [g.row for g in got_t]
+    assert np.allclose([s for _, s, _ in t_rows], [g.score for g in got_t], atol=1e-6)
+    assert np.allclose([l for _, _, l in t_rows], [g.lexical_score for g in got_t], atol=1e-6) and any(l > 0 for _, _, l in t_rows)
     eng.close()

@@ -366,3 +366,34 @@ def test_engine_search_text_with_more_candidates_than_one_workgroup_sorts(rlr, o
     else:
         assert retries == 0, retries
     eng.close()
+
+
+def test_engine_search_text_at_150k_chunks_sampled_selection_regime(rlr, oracle):
+    """150 k chunks, common query words (n_touched ~ the whole corpus), 1500 BM25 pairs wanted: the sampled selection works
+    from an 8192-entry sample of ~150 k keys (mu ~ 80 expected hits) -- the regime the C2 / 10 M-chunk deployments run
+    in.  Same answer as the oracle given the oracle's pairs, and no query needed the exact-path retry."""
+    n, dim = 150_000, 32
+    rng = np.random.default_rng(51)
+    zipf = 1.0 / np.arange(1, len(VOCAB) + 1)
+    zipf /= zipf.sum()
+    words = rng.choice(len(VOCAB), size=(n, 12), p=zipf)
+    lens = rng.integers(3, 13, size=n)
+    texts = [" ".join(VOCAB[w] for w in words[i, : lens[i]]) for i in range(n)]
+    rows = oracle.synth_rows(n, dim, seed=52)
+    eng = rlr.RagEngine(dim)
+    eng.add_document("d", texts, rows)
+    stored = eng.index.fetch_rows(np.arange(n))
+    o = OL.LexicalIndex()
+    for r, t in enumerate(texts):
+        o.add_chunk(r, t, rank=r)
+    for qi, (text, k, div) in enumerate([("w000x w001x w017x", 100, 0.3), ("w003x common", 100, 0.0), ("w100x w200x", 50, 0.7)]):
+        q = oracle.synth_query(dim, seed=53 + qi)
+        k_eff = k if div == 0.0 else max(3 * k, k + 10)
+        pairs = [(c, float(s)) for c, s in o.score(text, 5 * k_eff, keep_zero=False)]
+        got = eng.search_with_diversity(q, k, div, query_text=text)
+        wr, wc, we, wl = oracle.search_with_diversity(stored, q, k, div, lex=pairs)
+        assert [g_.row for g_ in got] == list(wr), (text, k, div)
+        assert np.array_equal(bits([g_.score for g_ in got]), bits(wc)), (text, k, div)
+        assert np.array_equal(bits([g_.lexical_score for g_ in got]), bits(wl)), (text, k, div)
+    assert eng.lexical.segments()["select_retries"] == 0
+    eng.close()
