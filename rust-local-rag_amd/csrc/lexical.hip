@@ -298,10 +298,25 @@ __global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restric
             ctl->thr = 0;
         return;
     }
-    for (uint32_t i = threadIdx.x; i < s; i += 1024) {
-        const uint32_t at = static_cast<uint32_t>(static_cast<uint64_t>(i) * n / s); // strided: every part of the list
-        const uint32_t row = touched[at];
-        s_k[i] = pack_result(scores[row], row);
+    // two dependent gathers per sample (list entry -> its score): all eight list loads of a thread first, then all
+    // eight score loads, instead of eight serial round trips
+    constexpr int kPer = kSampleMax / 1024;
+    uint32_t rows_[kPer];
+    float sc_[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const uint32_t i = threadIdx.x + 1024 * u;
+        const uint32_t at = i < s ? static_cast<uint32_t>(static_cast<uint64_t>(i) * n / s) : 0u; // strided: every part of the list
+        rows_[u] = touched[at];
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u)
+        sc_[u] = scores[rows_[u]];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const uint32_t i = threadIdx.x + 1024 * u;
+        if (i < s)
+            s_k[i] = pack_result(sc_[u], rows_[u]);
     }
     __syncthreads();
     const float mu = static_cast<float>(limit) * static_cast<float>(s) / static_cast<float>(n);
