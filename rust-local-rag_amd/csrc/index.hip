@@ -465,6 +465,7 @@ struct SearchPlan {
     float two_eps;
     float two_eps_img; // band when the nomination scan ran over the binary16 image
     float scale = 1.0f; // |row|_max * |query|_max when that exceeds 1 (the bands above already carry it)
+    bool unordered = false; // the consumer wants the best k as a SET (the hybrid blend re-orders everything anyway)
 };
 
 // The guard bands are error bounds for unit-norm operands; every term of them is linear in |row| * |query|.
@@ -533,9 +534,11 @@ __global__ __launch_bounds__(256) void hist_assert_zero_kernel(const uint32_t *_
 }
 
 // device-side: sort the re-scored candidates (<= kLdsSortCap) and emit the best k.
+// unordered: more than 1024 candidates are not sorted (a 2048-entry bitonic network: 22 us) -- the k best are found by a
+// radix select of the k-th key and written in any order (valid entries first, zeros behind, as in the sorted form).
 __global__ __launch_bounds__(1024) void sort_emit_kernel(uint64_t *__restrict__ packed, const SelectState *__restrict__ st,
                                                          uint64_t *__restrict__ out, uint32_t k,
-                                                         uint64_t *__restrict__ meta)
+                                                         uint64_t *__restrict__ meta, bool unordered)
 {
     __shared__ uint64_t s[4096];
     const uint32_t n_raw = st->n_cand;
@@ -563,6 +566,27 @@ __global__ __launch_bounds__(1024) void sort_emit_kernel(uint64_t *__restrict__ 
                 out[rank] = mine;
         }
         for (uint32_t i = n_raw + threadIdx.x; i < k; i += 1024)
+            out[i] = 0ull;
+        return;
+    }
+    if (unordered) {
+        __shared__ uint32_t s_hist[2048];
+        __shared__ uint32_t s_pick[3];
+        __shared__ uint32_t s_n;
+        for (uint32_t i = threadIdx.x; i < n_raw; i += 1024)
+            s[i] = packed[i];
+        if (threadIdx.x == 0)
+            s_n = 0;
+        __syncthreads();
+        uint64_t kth = 0;
+        if (n_raw > k)
+            kth = lds_kth_key64(s, n_raw, k, s_hist, s_pick, 1024); // unique keys: exactly k of them are >= kth
+        for (uint32_t i = threadIdx.x; i < n_raw; i += 1024) {
+            const uint64_t v = s[i];
+            if (v >= kth)
+                out[atomicAdd(&s_n, 1u)] = v;
+        }
+        for (uint32_t i = min(n_raw, k) + threadIdx.x; i < k; i += 1024)
             out[i] = 0ull;
         return;
     }
@@ -840,7 +864,7 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
     __shared__ uint32_t s_flag[kHybridLexMax]; // lexical pair j was reached by the fetch
     __shared__ uint32_t s_hist[2048];
     __shared__ uint32_t s_pick[2];
-    __shared__ uint32_t s_got, s_cand, s_nsel;
+    __shared__ uint32_t s_got, s_cand, s_nsel, s_emin;
     __shared__ float s_cneed;
     const uint32_t t = threadIdx.x;
     float *cc = cand, *ce = cand + kHybridSlots, *cl = cand + 2 * kHybridSlots;
@@ -858,6 +882,7 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
         s_cand = 0;
         s_nsel = 0;
         s_cneed = 0.0f;
+        s_emin = 0xFFFFFFFFu;
     }
     for (uint32_t i = t; i < kHybridHash; i += 1024)
         s_hrow[i] = 0;
@@ -884,9 +909,10 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
     for (uint32_t i = t; i < fetch; i += 1024) {
         const uint64_t p = overflow ? 0ull : packed[i];
         uint64_t key = 0;
-        if (p != 0) { // valid entries are a prefix: (cosine desc, row asc), padding zeros behind
+        if (p != 0) { // valid entries are a prefix (in no particular order), padding zeros behind
             const uint32_t row = 0xFFFFFFFFu - static_cast<uint32_t>(p & 0xFFFFFFFFull);
             const float e = key_score(static_cast<uint32_t>(p >> 32));
+            atomicMin(&s_emin, static_cast<uint32_t>(p >> 32)); // the smallest fetched cosine (NaN orders lowest)
             float l = 0.0f;
             uint32_t h = (row * 2654435761u) >> 20;
             for (;;) {
@@ -976,7 +1002,7 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
     if (t == 0) {
         uint32_t status = overflow ? 1u : flood ? 2u : 0u;
         if (!status && got < n_rows && got > 0) {
-            const float t0 = w_e * ce[got - 1]; // the smallest fetched cosine bounds every unfetched (non-lexical) row
+            const float t0 = w_e * key_score(s_emin); // the smallest fetched cosine bounds every unfetched (non-lexical) row
             const float t1 = w_l * 0.0f;
             const float c_tail = t0 + t1;
             const bool ok = n_cand >= need && (c_tail != c_tail || s_cneed > c_tail);
@@ -1123,7 +1149,7 @@ hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p
         e = hipMemsetAsync(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), s);
     }
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rlr::sort_emit_kernel, dim3(1), dim3(1024), 0, s, c->d_packed, st, d_out_q, p.k, d_meta_q);
+    hipLaunchKernelGGL(rlr::sort_emit_kernel, dim3(1), dim3(1024), 0, s, c->d_packed, st, d_out_q, p.k, d_meta_q, p.unordered);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(c->ev[3], s)) != hipSuccess) return e;
     return hipSuccess;
@@ -2342,6 +2368,7 @@ static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t nee
     p.two_eps = 2.0f * eps;
     p.two_eps_img = image_two_eps(ix, eps);
     p.cap = kLdsSortCap;
+    p.unordered = true; // the blend orders fetched and lexical rows together: it needs the fetched SET and its minimum
     RLR_TRY(ctx_prepare(ix, c, 1, p));
     const uint32_t P = need;
     const uint32_t k_cap = diversify ? std::max<uint32_t>(std::min<uint32_t>(std::max<uint32_t>(k, 1u), P), 1u) : P;
