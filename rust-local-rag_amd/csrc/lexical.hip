@@ -585,22 +585,6 @@ int32_t workspace_acquire(rlr_lexical *lx, LexWorkspace **out)
     }
 }
 
-struct WorkspaceLease {
-    rlr_lexical *lx;
-    LexWorkspace *ws = nullptr;
-    explicit WorkspaceLease(rlr_lexical *l) : lx(l) {}
-    ~WorkspaceLease()
-    {
-        if (!ws)
-            return;
-        {
-            std::lock_guard<std::mutex> lk(lx->ws_mu);
-            lx->ws_free.push_back(ws);
-        }
-        lx->ws_cv.notify_one();
-    }
-};
-
 int32_t commit_full(rlr_lexical *lx)
 {
     const uint64_t n_rows = lx->doc_terms.size();
