@@ -60,7 +60,9 @@ void rlr_lexical_destroy(rlr_lexical *lex);
 int32_t rlr_lexical_add_chunk(rlr_lexical *lex, uint64_t row, const char *tokens, size_t len);
 
 /* LexicalIndex::remove_chunk (:2139-2167) for a set of rows + the row compaction that
- * rlr_index_delete_rows performs.  Rows may be given in any order; unknown rows are ignored. */
+ * rlr_index_delete_rows performs.  Rows may be given in any order; unknown rows are ignored.  The device postings
+ * follow by an ordered compaction of both segments (three launches per segment, survivors renumbered in place of a
+ * host rebuild and re-upload: 3 ms instead of 0.17 s at 26.6 M postings). */
 int32_t rlr_lexical_remove_rows(rlr_lexical *lex, const uint64_t *rows, uint32_t n);
 
 /* LexicalIndex::clear (:2098-2104). */
@@ -85,8 +87,9 @@ int32_t rlr_lexical_segments(rlr_lexical *lex, uint64_t *main_postings, uint64_t
  * min(limit, RLR_LEXICAL_MAX_LIMIT) pairs, ordered (score desc, row asc); limit == 0 means
  * "no truncation" in the reference (:2220) and is served up to RLR_LEXICAL_MAX_LIMIT pairs.
  * The first call after a mutation brings the device postings up to date: appends (rows beyond every row present at
- * the last full rebuild) cost O(terms + appended postings); a replaced or removed row, or an appended segment that
- * has outgrown an eighth of the main one, costs a full rebuild. */
+ * the last full rebuild) cost O(terms + appended postings); a replaced row of the main segment, or an appended segment
+ * that has outgrown an eighth of the main one, costs a full rebuild (removals are applied to the device postings by
+ * rlr_lexical_remove_rows itself). */
 int32_t rlr_lexical_score(rlr_lexical *lex, const char *query_tokens, size_t len, uint32_t limit,
                           uint64_t *rows_out, float *scores_out, uint32_t *n_out);
 

@@ -404,6 +404,105 @@ __global__ __launch_bounds__(256) void lex_clear_kernel(float *__restrict__ scor
         scores[touched[i]] = 0.0f;
 }
 
+// ---- removal of rows without rebuilding the postings on the host ---------------------------------------------
+// rlr_lexical_remove_rows renumbers the surviving rows (the compaction rlr_index_delete_rows applies to the matrix).
+// On the device that is one ordered stream compaction per posting segment: drop the postings of removed rows, map
+// the others through remap[old row] -> new row, keep the order -- the CSR stays valid with the per-term counts the
+// host already maintains.  Three launches: survivors per 2048-posting block, exclusive scan of the block counts,
+// ordered scatter.
+constexpr uint32_t kDeadRow = 0xFFFFFFFFu;
+constexpr uint32_t kCsrBlock = 2048;
+
+__global__ __launch_bounds__(256) void csr_count_kernel(const uint32_t *__restrict__ post_row, uint64_t total,
+                                                        const uint32_t *__restrict__ remap, uint32_t *__restrict__ block_cnt)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0)
+        s_cnt = 0;
+    __syncthreads();
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kCsrBlock;
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < kCsrBlock / 256; ++j) {
+        const uint64_t i = base + j * 256 + threadIdx.x;
+        if (i < total && remap[post_row[i]] != kDeadRow)
+            ++mine;
+    }
+    if (mine)
+        atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        block_cnt[blockIdx.x] = s_cnt;
+}
+
+// in-place exclusive scan of nb counts by one workgroup (chunks of 1024 with a running carry)
+__global__ __launch_bounds__(1024) void csr_scan_kernel(uint32_t *__restrict__ v, uint32_t nb)
+{
+    __shared__ uint32_t s[1024];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0)
+        s_carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < nb; c0 += 1024) {
+        const uint32_t i = c0 + threadIdx.x;
+        const uint32_t x = i < nb ? v[i] : 0u;
+        s[threadIdx.x] = x;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan
+            const uint32_t add = threadIdx.x >= d ? s[threadIdx.x - d] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const uint32_t carry = s_carry;
+        if (i < nb)
+            v[i] = carry + s[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            s_carry = carry + s[1023];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void csr_scatter_kernel(const uint32_t *__restrict__ post_row, const uint32_t *__restrict__ post_tf,
+                                                          uint64_t total, const uint32_t *__restrict__ remap,
+                                                          const uint32_t *__restrict__ block_off, uint32_t *__restrict__ out_row,
+                                                          uint32_t *__restrict__ out_tf)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kCsrBlock;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        s_base = block_off[blockIdx.x];
+    __syncthreads();
+    for (uint32_t j = 0; j < kCsrBlock / 256; ++j) { // sub-chunks in order, threads in order inside one: a stable compaction
+        const uint64_t i = base + j * 256 + threadIdx.x;
+        uint32_t nr = kDeadRow, tf = 0;
+        if (i < total) {
+            nr = remap[post_row[i]];
+            tf = post_tf[i];
+        }
+        const bool keep = nr != kDeadRow;
+        const uint64_t mask = __ballot(keep);
+        if (lane == 0)
+            s_wave[wave] = static_cast<uint32_t>(__popcll(mask));
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w)
+            before += s_wave[w];
+        const uint32_t chunk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        const uint32_t at = s_base + before + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+        if (keep) {
+            out_row[at] = nr;
+            out_tf[at] = tf;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_base += chunk_total;
+        __syncthreads();
+    }
+}
+
 template <typename T>
 int32_t dev_grow(T **p, uint64_t *cap, uint64_t need, bool zero = false)
 {
@@ -485,6 +584,9 @@ struct rlr_lexical {
     uint32_t *d_post_row = nullptr, *d_post_tf = nullptr, *d_doc_len = nullptr;
     uint32_t *d_dpost_row = nullptr, *d_dpost_tf = nullptr;
     uint64_t post_cap = 0, post_tf_cap = 0, doc_cap = 0, dpost_cap = 0, dpost_tf_cap = 0;
+    uint32_t *d_remap = nullptr, *d_blocks = nullptr; // row removal on the device: old row -> new row, block counts
+    uint64_t remap_cap = 0, blocks_cap = 0;
+    uint64_t n_device_removals = 0;
     // ---- per-call workspaces
     std::mutex ws_mu;
     std::condition_variable ws_cv;
@@ -499,9 +601,12 @@ void remove_row_stats(rlr_lexical *lx, uint64_t row)
     auto &terms = lx->doc_terms[row];
     if (terms.empty())
         return;
+    const bool in_main = !lx->full_dirty && row < lx->main_rows; // (main_df is rebuilt anyway once full_dirty is set)
     for (const auto &tc : terms) {
         if (lx->df[tc.first] > 0 && --lx->df[tc.first] == 0)
             lx->n_live_terms--;
+        if (in_main && tc.first < lx->main_df.size() && lx->main_df[tc.first] > 0)
+            lx->main_df[tc.first]--;
     }
     lx->n_postings -= terms.size();
     const uint32_t len = lx->doc_len[row];
@@ -669,6 +774,78 @@ int32_t commit(rlr_lexical *lx)
     return commit_full(lx);
 }
 
+// Bring both posting segments, the per-term offsets and the document lengths in line with a removal the host state has
+// already absorbed.  remap: old row -> new row (kDeadRow: removed).  Caller holds the index exclusively.
+int32_t compact_segment(rlr_lexical *lx, uint32_t **rows, uint32_t **tfs, uint64_t *cap_rows, uint64_t *cap_tfs, uint64_t total,
+                        uint64_t new_total)
+{
+    if (total == 0)
+        return RLR_OK;
+    const uint32_t nb = static_cast<uint32_t>((total + kCsrBlock - 1) / kCsrBlock);
+    LEX_TRY(dev_grow(&lx->d_blocks, &lx->blocks_cap, nb));
+    uint32_t *out_rows = nullptr, *out_tfs = nullptr;
+    const uint64_t cap = std::max<uint64_t>(new_total + new_total / 8, 1024);
+    LEX_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&out_rows), cap * sizeof(uint32_t)));
+    hipError_t e = rlr::dev_malloc(reinterpret_cast<void **>(&out_tfs), cap * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(out_rows);
+        return set_error(RLR_E_OOM, "lexical compaction: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(csr_count_kernel, dim3(nb), dim3(256), 0, nullptr, *rows, total, lx->d_remap, lx->d_blocks);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, nullptr, lx->d_blocks, nb);
+    hipLaunchKernelGGL(csr_scatter_kernel, dim3(nb), dim3(256), 0, nullptr, *rows, *tfs, total, lx->d_remap, lx->d_blocks, out_rows,
+                       out_tfs);
+    e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        (void)hipFree(out_rows);
+        (void)hipFree(out_tfs);
+        return set_error(RLR_E_HIP, "lexical compaction failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(*rows);
+    (void)hipFree(*tfs);
+    *rows = out_rows;
+    *tfs = out_tfs;
+    *cap_rows = *cap_tfs = cap;
+    return RLR_OK;
+}
+
+int32_t remove_on_device(rlr_lexical *lx, const std::vector<uint32_t> &remap, uint64_t dead_main_rows, uint64_t dead_main_postings,
+                         uint64_t dead_delta_postings)
+{
+    LEX_HIP(hipSetDevice(lx->device));
+    LEX_TRY(dev_grow(&lx->d_remap, &lx->remap_cap, remap.size()));
+    LEX_HIP(hipMemcpy(lx->d_remap, remap.data(), remap.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const uint64_t new_main = lx->main_postings - dead_main_postings, new_delta = lx->delta_postings - dead_delta_postings;
+    LEX_TRY(compact_segment(lx, &lx->d_post_row, &lx->d_post_tf, &lx->post_cap, &lx->post_tf_cap, lx->main_postings, new_main));
+    LEX_TRY(compact_segment(lx, &lx->d_dpost_row, &lx->d_dpost_tf, &lx->dpost_cap, &lx->dpost_tf_cap, lx->delta_postings,
+                            new_delta));
+    // per-term offsets from the counts the host keeps (the compaction preserved the order inside every posting list)
+    const size_t n_terms = lx->df.size();
+    lx->main_df.resize(n_terms, 0);
+    lx->term_off.assign(n_terms + 1, 0);
+    lx->dterm_off.assign(n_terms + 1, 0);
+    for (size_t t = 0; t < n_terms; ++t) {
+        lx->term_off[t + 1] = lx->term_off[t] + lx->main_df[t];
+        lx->dterm_off[t + 1] = lx->dterm_off[t] + (lx->df[t] - lx->main_df[t]);
+    }
+    if (lx->term_off[n_terms] != new_main || lx->dterm_off[n_terms] != new_delta)
+        return set_error(RLR_E_HIP, "lexical compaction: posting counts disagree (%llu / %llu main, %llu / %llu appended)",
+                         static_cast<unsigned long long>(lx->term_off[n_terms]), static_cast<unsigned long long>(new_main),
+                         static_cast<unsigned long long>(lx->dterm_off[n_terms]), static_cast<unsigned long long>(new_delta));
+    lx->main_rows -= dead_main_rows;
+    lx->main_postings = new_main;
+    lx->delta_postings = new_delta;
+    const uint64_t n_rows = lx->doc_terms.size();
+    if (n_rows > lx->doc_cap || !lx->d_doc_len)
+        LEX_TRY(dev_grow(&lx->d_doc_len, &lx->doc_cap, n_rows + n_rows / 4));
+    if (n_rows)
+        LEX_HIP(hipMemcpy(lx->d_doc_len, lx->doc_len.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice));
+    lx->n_device_removals++;
+    return RLR_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -718,7 +895,7 @@ void rlr_lexical_destroy(rlr_lexical *lx)
     (void)hipSetDevice(lx->device);
     for (LexWorkspace *ws : lx->ws_free) // every call has returned (the caller's contract), so all of them are here
         workspace_destroy(ws);
-    void *dev[] = {lx->d_post_row, lx->d_post_tf, lx->d_doc_len, lx->d_dpost_row, lx->d_dpost_tf};
+    void *dev[] = {lx->d_post_row, lx->d_post_tf, lx->d_doc_len, lx->d_dpost_row, lx->d_dpost_tf, lx->d_remap, lx->d_blocks};
     for (void *p : dev)
         if (p)
             (void)hipFree(p);
@@ -788,16 +965,35 @@ int32_t rlr_lexical_remove_rows(rlr_lexical *lx, const uint64_t *rows, uint32_t 
         return set_error(RLR_E_INVALID, "rows is null");
     std::unique_lock<std::shared_mutex> lk(lx->mu);
     const uint64_t size = lx->doc_terms.size();
+    // The device postings can follow the removal by a compaction (no host rebuild, no re-upload) when they are current;
+    // pending appends are committed first (cheap: the appended segment only).
+    bool on_device = !lx->full_dirty && (lx->main_postings > 0 || lx->delta_postings > 0 || lx->delta_dirty);
+    if (on_device && lx->delta_dirty) {
+        LEX_HIP(hipSetDevice(lx->device));
+        LEX_TRY(commit_delta(lx));
+    }
     std::vector<char> dead(size, 0);
     bool any = false;
+    uint64_t dead_main_rows = 0, dead_main_postings = 0, dead_delta_postings = 0;
     for (uint32_t i = 0; i < n; ++i)
         if (rows[i] < size && !dead[rows[i]]) {
             dead[rows[i]] = 1;
-            remove_row_stats(lx, rows[i]);
+            if (on_device) {
+                if (rows[i] < lx->main_rows) {
+                    dead_main_rows++;
+                    dead_main_postings += lx->doc_terms[rows[i]].size();
+                } else {
+                    dead_delta_postings += lx->doc_terms[rows[i]].size();
+                }
+            }
+            remove_row_stats(lx, rows[i]); // (also takes the row's terms out of main_df)
             any = true;
         }
     if (!any)
         return RLR_OK;
+    std::vector<uint32_t> remap;
+    if (on_device)
+        remap.assign(size, kDeadRow);
     uint64_t w = 0; // stable compaction, the same renumbering rlr_index_delete_rows applies
     for (uint64_t r = 0; r < size; ++r)
         if (!dead[r]) {
@@ -805,12 +1001,20 @@ int32_t rlr_lexical_remove_rows(rlr_lexical *lx, const uint64_t *rows, uint32_t 
                 lx->doc_terms[w] = std::move(lx->doc_terms[r]);
                 lx->doc_len[w] = lx->doc_len[r];
             }
+            if (on_device)
+                remap[r] = static_cast<uint32_t>(w);
             ++w;
         }
     lx->doc_terms.resize(w);
     lx->doc_len.resize(w);
-    lx->full_dirty = true; // rows are renumbered
-    return RLR_OK;
+    if (!on_device || lx->main_postings >= 0xFFFFFFFFull || lx->delta_postings >= 0xFFFFFFFFull) {
+        lx->full_dirty = true; // rows are renumbered: the next score call rebuilds the postings
+        return RLR_OK;
+    }
+    const int32_t st = remove_on_device(lx, remap, dead_main_rows, dead_main_postings, dead_delta_postings);
+    if (st != RLR_OK)
+        lx->full_dirty = true; // whatever state the device arrays are in, the next commit replaces them
+    return st;
 }
 
 int32_t rlr_lexical_clear(rlr_lexical *lx)

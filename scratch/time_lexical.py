@@ -50,3 +50,8 @@ for i in range(50):
 print("search right after appending one chunk: median %.2f ms, max %.2f ms   segments %s" % (np.median(ts) * 1e3, max(ts) * 1e3, g.segments()), flush=True)
 g.add_tokens(5, vocab[rng.choice(V, size=30, p=zipf)])
 t0 = time.perf_counter(); g.score_tokens(["t00100", "t00200"], 100); print("search after replacing an old chunk (full rebuild): %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+# removal (a document re-ingest drops its old chunks first): both posting segments are compacted on the device
+for rows_ in ([7], list(range(1000, 1100)), list(range(50000, 50000 + 5000, 5))):
+    t0 = time.perf_counter(); g.remove_rows(rows_); t_rm = time.perf_counter() - t0
+    t0 = time.perf_counter(); g.score_tokens(["t00100", "t00200"], 100); t_sc = time.perf_counter() - t0
+    print("remove %4d rows: %.2f ms, search right after: %.2f ms   %s" % (len(rows_), t_rm * 1e3, t_sc * 1e3, g.segments()), flush=True)

@@ -218,7 +218,8 @@ def test_bm25_concurrent_score_calls_use_their_own_workspaces(rlr):
 def test_bm25_appends_rebuild_only_the_appended_segment(rlr):
     """An ingest loop that searches after every document: appended rows land in the second posting segment (no full
     rebuild), answers stay bit-equal to the oracle while statistics (df, average length) move under both segments;
-    replacing an old row, removing rows, and an appended segment that outgrows main / 8 each force one full rebuild."""
+    replacing an old row and an appended segment that outgrows main / 8 each force one full rebuild; removing rows does
+    not (both segments are compacted and renumbered on the device)."""
     texts = make_texts(6000, seed=21, lo=30, hi=60)             # ~200 k postings in the main segment
     g, o = build_pair(rlr, texts)
     queries = [("w000x w001x", 50), ("common frequent w010x", 200), ("w017x", 0), ("né Straße w399x", 20)]
@@ -249,17 +250,30 @@ def test_bm25_appends_rebuild_only_the_appended_segment(rlr):
     check(g, o, "w001x rewritten", 100)
     seg = g.segments()
     assert seg["full_rebuilds"] == 2 and seg["appended_postings"] == 0 and seg["main_postings"] == g.info()["n_postings"]
-    # removal renumbers rows: full rebuild
+    # removal renumbers rows: an ordered compaction of both segments on the device, no rebuild -- with appended rows present
+    g.add_chunk(n + len(extra), "w000x appendedbeforeremoval")
+    o.add_chunk(n + len(extra), "w000x appendedbeforeremoval", rank=n + len(extra))
+    check(g, o, "appendedbeforeremoval w000x", 50)
+    before = g.segments()
+    assert before["appended_postings"] == 2
     g.remove_rows([0, 17, n + 1])
     o2 = OL.LexicalIndex()
-    kept = [t for i, t in enumerate(texts + extra) if i not in (0, 17, n + 1)]
+    kept = [t for i, t in enumerate(texts + extra + ["w000x appendedbeforeremoval"]) if i not in (0, 17, n + 1)]
     kept[5 - 1] = "w001x rewritten early row"                   # row 5 moved down by the removal of row 0
     kept[n + 3 - 3] = "w000x w000x replaced"
     for r, t in enumerate(kept):
         o2.add_chunk(r, t, rank=r)
-    for q, lim in queries:
+    for q, lim in queries + [("appendedbeforeremoval w000x", 50), ("brandnewterm zzzunique", 10)]:
         check(g, o2, q, lim)
-    assert g.segments()["full_rebuilds"] == 3
+    seg = g.segments()
+    assert seg["full_rebuilds"] == 2 and seg["append_rebuilds"] == before["append_rebuilds"]   # nothing was rebuilt
+    assert seg["appended_postings"] == 2 and seg["main_postings"] == g.info()["n_postings"] - 2
+    # and appends keep working on the compacted segments
+    g.add_chunk(len(kept), "w001x afterremoval")
+    o2.add_chunk(len(kept), "w001x afterremoval", rank=len(kept))
+    kept.append("w001x afterremoval")
+    check(g, o2, "afterremoval w001x", 50)
+    assert g.segments()["full_rebuilds"] == 2
     # an appended segment larger than max(65536, main / 8) postings is folded into the main one
     big = make_texts(3000, seed=23, lo=30, hi=60)
     for i, t in enumerate(big):
@@ -268,7 +282,7 @@ def test_bm25_appends_rebuild_only_the_appended_segment(rlr):
     for q, lim in queries:
         check(g, o2, q, lim)
     seg = g.segments()
-    assert seg["full_rebuilds"] == 4 and seg["appended_postings"] == 0
+    assert seg["full_rebuilds"] == 3 and seg["appended_postings"] == 0
     g.close()
 
 
