@@ -411,3 +411,47 @@ def test_engine_search_text_at_150k_chunks_sampled_selection_regime(rlr, oracle)
         assert np.array_equal(bits([g_.lexical_score for g_ in got]), bits(wl)), (text, k, div)
     assert eng.lexical.segments()["select_retries"] == 0
     eng.close()
+
+
+def test_hybrid_entry_points_reject_bad_arguments_and_stay_usable(rlr, oracle):
+    """rlr_search_hybrid / rlr_engine_search_text argument checks (some of them after the scan has been enqueued: the stream is
+    drained and the search context handed back), and the index answers normally afterwards"""
+    import ctypes as C
+    N = rlr._native
+    L = N.lib()
+    n, dim = 3000, 64
+    rows = oracle.synth_rows(n, dim, seed=61)
+    eng = rlr.RagEngine(dim)
+    eng.add_document("d", make_texts(n, seed=62), rows)
+    q = oracle.normalize(oracle.synth_query(dim, seed=63))
+    out_r = np.zeros(64, np.uint64)
+    out_f = [np.zeros(64, np.float32) for _ in range(3)]
+    n_out, fb = C.c_uint32(), C.c_int32()
+
+    def hybrid(lrows, lscores, need=10, k=5, div=1, q_=q):
+        lr = np.ascontiguousarray(lrows, np.uint64)
+        ls = np.ascontiguousarray(lscores, np.float32)
+        return L.rlr_search_hybrid(eng.index.handle, q_.ctypes.data_as(N.f32p) if q_ is not None else None, need, k, 0.3, div, 0.7,
+                                   0.3, lr.ctypes.data_as(N.u64p), ls.ctypes.data_as(N.f32p), len(lrows), 2.0, -1.0,
+                                   out_r.ctypes.data_as(N.u64p), out_f[0].ctypes.data_as(N.f32p), out_f[1].ctypes.data_as(N.f32p),
+                                   out_f[2].ctypes.data_as(N.f32p), C.byref(n_out), C.byref(fb))
+
+    assert hybrid([5, 3], [1.0, 2.0]) == N.RLR_E_INVALID           # not ascending (detected after the scan was enqueued)
+    assert hybrid([5, 5], [1.0, 2.0]) == N.RLR_E_INVALID           # not unique
+    assert hybrid([5, n], [1.0, 2.0]) == N.RLR_E_INVALID           # outside the index
+    assert hybrid([5], [1.0], q_=None) == N.RLR_E_INVALID
+    assert hybrid([3, 5], [1.0, 2.0]) == N.RLR_OK and fb.value == 0 and n_out.value == 5
+    assert hybrid([3, 5], [1.0, 2.0], need=2000) == N.RLR_OK and fb.value == 1   # more candidates than the fused kernels keep
+    hits = (N.SearchHitC * 64)()
+    st = L.rlr_engine_search_text(eng.index.handle, None, q.ctypes.data_as(N.f32p), dim, b"w000x", 5, 5, 0.3, 0, None, hits, 64,
+                                  C.byref(n_out))
+    assert st == N.RLR_E_INVALID                                    # no lexical index
+    # everything still works
+    got = eng.search_with_diversity(q, 5, 0.3, query_text="w000x w001x")
+    o = OL.LexicalIndex()
+    for r, t in enumerate(make_texts(n, seed=62)):
+        o.add_chunk(r, t, rank=r)
+    pairs = [(c, float(s)) for c, s in o.score("w000x w001x", 5 * 15, keep_zero=False)]
+    wr, wc, _, _ = oracle.search_with_diversity(eng.index.fetch_rows(np.arange(n)), q, 5, 0.3, lex=pairs)
+    assert [g_.row for g_ in got] == list(wr) and np.array_equal(bits([g_.score for g_ in got]), bits(wc))
+    eng.close()
