@@ -703,6 +703,59 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
         n_out[q] = s_valid_overflow ? 0xFFFFFFFFu : m;
 }
 
+// The large-candidate path's finish (a guard band that outgrew the 4096-entry LDS sort: dense score distributions under
+// the 8-bit nomination, k in the thousands): the k best of n exactly re-scored keys in global memory by one workgroup --
+// radix select of the k-th key over the L2-resident list (3-6 passes, histograms in LDS), the winners gathered into LDS,
+// sorted, emitted.  One launch where a global bitonic network took log^2(n) of them.
+__global__ __launch_bounds__(1024) void topk_global_kernel(const uint64_t *__restrict__ keys, const SelectState *__restrict__ st,
+                                                           uint32_t cap, uint64_t *__restrict__ out, uint32_t k)
+{
+    __shared__ uint64_t s[4096];
+    __shared__ uint32_t s_hist[2048];
+    __shared__ uint32_t s_pick[3];
+    __shared__ uint32_t s_n;
+    const uint32_t n = min(st->n_cand, cap);
+    if (threadIdx.x == 0)
+        s_n = 0;
+    __syncthreads();
+    uint64_t kth = 0;
+    if (n > k)
+        kth = lds_kth_key64(keys, n, k, s_hist, s_pick, 1024); // (the helper only needs a pointer; keys are unique)
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint64_t v = keys[i];
+        if (v >= kth && v != 0) {
+            const uint32_t at = atomicAdd(&s_n, 1u);
+            if (at < 4096)
+                s[at] = v;
+        }
+    }
+    __syncthreads();
+    const uint32_t m = min(s_n, 4096u);
+    uint32_t n_pad = 1;
+    while (n_pad < m)
+        n_pad <<= 1;
+    for (uint32_t i = m + threadIdx.x; i < n_pad; i += 1024)
+        s[i] = 0;
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= n_pad; kk <<= 1)
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n_pad; i += 1024) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = s[i], b = s[ixj];
+                    const bool desc = (i & kk) == 0;
+                    if (desc ? (a < b) : (a > b)) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < k; i += 1024)
+        out[i] = i < m ? s[i] : 0ull;
+}
+
 __global__ void emit_kernel(const uint64_t *__restrict__ packed, uint32_t n, uint64_t *__restrict__ out, uint32_t k)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1200,9 +1253,20 @@ int32_t big_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint3
     h.cap = cap;
     RLR_HIP(hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, s));
     RLR_HIP(launch_collect(c->d_scores, n, st, c->d_cand, ix->n_cu, s));
-    RLR_HIP(launch_rescore(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st, c->d_packed, cap, s));
-    RLR_HIP(launch_sort_desc(c->d_packed, cap, s));
-    hipLaunchKernelGGL(rlr::emit_kernel, dim3((p.k + 255) / 256), dim3(256), 0, s, c->d_packed, n_cand, d_out_q, p.k);
+    static const bool old_finish = getenv("RLR_BIG_QUERY_SORT") != nullptr; // A/B and test switch: the global bitonic sort
+    hipError_t e = hipSuccess;
+    const bool staged = !old_finish && launch_rescore_staged(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st,
+                                                             c->d_packed, cap, nullptr, s, &e);
+    RLR_HIP(e);
+    if (!staged) // rows too large for the staged layout (or the switch): one lane per candidate
+        RLR_HIP(launch_rescore(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st, c->d_packed, cap, s));
+    if (!old_finish && p.k <= kLdsSortCap) {
+        // second level: the exact keys are selected and sorted by one workgroup
+        hipLaunchKernelGGL(rlr::topk_global_kernel, dim3(1), dim3(1024), 0, s, c->d_packed, st, cap, d_out_q, p.k);
+    } else {
+        RLR_HIP(launch_sort_desc(c->d_packed, cap, s));
+        hipLaunchKernelGGL(rlr::emit_kernel, dim3((p.k + 255) / 256), dim3(256), 0, s, c->d_packed, n_cand, d_out_q, p.k);
+    }
     RLR_HIP(hipGetLastError());
     RLR_HIP(hipStreamSynchronize(s));
     return RLR_OK;

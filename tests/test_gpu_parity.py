@@ -152,6 +152,39 @@ def test_duplicate_chunks_overflow_the_guard_band(rlr, oracle):
     ix.close()
 
 
+def test_dense_scores_under_the_8bit_nomination_take_the_second_level(rlr, oracle):
+    """a tight cluster around the query: tens of thousands of cosines inside the 8-bit nomination band, k in the hundreds to
+    thousands -- the band outgrows the 4096-entry LDS sort and the large-candidate path finishes by a one-workgroup radix
+    select over the exactly re-scored keys (it was a global bitonic network).  Bit-equal to the oracle; same for the f32
+    nomination with k = 3000 (> 1024 and the band near the limit) and for several queries at once."""
+    n, dim = 60000, 256
+    rng = np.random.default_rng(77)
+    q = oracle.synth_query(dim, seed=78)
+    centre = oracle.normalize(q)
+    rows = oracle.synth_rows(n, dim, seed=79)
+    tight = centre[None, :] + np.float32(0.02) * rng.standard_normal((30000, dim)).astype(np.float32)
+    rows[:30000] = tight / np.linalg.norm(tight, axis=1, keepdims=True).astype(np.float32)
+    ix = make_index(rlr, rows)
+    qn = oracle.normalize(q)
+    ix.enable_batch_image(False, q8=True)
+    for k in (100, 900, 3000):
+        ix.profile_read(reset=True)
+        r, c = ix.search_topk(qn, k)
+        wr, wc = oracle_topk(oracle, rows, qn, k)
+        assert np.array_equal(r[0], wr) and np.array_equal(bits(c[0]), bits(wc)), k
+    assert ix.profile_read().n_retries >= 1                     # at least the last one overflowed the LDS sort
+    q2 = oracle.normalize(centre + np.float32(0.05) * oracle.synth_query(dim, seed=80))
+    r, c = ix.search_topk(np.stack([qn, q2, qn]), 2000)
+    for i, qq in enumerate((qn, q2, qn)):
+        wr, wc = oracle_topk(oracle, rows, qq, 2000)
+        assert np.array_equal(r[i], wr) and np.array_equal(bits(c[i]), bits(wc)), i
+    ix.enable_batch_image(False)                                 # f32 nomination
+    r, c = ix.search_topk(qn, 3000)
+    wr, wc = oracle_topk(oracle, rows, qn, 3000)
+    assert np.array_equal(r[0], wr) and np.array_equal(bits(c[0]), bits(wc))
+    ix.close()
+
+
 def test_nan_and_zero_rows(rlr, oracle):
     rows = oracle.synth_rows(300, 768, seed=31)
     rows[5] = 0.0
