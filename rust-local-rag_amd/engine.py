@@ -187,14 +187,20 @@ class RagEngine:
         ls = np.ascontiguousarray(scores if scores else [0], dtype=np.float32)
         return lr, ls, len(rows)
 
+    _HIT_DTYPE = np.dtype([("row", "<u8"), ("score", "<f4"), ("embedding_score", "<f4"), ("lexical_score", "<f4"),
+                           ("initial_score", "<f4")])   # = _native.SearchHitC
+
     def _results(self, hits, n: int) -> List[SearchResult]:
+        if n == 0:
+            return []
+        # one view over the ctypes array and one tolist() instead of 5 n attribute reads (a third of a 0.3 ms search)
+        rows = np.frombuffer(hits, dtype=self._HIT_DTYPE, count=n).tolist()
+        chunks = self._chunks
         out = []
-        for i in range(n):
-            h = hits[i]
-            ch = self._chunks[h.row]
-            out.append(SearchResult(ch.text, float(h.score), ch.document_name, ch.id, ch.chunk_index, ch.page_number,
-                                    ch.section, float(h.embedding_score), float(h.lexical_score),
-                                    float(h.initial_score), None, None, None, int(h.row)))
+        for row, score, emb, lex, init in rows:
+            ch = chunks[row]
+            out.append(SearchResult(ch.text, score, ch.document_name, ch.id, ch.chunk_index, ch.page_number, ch.section,
+                                    emb, lex, init, None, None, None, row))
         return out
 
     # -- RagEngine::search (rag_engine.rs:470-701) -----------------------------------------
