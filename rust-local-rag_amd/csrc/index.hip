@@ -1255,12 +1255,15 @@ int32_t big_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint3
     RLR_HIP(launch_collect(c->d_scores, n, st, c->d_cand, ix->n_cu, s));
     static const bool old_finish = getenv("RLR_BIG_QUERY_SORT") != nullptr; // A/B and test switch: the global bitonic sort
     hipError_t e = hipSuccess;
-    const bool staged = !old_finish && launch_rescore_staged(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st,
-                                                             c->d_packed, cap, nullptr, s, &e);
+    const bool second_level = !old_finish && p.k <= kLdsSortCap;
+    // (the staged kernel writes the n_cand keys only; the global sort below needs the zero padding up to `cap` that the
+    // one-lane kernel writes)
+    const bool staged = second_level && launch_rescore_staged(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st,
+                                                              c->d_packed, cap, nullptr, s, &e);
     RLR_HIP(e);
-    if (!staged) // rows too large for the staged layout (or the switch): one lane per candidate
+    if (!staged) // rows too large for the staged layout, k beyond the one-workgroup finish, or the switch
         RLR_HIP(launch_rescore(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, c->d_cand, st, c->d_packed, cap, s));
-    if (!old_finish && p.k <= kLdsSortCap) {
+    if (second_level) {
         // second level: the exact keys are selected and sorted by one workgroup
         hipLaunchKernelGGL(rlr::topk_global_kernel, dim3(1), dim3(1024), 0, s, c->d_packed, st, cap, d_out_q, p.k);
     } else {

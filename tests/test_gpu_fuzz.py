@@ -328,6 +328,13 @@ def test_poisoned_allocations():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "multi-shard fuzz ok" in out.stdout
+    # and the directed tests of the paths with the most scratch buffers: large-candidate finishes, fused / hybrid searches,
+    # the lexical index (a large-candidate finish once sorted the uninitialised tail of its key buffer: only this mode saw it)
+    sel = "k_larger or dense or overflow or flood or search_diverse or config2 or hybrid or text or bm25 or mmr_single"
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k", sel,
+                          os.path.join("tests", "test_gpu_parity.py"), os.path.join("tests", "test_gpu_lexical.py")],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_lexical_sampled_selection_retry_path():
