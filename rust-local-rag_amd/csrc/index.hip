@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -153,7 +154,10 @@ struct rlr_index {
     void *d_image = nullptr;
     size_t image_cap = 0;       // bytes
     std::mutex mu;
+    std::condition_variable ctx_cv; // callers beyond ctx_cap wait here for a context to come back
     std::vector<Ctx *> free_ctx;
+    int ctx_made = 0;               // contexts alive (in free_ctx or leased)
+    int ctx_cap = 16;               // RLR_MAX_CONTEXTS (1..64)
     bool profiling = false;
     rlr_profile prof{};
 };
@@ -262,25 +266,48 @@ void ctx_free(Ctx *c)
     delete c;
 }
 
+// A free context, a new one while fewer than ctx_cap exist, else wait until a call hands one back.  The reference serves
+// searches from one tokio worker per core under a read lock (src/main.rs:140, src/mcp_server.rs:89, :377): callers may be
+// many, but every context costs a stream, pinned memory and n_rows x 4 B of scores, and more streams than hardware
+// queues buy no overlap -- so the pool is bounded like the lexical index' workspaces and the surplus callers queue.
 int32_t ctx_acquire(rlr_index *ix, Ctx **out)
 {
     {
-        std::lock_guard<std::mutex> lk(ix->mu);
-        if (!ix->free_ctx.empty()) {
-            *out = ix->free_ctx.back();
-            ix->free_ctx.pop_back();
-            if ((*out)->hist_dirty) { // a previous call failed half way: restore the zero-histogram invariant
-                (void)hipStreamSynchronize((*out)->stream);
-                // (on the context's own stream: the null stream does not order against a non-blocking one)
-                if (hipMemsetAsync((*out)->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), (*out)->stream) == hipSuccess)
-                    (*out)->hist_dirty = false;
+        std::unique_lock<std::mutex> lk(ix->mu);
+        for (;;) {
+            if (!ix->free_ctx.empty()) {
+                Ctx *c = ix->free_ctx.back();
+                ix->free_ctx.pop_back();
+                lk.unlock();
+                if (c->hist_dirty) { // a previous call failed half way: restore the zero-histogram invariant
+                    (void)hipStreamSynchronize(c->stream);
+                    // (on the context's own stream: the null stream does not order against a non-blocking one)
+                    if (hipMemsetAsync(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), c->stream) == hipSuccess)
+                        c->hist_dirty = false;
+                }
+                *out = c;
+                return RLR_OK;
             }
-            return RLR_OK;
+            if (ix->ctx_made < ix->ctx_cap) {
+                ix->ctx_made++;
+                break;
+            }
+            ix->ctx_cv.wait(lk);
         }
     }
+    auto give_up = [ix](Ctx *c) {
+        ctx_free(c);
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            ix->ctx_made--;
+        }
+        ix->ctx_cv.notify_one();
+    };
     Ctx *c = new (std::nothrow) Ctx();
-    if (!c)
+    if (!c) {
+        give_up(nullptr);
         return fail(RLR_E_OOM, "host allocation failed");
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; ++i)
         e = hipEventCreate(&c->ev[i]);
@@ -302,7 +329,7 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
     if (e == hipSuccess)
         e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
-        ctx_free(c);
+        give_up(c);
         return fail(RLR_E_HIP, "context setup failed: %s", hipGetErrorString(e));
     }
     *out = c;
@@ -311,8 +338,11 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
 
 void ctx_release(rlr_index *ix, Ctx *c)
 {
-    std::lock_guard<std::mutex> lk(ix->mu);
-    ix->free_ctx.push_back(c);
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        ix->free_ctx.push_back(c);
+    }
+    ix->ctx_cv.notify_one();
 }
 
 struct CtxLease {
@@ -1713,6 +1743,8 @@ int32_t rlr_index_create(uint32_t dim, int32_t dtype, int32_t device_id, rlr_ind
         ix->scan_variant = static_cast<int>(strtol(v, nullptr, 0));
     if (const char *v = getenv("RLR_BATCH_MIN"))
         ix->batch_min = static_cast<uint32_t>(strtoul(v, nullptr, 0));
+    if (const char *v = getenv("RLR_MAX_CONTEXTS"))
+        ix->ctx_cap = static_cast<int>(std::min<long>(std::max<long>(strtol(v, nullptr, 0), 1), 64));
     *out = ix;
     return RLR_OK;
 }

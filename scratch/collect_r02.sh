@@ -24,7 +24,7 @@ run b256_fetch --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_b256_fetch -- $
 run c2_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_c2_kt -- python3 $R/scratch/time_c2_abi.py
 run hyb_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_hyb_kt -- python3 $R/scratch/time_c2_hybrid.py hybrid-only
 run c5_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_c5_kt -- python3 $R/scratch/time_c5_shard.py --image
-run lex_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_lex_kt -- python3 $R/scratch/time_lexical.py 200000
+run lex_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_lex_kt -- python3 $R/scratch/time_lexical.py 200000 --serial
 run multi8_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_multi8_kt -- python3 $R/bench.py --batch 8 --steps 20 --warmup 3 --no-cpu --settle-ms 0
 grep -h '"metric"' $O/${TAG}_multi8_kt.log | tail -1 > $O/${TAG}_bench_batch8_under_rocprof.json
 cd $R

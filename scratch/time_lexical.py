@@ -39,7 +39,9 @@ def run(n_threads, per=200):
     for t in ts: t.join()
     dt = time.perf_counter() - t0
     print("%2d caller threads: %8.0f score calls/s" % (n_threads, n_threads * per / dt), flush=True)
-for nt in (1, 2, 4, 8):  # (more callers than workspaces: scratch/stress_lexical_threads.py)
+# --serial: one caller only.  Used for profile collection: several host threads submitting under rocprofv3's queue
+# interception trip a ROCr 7.2 / rocprofiler-sdk defect (profiles/r03_profiled_stress_aborts.md); unprofiled, the full sweep runs.
+for nt in ((1,) if "--serial" in sys.argv else (1, 2, 4, 8, 16, 32)):
     run(nt)
 
 # ingest loop: one appended chunk, then a search (the commit rebuilds only the appended segment)
