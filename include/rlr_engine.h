@@ -130,6 +130,36 @@ int32_t rlr_engine_embedding_candidates(rlr_index *idx, const float *query_raw, 
                                         uint32_t count, uint64_t *rows_out, float *scores_out,
                                         uint32_t *n_out);
 
+/* ---- the same entry points over a corpus sharded across several GPUs in ONE process (rlr_multi, include/rlr_gpu.h) ----
+ * The reference is a single-process server whose surface is RagEngine::search / search_with_diversity
+ * (rag_engine.rs:470-475, :717-723, called from mcp_server.rs:89-93); a corpus that does not fit one GPU (BASELINE
+ * config 4: 100 M x 768 f32) is held by an rlr_multi and searched through these.  Same arguments, defaults, fall-backs
+ * and results as the rlr_engine_* functions above over one index holding every row -- the host logic is the same code
+ * (csrc/engine_host.h) on the sharded primitives: per-shard scan + exchange + merge for the candidates
+ * (rlr_multi_search_topk: host merge or RCCL all-gather, rlr_multi_set_exchange), reference-order cosines of the
+ * lexical rows from the shards that own them, and MMR with the on-fabric winner-row exchange
+ * (rlr_multi_mmr_select(_batch)).  Row numbers are global.  `lex` of _search_text is ONE GPU LexicalIndex over the
+ * global rows (BM25 postings are small next to the embeddings; they stay on one device). */
+int32_t rlr_multi_engine_search(rlr_multi *m, const float *query_raw, uint32_t dq, uint32_t top_k,
+                                const rlr_query_weights *weights, const uint64_t *lex_rows, const float *lex_scores,
+                                uint32_t n_lex, int32_t stage, rlr_search_hit *out, uint32_t cap, uint32_t *n_out);
+int32_t rlr_multi_engine_search_with_diversity(rlr_multi *m, const float *query_raw, uint32_t dq, uint32_t top_k,
+                                               float diversity_factor, const rlr_query_weights *weights,
+                                               const uint64_t *lex_rows, const float *lex_scores, uint32_t n_lex,
+                                               rlr_search_hit *out, uint32_t cap, uint32_t *n_out);
+int32_t rlr_multi_engine_search_text(rlr_multi *m, rlr_lexical *lex, const float *query_raw, uint32_t dq,
+                                     const char *query_tokens, size_t tokens_len, uint32_t top_k, float diversity_factor,
+                                     int32_t stage, const rlr_query_weights *weights, rlr_search_hit *out, uint32_t cap,
+                                     uint32_t *n_out);
+/* BASELINE config 5's shape (1024 queries, top-100, lambda 0.7 over a sharded corpus): one batched top-k per shard +
+ * exchange, per-query pools, one batched cross-shard MMR. */
+int32_t rlr_multi_engine_search_with_diversity_batch(rlr_multi *m, const float *queries_raw, uint32_t dq,
+                                                     uint32_t n_queries, uint32_t top_k, float diversity_factor,
+                                                     const rlr_query_weights *weights, rlr_search_hit *out,
+                                                     uint32_t cap, uint32_t *n_out);
+int32_t rlr_multi_engine_embedding_candidates(rlr_multi *m, const float *query_raw, uint32_t dq, uint32_t count,
+                                              uint64_t *rows_out, float *scores_out, uint32_t *n_out);
+
 /* ---- corpus file at scale ---------------------------------------------------------
  * `chunks_{model}.json` (PersistedState, rag_engine.rs:1478-1499; read whole with serde_json :1555-1557) read
  * in one streaming pass over the memory-mapped file: the embedding arrays go straight into a dense row-major f32

@@ -225,10 +225,22 @@ int32_t rlr_search_topk_device(rlr_index *idx, const float *queries, uint32_t n_
  * Returns after the gather has finished.  replaces: the embedding re-lookup rag_engine.rs:742-753
  * for rows that live on this GPU. */
 int32_t rlr_fetch_rows_device(rlr_index *idx, const uint64_t *rows, uint32_t n, void *d_out);
+/* The same gather without the widening: rows as the index stores them (rlr_index_row_bytes bytes each: dim elements
+ * of the index' dtype, padded to 16 bytes), dense, in DEVICE memory -- the send side of the one-process winner-row
+ * exchange (binary16 rows travel as 2 bytes per element).  Returns after the gather has finished. */
+int32_t rlr_gather_rows_device(rlr_index *idx, const uint64_t *rows, uint32_t n, void *d_out);
+int32_t rlr_index_row_bytes(const rlr_index *idx, uint32_t *bytes_out);
 /* rlr_mmr_select_batch for pools whose row VALUES are already in device memory (after the
  * exchange): d_values is n_queries x P x dim f32 on idx's device, complete before the call
  * (synchronise the stream that produced it).  `idx` supplies the device, dim and workspace; its
  * rows are not read.  Everything else as rlr_mmr_select_batch. */
+/* rlr_mmr_select_batch for pools whose rows sit in a STAGED matrix in device memory instead of the index: d_staged =
+ * n_staged raw rows in idx's dtype and row pitch (what rlr_gather_rows_device writes; e.g. the receive buffer of the
+ * winner-row exchange), pool_slots[q * P + j] = the staged row that is candidate j of pool q.  `idx` supplies device,
+ * dim, dtype and workspace; its own rows are not read.  n_queries == 1 takes pools up to 4096 candidates. */
+int32_t rlr_mmr_select_staged(rlr_index *idx, const void *d_staged, uint64_t n_staged, const uint64_t *pool_slots,
+                              const float *pool_scores, const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P,
+                              uint32_t k, float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out);
 int32_t rlr_mmr_select_values(rlr_index *idx, const void *d_values, const float *pool_scores,
                               const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k,
                               float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out);
@@ -288,10 +300,31 @@ int32_t rlr_multi_search_topk(rlr_multi *m, const float *queries, uint32_t n_que
                               float guard_eps, uint64_t *rows_out, float *cos_out, uint32_t *n_out);
 int32_t rlr_multi_score_rows(rlr_multi *m, const float *query, const uint64_t *rows, uint32_t n, float *cos_out);
 int32_t rlr_multi_fetch_rows(rlr_multi *m, const uint64_t *rows, uint32_t n, float *out);
-/* MMR over a pool whose rows live on different shards: the pool rows are gathered to the first
- * device (P x dim f32, < 1 MB for the reference's pool of 300) and selected there. */
+/* MMR over pools whose rows live on different shards (SURVEY.md 8(e) "MMR on sharded data"; replaces the embedding
+ * re-lookup + mmr_diversify of rag_engine.rs:742-756 for a sharded corpus).  The winner-row exchange stays on the
+ * fabric: every shard gathers the pool rows it owns on its own device (raw rows: binary16 stays binary16), one
+ * device-to-device copy per (source shard, owner) pair (hipMemcpyPeerAsync over xGMI; no host bounce) puts them into
+ * the receive buffer of the GPU that owns the query -- query q is diversified on shard q mod n_shards -- and that GPU
+ * runs the Gram + greedy kernels over its buffer.  Same results as rlr_mmr_select(_batch) over one index holding every
+ * row.  Arguments as rlr_mmr_select / rlr_mmr_select_batch with GLOBAL row numbers; one pool: P <= 4096, batch:
+ * P <= 1024.  Concurrent callers are served (up to four exchanges in flight, the rest wait). */
 int32_t rlr_multi_mmr_select(rlr_multi *m, const uint64_t *pool_rows, const float *pool_scores, uint32_t P,
                              uint32_t k, float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out);
+int32_t rlr_multi_mmr_select_batch(rlr_multi *m, const uint64_t *pool_rows, const float *pool_scores,
+                                   const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k, float lambda,
+                                   uint32_t *order_out, float *mmr_out, uint32_t *n_out);
+/* Which path the calls on this handle took (no reference counterpart; a multi-GPU run explains its own numbers):
+ * rlr_multi_search_topk calls served by the RCCL exchange / by the host merge / RCCL calls that fell through to the
+ * host merge (more than 16 shards, shards x k > 8192, a shard's guard band overflowed), wall time of the RCCL form
+ * (local pipelines + all-gather + merge kernel), and the cross-shard MMR exchanges with their bytes and wall time
+ * (gather + device-to-device copies, without the Gram / greedy kernels). */
+typedef struct rlr_multi_stats_t {
+    uint64_t n_topk_rccl, n_topk_host_merge, n_topk_rccl_fell_back;
+    double topk_rccl_ms;
+    uint64_t n_mmr_exchanges, mmr_exchange_bytes;
+    double mmr_exchange_ms;
+} rlr_multi_stats_t;
+int32_t rlr_multi_stats(rlr_multi *m, rlr_multi_stats_t *out, int32_t reset);
 
 /* ---- measurement hooks --------------------------------------------------- */
 typedef struct rlr_profile {

@@ -6,6 +6,7 @@
 // rlr_search_topk / rlr_score_rows, MMR from rlr_mmr_select.
 #include "../../include/rlr_engine.h"
 #include "../../include/rlr_lexical.h"
+#include "engine_host.h"
 #include "lexical_internal.h"
 
 #include <algorithm>
@@ -55,82 +56,34 @@ const rlr_resolved_weights &cached_defaults()
     return g_defaults;
 }
 
-struct Cand {
-    uint64_t row;
-    float c, e, l;
-};
+using namespace rlr_host;
 
-// (combined desc, row asc), NaN last
-bool cand_before(const Cand &a, const Cand &b)
-{
-    const bool an = std::isnan(a.c), bn = std::isnan(b.c);
-    if (an || bn) {
-        if (an != bn)
-            return bn;
-        return a.row < b.row;
-    }
-    if (a.c != b.c)
-        return a.c > b.c;
-    return a.row < b.row;
-}
-
-float combine(const rlr_resolved_weights &w, float e, float l)
-{
-    const float t0 = w.embedding * e; // :531-532, two rounded products then one add
-    const float t1 = w.lexical * l;
-    return t0 + t1;
-}
-
-// query_embedding after `normalize` (:494), shaped to the index dim the way dot_product's
-// zip would see it (:1778): extra components are dropped, missing ones contribute 0.
-std::vector<float> prepare_query(const float *query_raw, uint32_t dq, uint32_t dim)
-{
-    std::vector<float> q(query_raw, query_raw + dq);
-    rlr_normalize(q.data(), q.size());
-    q.resize(dim, 0.0f);
-    return q;
-}
-
-// The lexical map of search() (:505-506, a HashMap: a repeated chunk keeps its LAST score) as ascending unique rows,
-// and max_lexical (:515-519: over every pair, floored at f32::EPSILON).
-struct LexPrep {
-    std::vector<uint64_t> rows;
-    std::vector<float> scores;
-    float max_lex = 1.1920929e-07f;
-    // normalised lexical score of `row`, 0 when it has none (:527-530)
-    bool find(uint64_t row, float *l) const
+// one index on one GPU as a backend of engine_host.h
+struct SingleBackend {
+    rlr_index *idx;
+    uint64_t n_rows = 0;
+    uint32_t dim = 0;
+    int32_t topk(const float *queries, uint32_t nq, uint32_t k, uint64_t *rows, float *cos, uint32_t *n) const
     {
-        const auto it = std::lower_bound(rows.begin(), rows.end(), row);
-        if (it == rows.end() || *it != row)
-            return false;
-        *l = scores[static_cast<size_t>(it - rows.begin())] / max_lex;
-        return true;
+        return rlr_search_topk(idx, queries, nq, k, -1.0f, rows, cos, n);
+    }
+    int32_t score_rows(const float *query, const uint64_t *rows, uint32_t n, float *cos) const
+    {
+        return rlr_score_rows(idx, query, rows, n, cos);
+    }
+    int32_t mmr(const uint64_t *pool_rows, const float *pool_scores, const uint32_t *pool_sizes, uint32_t nq, uint32_t P,
+                uint32_t k, float lambda, uint32_t *order, uint32_t *n_sel) const
+    {
+        if (nq == 1)
+            return rlr_mmr_select(idx, pool_rows, pool_scores, pool_sizes[0], k, lambda, order, nullptr, n_sel);
+        return rlr_mmr_select_batch(idx, pool_rows, pool_scores, pool_sizes, nq, P, k, lambda, order, nullptr, n_sel);
     }
 };
 
-LexPrep prepare_lexical(uint64_t N, const uint64_t *lex_rows, const float *lex_scores, uint32_t n_lex)
+int32_t single_backend(rlr_index *idx, SingleBackend *be)
 {
-    LexPrep p;
-    float max_lex = 0.0f;
-    std::vector<uint32_t> order;
-    order.reserve(n_lex);
-    for (uint32_t i = 0; i < n_lex; ++i) {
-        max_lex = std::fmax(max_lex, lex_scores[i]);
-        if (lex_rows[i] < N)
-            order.push_back(i);
-    }
-    if (max_lex >= 1.1920929e-07f)
-        p.max_lex = max_lex;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lex_rows[a] < lex_rows[b]; });
-    p.rows.reserve(order.size());
-    p.scores.reserve(order.size());
-    for (size_t i = 0; i < order.size(); ++i) {
-        if (i + 1 < order.size() && lex_rows[order[i + 1]] == lex_rows[order[i]])
-            continue; // a later pair for the same chunk overwrites this one
-        p.rows.push_back(lex_rows[order[i]]);
-        p.scores.push_back(lex_scores[order[i]]);
-    }
-    return p;
+    be->idx = idx;
+    return rlr_index_info(idx, &be->n_rows, &be->dim, nullptr, nullptr);
 }
 
 int32_t search_impl(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_t top_k,
@@ -176,95 +129,11 @@ int32_t search_impl(rlr_index *idx, const float *query_raw, uint32_t dq, uint32_
         }
     }
 
-    std::vector<float> lcos(lrows.size());
-    if (!lrows.empty()) {
-        st = rlr_score_rows(idx, q.data(), lrows.data(), static_cast<uint32_t>(lrows.size()), lcos.data());
-        if (st != RLR_OK)
-            return st;
-    }
-
-    std::vector<Cand> cands;
-    if (w.embedding == 0.0f) {
-        // every non-lexical row scores 0*e + w_l*0 = 0 -> they tie and the build's tie rule
-        // (row asc) picks the lowest rows; no scan needed, only their cosines for reporting.
-        const uint64_t take = std::min<uint64_t>(N, need + lrows.size());
-        std::vector<uint64_t> rows(take);
-        for (uint64_t r = 0; r < take; ++r)
-            rows[r] = r;
-        std::vector<float> cosv(take);
-        st = rlr_score_rows(idx, q.data(), rows.data(), static_cast<uint32_t>(take), cosv.data());
-        if (st != RLR_OK)
-            return st;
-        for (uint64_t r = 0; r < take; ++r) {
-            float l = 0.0f;
-            (void)lex.find(r, &l);
-            cands.push_back({r, combine(w, cosv[r], l), cosv[r], l});
-        }
-        for (size_t i = 0; i < lrows.size(); ++i)
-            if (lrows[i] >= take) {
-                const float l = lex.scores[i] / lex.max_lex;
-                cands.push_back({lrows[i], combine(w, lcos[i], l), lcos[i], l});
-            }
-        std::sort(cands.begin(), cands.end(), cand_before);
-    } else {
-        // Non-lexical rows are ordered by cosine alone (w_e > 0 and rounding is monotone), so
-        // the device top-(need + n_lex + slack) by cosine, united with the lexical rows,
-        // contains the top-`need` by combined score.  Distinct cosines can round to the same
-        // combined score; if such a tie chain reaches the last fetched row the fetch is widened.
-        uint64_t fetch = std::min<uint64_t>(N, need + lrows.size() + 8);
-        std::vector<uint64_t> rows;
-        std::vector<float> cosv;
-        std::vector<char> seen(lrows.size());
-        for (;;) {
-            rows.assign(fetch, 0);
-            cosv.assign(fetch, 0.0f);
-            uint32_t got = 0;
-            st = rlr_search_topk(idx, q.data(), 1, static_cast<uint32_t>(fetch), -1.0f, rows.data(), cosv.data(), &got);
-            if (st != RLR_OK)
-                return st;
-            cands.clear();
-            std::fill(seen.begin(), seen.end(), 0);
-            for (uint32_t i = 0; i < got; ++i) {
-                float l = 0.0f;
-                const auto it = std::lower_bound(lrows.begin(), lrows.end(), rows[i]);
-                if (it != lrows.end() && *it == rows[i]) {
-                    const size_t j = static_cast<size_t>(it - lrows.begin());
-                    l = lex.scores[j] / lex.max_lex;
-                    seen[j] = 1;
-                }
-                cands.push_back({rows[i], combine(w, cosv[i], l), cosv[i], l});
-            }
-            for (size_t i = 0; i < lrows.size(); ++i)
-                if (!seen[i]) {
-                    const float l = lex.scores[i] / lex.max_lex;
-                    cands.push_back({lrows[i], combine(w, lcos[i], l), lcos[i], l});
-                }
-            std::sort(cands.begin(), cands.end(), cand_before);
-            if (got >= N || got == 0)
-                break;
-            const float c_tail = combine(w, cosv[got - 1], 0.0f); // bound on every unfetched row
-            if (cands.size() >= need && (std::isnan(c_tail) || cands[need - 1].c > c_tail))
-                break;
-            fetch = std::min<uint64_t>(N, fetch * 2);
-        }
-    }
-    if (cands.size() > need)
-        cands.resize(need);
-    result.swap(cands);
-    return RLR_OK;
-}
-
-void emit(const std::vector<Cand> &v, rlr_search_hit *out, uint32_t cap, uint32_t *n_out)
-{
-    const uint32_t n = static_cast<uint32_t>(std::min<size_t>(v.size(), cap));
-    for (uint32_t i = 0; i < n; ++i) {
-        out[i].row = v[i].row;
-        out[i].score = v[i].c;
-        out[i].embedding_score = v[i].e;
-        out[i].lexical_score = v[i].l;
-        out[i].initial_score = v[i].c;
-    }
-    *n_out = n;
+    SingleBackend be;
+    be.idx = idx;
+    be.n_rows = N;
+    be.dim = dim;
+    return blend_search(be, q, need, w, lex, result);
 }
 
 } // namespace
@@ -521,99 +390,20 @@ int32_t rlr_engine_search_with_diversity_batch(rlr_index *idx, const float *quer
         n_out[q] = 0;
     if (n_queries == 0)
         return RLR_OK;
-    uint64_t N = 0;
-    uint32_t dim = 0;
-    int32_t st = rlr_index_info(idx, &N, &dim, nullptr, nullptr);
+    SingleBackend be;
+    int32_t st = single_backend(idx, &be);
     if (st != RLR_OK)
         return st;
-    if (N == 0)
-        return RLR_OK;
     if (diversity_factor < 0.0f) diversity_factor = 0.0f;
     if (diversity_factor > 1.0f) diversity_factor = 1.0f;
     rlr_resolved_weights w;
     rlr_resolve_weights(weights, &w);
-    const bool plain = diversity_factor == 0.0f;
-    const uint32_t k_eff = std::max<uint32_t>(plain ? top_k : static_cast<uint32_t>(std::min<uint64_t>(
-                                                                  std::max<uint64_t>(static_cast<uint64_t>(top_k) * 3, static_cast<uint64_t>(top_k) + 10),
-                                                                  0xFFFFFFFFull)),
-                                              1u); // search() treats 0 as 1 (:490)
-    const uint64_t need = std::min<uint64_t>(N, k_eff);
-
-    auto single = [&](uint32_t q) -> int32_t { // reference path for one query of the batch
-        return rlr_engine_search_with_diversity(idx, queries_raw + static_cast<size_t>(q) * dq, dq, top_k, diversity_factor,
-                                                weights, nullptr, nullptr, 0, out + static_cast<size_t>(q) * cap, cap,
-                                                &n_out[q]);
-    };
-    if (w.embedding == 0.0f || need > 1024) { // degenerate weight / pool beyond the batched MMR: loop
-        for (uint32_t q = 0; q < n_queries; ++q)
-            if ((st = single(q)) != RLR_OK)
-                return st;
-        return RLR_OK;
-    }
-
-    std::vector<float> qn(static_cast<size_t>(n_queries) * dim);
-    for (uint32_t q = 0; q < n_queries; ++q) {
-        const std::vector<float> v = prepare_query(queries_raw + static_cast<size_t>(q) * dq, dq, dim);
-        std::memcpy(qn.data() + static_cast<size_t>(q) * dim, v.data(), dim * sizeof(float));
-    }
-    const uint32_t fetch = static_cast<uint32_t>(std::min<uint64_t>(N, need + 8));
-    std::vector<uint64_t> rows(static_cast<size_t>(n_queries) * fetch);
-    std::vector<float> cosv(static_cast<size_t>(n_queries) * fetch);
-    std::vector<uint32_t> got(n_queries);
-    st = rlr_search_topk(idx, qn.data(), n_queries, fetch, -1.0f, rows.data(), cosv.data(), got.data());
+    std::vector<std::vector<Cand>> results;
+    st = generic_search_with_diversity_batch(be, queries_raw, dq, n_queries, top_k, diversity_factor, w, results);
     if (st != RLR_OK)
         return st;
-
-    const uint32_t P = static_cast<uint32_t>(need);
-    std::vector<std::vector<Cand>> pools(n_queries);
-    std::vector<uint32_t> redo;
-    for (uint32_t q = 0; q < n_queries; ++q) {
-        std::vector<Cand> &c = pools[q];
-        c.reserve(got[q]);
-        for (uint32_t i = 0; i < got[q]; ++i) {
-            const float e = cosv[static_cast<size_t>(q) * fetch + i];
-            c.push_back({rows[static_cast<size_t>(q) * fetch + i], combine(w, e, 0.0f), e, 0.0f});
-        }
-        std::sort(c.begin(), c.end(), cand_before);
-        // same boundary rule as search_impl: a rounding tie that reaches the last fetched row
-        // cannot be resolved from this fetch -> that query takes the single-query path
-        if (got[q] < N && got[q] > 0) {
-            const float c_tail = combine(w, cosv[static_cast<size_t>(q) * fetch + got[q] - 1], 0.0f);
-            if (!(c.size() >= need && (std::isnan(c_tail) || c[need - 1].c > c_tail)))
-                redo.push_back(q);
-        }
-        if (c.size() > need)
-            c.resize(need);
-    }
-    if (plain) {
-        for (uint32_t q = 0; q < n_queries; ++q)
-            emit(pools[q], out + static_cast<size_t>(q) * cap, cap, &n_out[q]);
-    } else {
-        std::vector<uint64_t> prow(static_cast<size_t>(n_queries) * P, 0);
-        std::vector<float> psc(static_cast<size_t>(n_queries) * P, 0.0f);
-        std::vector<uint32_t> psz(n_queries), order(static_cast<size_t>(n_queries) * P), nsel(n_queries);
-        for (uint32_t q = 0; q < n_queries; ++q) {
-            psz[q] = static_cast<uint32_t>(pools[q].size());
-            for (uint32_t i = 0; i < psz[q]; ++i) {
-                prow[static_cast<size_t>(q) * P + i] = pools[q][i].row;
-                psc[static_cast<size_t>(q) * P + i] = pools[q][i].c;
-            }
-        }
-        st = rlr_mmr_select_batch(idx, prow.data(), psc.data(), psz.data(), n_queries, P, top_k, diversity_factor,
-                                  order.data(), nullptr, nsel.data());
-        if (st != RLR_OK)
-            return st;
-        std::vector<Cand> picked;
-        for (uint32_t q = 0; q < n_queries; ++q) {
-            picked.clear();
-            for (uint32_t i = 0; i < nsel[q]; ++i)
-                picked.push_back(pools[q][order[static_cast<size_t>(q) * P + i]]);
-            emit(picked, out + static_cast<size_t>(q) * cap, cap, &n_out[q]);
-        }
-    }
-    for (uint32_t q : redo)
-        if ((st = single(q)) != RLR_OK)
-            return st;
+    for (uint32_t q = 0; q < n_queries; ++q)
+        emit(results[q], out + static_cast<size_t>(q) * cap, cap, &n_out[q]);
     return RLR_OK;
 }
 

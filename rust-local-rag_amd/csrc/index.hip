@@ -1652,8 +1652,10 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     return RLR_OK;
 }
 
-int32_t upload_list(rlr_index *ix, Ctx *c, const uint64_t *rows, uint32_t n)
+int32_t upload_list(rlr_index *ix, Ctx *c, const uint64_t *rows, uint32_t n, uint64_t bound = ~0ull)
 {
+    if (bound == ~0ull)
+        bound = ix->n_rows;
     if (c->list_cap < n || !c->d_list) {
         if (c->d_list) (void)hipFree(c->d_list);
         if (c->d_vals) (void)hipFree(c->d_vals);
@@ -1668,9 +1670,9 @@ int32_t upload_list(rlr_index *ix, Ctx *c, const uint64_t *rows, uint32_t n)
     RLR_TRY(pin_reserve(c, static_cast<size_t>(n) * 8 + 64));
     uint32_t *h = static_cast<uint32_t *>(c->h_pin);
     for (uint32_t i = 0; i < n; ++i) {
-        if (rows[i] >= ix->n_rows)
-            return fail(RLR_E_RANGE, "row %llu out of range (index holds %llu rows)",
-                        static_cast<unsigned long long>(rows[i]), static_cast<unsigned long long>(ix->n_rows));
+        if (rows[i] >= bound)
+            return fail(RLR_E_RANGE, "row %llu out of range (%llu rows)", static_cast<unsigned long long>(rows[i]),
+                        static_cast<unsigned long long>(bound));
         h[i] = static_cast<uint32_t>(rows[i]);
     }
     RLR_HIP(hipMemcpyAsync(c->d_list, h, static_cast<size_t>(n) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -2242,8 +2244,10 @@ static void note_mmr(rlr_index *ix, Ctx *c, uint32_t n_queries)
     ix->prof.mmr_ms += ms;
 }
 
-int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *pool_scores, uint32_t P, uint32_t k,
-                       float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out)
+// one pool of up to 4096 candidates; d_matrix != null: pool_rows are slots of that staged matrix (see mmr_batch_impl)
+static int32_t mmr_single_impl(rlr_index *ix, const uint64_t *pool_rows, const float *pool_scores, uint32_t P, uint32_t k,
+                               float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out, const void *d_matrix,
+                               uint64_t n_matrix)
 {
     RLR_TRY(check_handle(ix));
     if (!n_out)
@@ -2260,7 +2264,7 @@ int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *po
     RLR_TRY(ctx_acquire(ix, &lease.c));
     Ctx *c = lease.c;
     hipStream_t s = c->stream;
-    RLR_TRY(upload_list(ix, c, pool_rows, P));
+    RLR_TRY(upload_list(ix, c, pool_rows, P, d_matrix ? n_matrix : ~0ull));
     // pool (P x dim) followed by gram (P x P), scores (P), order (P), mmr (P), n (1)
     const uint64_t floats = static_cast<uint64_t>(P) * ix->dim + static_cast<uint64_t>(P) * P + 3ull * P + 4;
     RLR_TRY(grow(&c->d_pool, &c->pool_cap, floats));
@@ -2273,7 +2277,7 @@ int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *po
     const bool timed = ix->profiling;
     RLR_HIP(hipMemcpyAsync(d_sc, pool_scores, static_cast<size_t>(P) * sizeof(float), hipMemcpyHostToDevice, s));
     if (timed) RLR_HIP(hipEventRecord(c->ev[0], s));
-    RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
+    RLR_HIP(launch_gram_rows(d_matrix ? d_matrix : ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
     RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, nullptr, 1, s));
     if (timed) RLR_HIP(hipEventRecord(c->ev[1], s));
     // one D2H: order | mmr | n are contiguous
@@ -2292,6 +2296,12 @@ int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *po
     }
     *n_out = n_sel;
     return RLR_OK;
+}
+
+int32_t rlr_mmr_select(rlr_index *ix, const uint64_t *pool_rows, const float *pool_scores, uint32_t P, uint32_t k,
+                       float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out)
+{
+    return mmr_single_impl(ix, pool_rows, pool_scores, P, k, lambda, order_out, mmr_out, n_out, nullptr, 0);
 }
 
 int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uint32_t k, float lambda, float w_embedding,
@@ -2680,9 +2690,12 @@ int32_t rlr_search_hybrid(rlr_index *ix, const float *query, uint32_t need, uint
 // Batched MMR over P-strided pools.  The pool rows either live in the index (pool_rows != null:
 // gathered to f32 here) or are already in device memory as n_queries x P x dim f32 values
 // (d_values != null: the sharded path, after the winner-row exchange).
+// d_matrix != null: pool_rows are slots of that matrix (n_matrix raw rows in the index' own dtype and pitch, e.g. the
+// receive buffer of the cross-shard winner-row exchange) instead of rows of the index.
 static int32_t mmr_batch_impl(rlr_index *ix, const uint64_t *pool_rows, const float *d_values, const float *pool_scores,
                               const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k, float lambda,
-                              uint32_t *order_out, float *mmr_out, uint32_t *n_out)
+                              uint32_t *order_out, float *mmr_out, uint32_t *n_out, const void *d_matrix = nullptr,
+                              uint64_t n_matrix = 0)
 {
     RLR_TRY(check_handle(ix));
     if (n_queries == 0)
@@ -2725,7 +2738,7 @@ static int32_t mmr_batch_impl(rlr_index *ix, const uint64_t *pool_rows, const fl
             for (uint32_t q = 0; q < m; ++q)
                 std::memcpy(rows_chunk.data() + static_cast<size_t>(q) * P, pool_rows + static_cast<size_t>(q0 + q) * P,
                             pool_sizes[q0 + q] * sizeof(uint64_t));
-            RLR_TRY(upload_list(ix, c, rows_chunk.data(), n_list));
+            RLR_TRY(upload_list(ix, c, rows_chunk.data(), n_list, d_matrix ? n_matrix : ~0ull));
         }
         const uint64_t pool_floats = 0; // (the pool rows are read in place)
         const uint64_t floats = pool_floats + static_cast<uint64_t>(m) * P * P + 3ull * n_list + 2ull * m + 8;
@@ -2747,7 +2760,7 @@ static int32_t mmr_batch_impl(rlr_index *ix, const uint64_t *pool_rows, const fl
         const bool timed = ix->profiling;
         if (timed) RLR_HIP(hipEventRecord(c->ev[0], s));
         if (pool_rows) // the Gram kernel reads the index rows through the list: no gathered copy
-            RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, m, s));
+            RLR_HIP(launch_gram_rows(d_matrix ? d_matrix : ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, m, s));
         else
             RLR_HIP(launch_gram(d_values + static_cast<size_t>(q0) * P * ix->dim, P, ix->dim, d_gram, m, s));
         RLR_HIP(launch_mmr_greedy(d_gram, d_sc, P, k, lambda, d_order, d_mmr, d_n, d_sizes, m, s));
@@ -2788,6 +2801,45 @@ int32_t rlr_mmr_select_values(rlr_index *ix, const void *d_values, const float *
         return fail(RLR_E_INVALID, "null argument");
     return mmr_batch_impl(ix, nullptr, static_cast<const float *>(d_values), pool_scores, pool_sizes, n_queries, P, k, lambda,
                           order_out, mmr_out, n_out);
+}
+
+int32_t rlr_mmr_select_staged(rlr_index *ix, const void *d_staged, uint64_t n_staged, const uint64_t *pool_slots,
+                              const float *pool_scores, const uint32_t *pool_sizes, uint32_t n_queries, uint32_t P, uint32_t k,
+                              float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_out)
+{
+    if (n_queries && (!d_staged || !pool_slots || n_staged == 0))
+        return fail(RLR_E_INVALID, "null argument");
+    if (n_queries == 1 && pool_sizes && pool_sizes[0] > 1024) // one large pool: the single-pool kernels (up to 4096)
+        return mmr_single_impl(ix, pool_slots, pool_scores, pool_sizes[0], k, lambda, order_out, mmr_out, n_out, d_staged,
+                               n_staged);
+    return mmr_batch_impl(ix, pool_slots, nullptr, pool_scores, pool_sizes, n_queries, P, k, lambda, order_out, mmr_out, n_out,
+                          d_staged, n_staged);
+}
+
+int32_t rlr_index_row_bytes(const rlr_index *ix, uint32_t *bytes_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (!bytes_out)
+        return fail(RLR_E_INVALID, "bytes_out is null");
+    *bytes_out = static_cast<uint32_t>(row_bytes(ix));
+    return RLR_OK;
+}
+
+int32_t rlr_gather_rows_device(rlr_index *ix, const uint64_t *rows, uint32_t n, void *d_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (n == 0)
+        return RLR_OK;
+    if (!rows || !d_out)
+        return fail(RLR_E_INVALID, "null argument");
+    RLR_TRY(use_device(ix));
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    RLR_TRY(upload_list(ix, c, rows, n));
+    RLR_HIP(launch_compact_rows(ix->d_rows, d_out, ix->pitch16, c->d_list, n, c->stream));
+    RLR_HIP(hipStreamSynchronize(c->stream));
+    return RLR_OK;
 }
 
 int32_t rlr_fetch_rows_device(rlr_index *ix, const uint64_t *rows, uint32_t n, void *d_out)

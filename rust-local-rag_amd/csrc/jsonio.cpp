@@ -12,7 +12,7 @@
 //      rounded, then narrowed to binary32 -- serde_json's f32 path (visit_f64 + `as f32`) and the Python loader's
 //      float64 -> float32 do exactly that, so the rows are bit-identical to theirs), each range into its own row of
 //      the matrix: about 25 ns per number per core.
-// Row r = the r-th chunk of the file.
+// Row r = the r-th DISTINCT chunk id of the file's (last) "chunks" map, in order of first appearance.
 #include "../../include/rlr_engine.h"
 
 #include <algorithm>
@@ -24,6 +24,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include <fcntl.h>
@@ -137,42 +138,109 @@ bool key_is(const char *s, const char *e, const char *lit)
     return static_cast<size_t>(e - s) == n && memcmp(s, lit, n) == 0;
 }
 
-// [p, end) = the inside of an embedding array (between '[' and ']'): numbers (or null = a non-finite value serde_json
-// wrote) into row[0..dim), extra components dropped, missing ones left 0 (dot_product's zip, rag_engine.rs:1778).
-// Returns nullptr, or the position of the first byte that is not part of a number list.
+// The JSON number grammar, -?(0|[1-9][0-9]*)(\.[0-9]+)?([eE][+-]?[0-9]+)?, as serde_json and Python's json module
+// enforce it (std::from_chars alone also takes "inf", "nan", "01", "1.", ".5").  Returns the end of the literal or
+// nullptr; *mag10 = decimal order of magnitude of the value (position of its first significant digit plus the exponent,
+// saturated) -- what decides between +-inf and +-0 when the literal is outside binary64's range.
+const char *scan_json_number(const char *p, const char *end, long *mag10)
+{
+    const char *q = p;
+    if (q < end && *q == '-')
+        ++q;
+    if (q >= end || *q < '0' || *q > '9')
+        return nullptr;
+    long first_sig = 0; // 10^first_sig is the weight of the first non-zero digit
+    bool seen_sig = false;
+    const char *int_begin = q;
+    if (*q == '0') {
+        ++q;
+    } else {
+        while (q < end && *q >= '0' && *q <= '9')
+            ++q;
+        seen_sig = true;
+        first_sig = static_cast<long>(q - int_begin) - 1;
+    }
+    if (q < end && *q == '.') {
+        ++q;
+        const char *frac = q;
+        while (q < end && *q >= '0' && *q <= '9') {
+            if (!seen_sig && *q != '0') {
+                seen_sig = true;
+                first_sig = -static_cast<long>(q - frac) - 1;
+            }
+            ++q;
+        }
+        if (q == frac)
+            return nullptr;
+    }
+    long ex = 0;
+    if (q < end && (*q == 'e' || *q == 'E')) {
+        ++q;
+        bool neg = false;
+        if (q < end && (*q == '+' || *q == '-'))
+            neg = *q++ == '-';
+        const char *d = q;
+        while (q < end && *q >= '0' && *q <= '9') {
+            if (ex < 100000000)
+                ex = ex * 10 + (*q - '0');
+            ++q;
+        }
+        if (q == d)
+            return nullptr;
+        if (neg)
+            ex = -ex;
+    }
+    *mag10 = seen_sig ? first_sig + ex : 0;
+    return q;
+}
+
+// [p, end) = the inside of an embedding array (between '[' and ']'): `value (, value)*` or nothing, a value being a JSON
+// number or null (= a non-finite value serde_json wrote), into row[0..dim); extra components dropped, missing ones left 0
+// (dot_product's zip, rag_engine.rs:1778).  Returns nullptr, or the position of the first byte that breaks that grammar
+// (a nested array, a string, "inf", a doubled or trailing comma, ...: serde_json refuses such a file, :1555-1557).
 const char *parse_embedding(const char *p, const char *end, float *row, uint32_t dim)
 {
-    uint32_t i = 0;
-    for (;;) {
-        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r' || *p == ','))
+    auto ws = [&] {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r'))
             ++p;
-        if (p >= end)
-            return nullptr;
+    };
+    uint32_t i = 0;
+    ws();
+    if (p >= end)
+        return nullptr; // []
+    for (;;) {
         double v;
         if (end - p >= 4 && memcmp(p, "null", 4) == 0) {
             v = std::nan("");
             p += 4;
         } else {
-            const auto r = std::from_chars(p, end, v);
+            long mag10 = 0;
+            const char *lit_end = scan_json_number(p, end, &mag10);
+            if (!lit_end)
+                return p;
+            const auto r = std::from_chars(p, lit_end, v);
             if (r.ec == std::errc::result_out_of_range) {
-                // from_chars leaves v unmodified on overflow / underflow: serde_json's f64 gives +-inf or 0 there
-                const bool neg = *p == '-';
-                v = 0.0;
-                for (const char *t = p; t < r.ptr; ++t)
-                    if (*t == 'e' || *t == 'E') {
-                        v = (t + 1 < r.ptr && t[1] == '-') ? 0.0 : HUGE_VAL;
-                        break;
-                    }
-                if (neg)
+                // from_chars leaves v unmodified on overflow / underflow: serde_json's f64 gives +-inf or +-0 there
+                v = mag10 > 0 ? HUGE_VAL : 0.0;
+                if (*p == '-')
                     v = -v;
-            } else if (r.ec != std::errc()) {
+            } else if (r.ec != std::errc() || r.ptr != lit_end) {
                 return p;
             }
-            p = r.ptr;
+            p = lit_end;
         }
         if (i < dim)
             row[i] = static_cast<float>(v);
         ++i;
+        ws();
+        if (p >= end)
+            return nullptr;
+        if (*p != ',')
+            return p;
+        ++p;
+        ws();
+        if (p >= end)
+            return p - 1; // trailing comma
     }
 }
 
@@ -187,9 +255,95 @@ struct Corpus {
     std::string meta;
 };
 
+constexpr uint64_t kDeadRange = ~0ull; // a range whose chunk was replaced by a later occurrence of the same id
+
+// JSON string contents [s, e) decoded (escapes, \uXXXX incl. surrogate pairs -> UTF-8): two spellings of one key must
+// compare equal, as they do in serde_json's HashMap and in Python's dict.  Invalid escapes are kept as written.
+std::string decode_string(const char *s, const char *e)
+{
+    std::string out;
+    out.reserve(static_cast<size_t>(e - s));
+    auto hex4 = [&](const char *q, unsigned *v) {
+        if (e - q < 4)
+            return false;
+        unsigned x = 0;
+        for (int i = 0; i < 4; ++i) {
+            const char ch = q[i];
+            unsigned d;
+            if (ch >= '0' && ch <= '9') d = static_cast<unsigned>(ch - '0');
+            else if (ch >= 'a' && ch <= 'f') d = static_cast<unsigned>(ch - 'a' + 10);
+            else if (ch >= 'A' && ch <= 'F') d = static_cast<unsigned>(ch - 'A' + 10);
+            else return false;
+            x = x * 16 + d;
+        }
+        *v = x;
+        return true;
+    };
+    auto utf8 = [&](unsigned cp) {
+        if (cp < 0x80) out += static_cast<char>(cp);
+        else if (cp < 0x800) {
+            out += static_cast<char>(0xC0 | (cp >> 6));
+            out += static_cast<char>(0x80 | (cp & 0x3F));
+        } else if (cp < 0x10000) {
+            out += static_cast<char>(0xE0 | (cp >> 12));
+            out += static_cast<char>(0x80 | ((cp >> 6) & 0x3F));
+            out += static_cast<char>(0x80 | (cp & 0x3F));
+        } else {
+            out += static_cast<char>(0xF0 | (cp >> 18));
+            out += static_cast<char>(0x80 | ((cp >> 12) & 0x3F));
+            out += static_cast<char>(0x80 | ((cp >> 6) & 0x3F));
+            out += static_cast<char>(0x80 | (cp & 0x3F));
+        }
+    };
+    for (const char *q = s; q < e; ++q) {
+        if (*q != '\\' || q + 1 >= e) {
+            out += *q;
+            continue;
+        }
+        ++q;
+        switch (*q) {
+        case 'b': out += '\b'; break;
+        case 'f': out += '\f'; break;
+        case 'n': out += '\n'; break;
+        case 'r': out += '\r'; break;
+        case 't': out += '\t'; break;
+        case 'u': {
+            unsigned hi = 0, lo = 0;
+            if (!hex4(q + 1, &hi)) {
+                out += "\\u";
+                break;
+            }
+            q += 4;
+            if (hi >= 0xD800 && hi < 0xDC00 && e - q >= 7 && q[1] == '\\' && q[2] == 'u' && hex4(q + 3, &lo) && lo >= 0xDC00 &&
+                lo < 0xE000) {
+                q += 6;
+                utf8(0x10000 + ((hi - 0xD800) << 10) + (lo - 0xDC00));
+            } else {
+                utf8(hi);
+            }
+            break;
+        }
+        default: out += *q; break; // \" \\ \/
+        }
+    }
+    return out;
+}
+
+bool key_equals(const char *s, const char *e, const char *lit)
+{
+    if (memchr(s, '\\', static_cast<size_t>(e - s)) == nullptr)
+        return key_is(s, e, lit);
+    return decode_string(s, e) == lit;
+}
+
 bool parse_document(Cursor &c, Corpus &out)
 {
     const char *last = c.begin; // everything in [last, p) still has to be copied to the metadata document
+    // chunk id -> row and row -> its embedding range: the document is a MAP (serde_json HashMap / Python dict: a repeated
+    // key keeps its first position and takes the last value), so a repeated id reuses its row and replaces the whole
+    // chunk, and a repeated "chunks" member starts over
+    std::unordered_map<std::string, uint64_t> row_of;
+    std::vector<int64_t> range_of_row;
     c.ws();
     if (c.p >= c.end || *c.p != '{')
         return c.fail("the document is not a JSON object");
@@ -212,7 +366,14 @@ bool parse_document(Cursor &c, Corpus &out)
             return c.fail("expected ':'");
         ++c.p;
         c.ws();
-        if (!key_is(ks, ke, "chunks") || c.p >= c.end || *c.p != '{') {
+        const bool is_chunks = key_equals(ks, ke, "chunks");
+        if (is_chunks) { // (again): the last "chunks" member is the one a map keeps
+            out.n = 0;
+            out.ranges.clear();
+            row_of.clear();
+            range_of_row.clear();
+        }
+        if (!is_chunks || c.p >= c.end || *c.p != '{') {
             if (!skip_value(c))
                 return false;
             continue;
@@ -235,9 +396,16 @@ bool parse_document(Cursor &c, Corpus &out)
                 return c.fail("expected ':'");
             ++c.p;
             c.ws();
-            // one row per chunk, whatever the chunk holds
-            const uint64_t row = out.n++;
-            size_t first_range = out.ranges.size();
+            // one row per chunk ID, whatever the chunk holds
+            auto ins = row_of.emplace(decode_string(ks, ke), out.n);
+            const uint64_t row = ins.first->second;
+            if (ins.second) {
+                out.n++;
+                range_of_row.push_back(-1);
+            } else if (range_of_row[row] >= 0) { // the earlier occurrence's embedding goes with the earlier value
+                out.ranges[static_cast<size_t>(range_of_row[row])].row = kDeadRange;
+                range_of_row[row] = -1;
+            }
             if (c.p >= c.end || *c.p != '{') {
                 if (!skip_value(c))
                     return false;
@@ -261,13 +429,18 @@ bool parse_document(Cursor &c, Corpus &out)
                     return c.fail("expected ':'");
                 ++c.p;
                 c.ws();
-                if (key_is(ks, ke, "embedding") && c.p < c.end && *c.p == '[') {
+                const bool is_emb = key_equals(ks, ke, "embedding");
+                if (is_emb && range_of_row[row] >= 0) { // a repeated key: the last one wins, as in a map
+                    out.ranges[static_cast<size_t>(range_of_row[row])].row = kDeadRange;
+                    range_of_row[row] = -1;
+                }
+                if (is_emb && c.p < c.end && *c.p == '[') {
                     const char *a0 = c.p;
                     // numbers, commas, white space and null only: the array ends at the next ']'
                     const char *close = static_cast<const char *>(memchr(c.p + 1, ']', static_cast<size_t>(c.end - c.p - 1)));
                     if (!close)
                         return c.fail("unterminated embedding array");
-                    out.ranges.resize(first_range); // a repeated key: the last one wins, as in a map
+                    range_of_row[row] = static_cast<int64_t>(out.ranges.size());
                     out.ranges.push_back({c.p + 1, close, row});
                     c.p = close + 1;
                     out.meta.append(last, a0);
@@ -280,6 +453,8 @@ bool parse_document(Cursor &c, Corpus &out)
         }
     }
     out.meta.append(last, c.end);
+    out.ranges.erase(std::remove_if(out.ranges.begin(), out.ranges.end(), [](const Range &r) { return r.row == kDeadRange; }),
+                     out.ranges.end());
     return true;
 }
 

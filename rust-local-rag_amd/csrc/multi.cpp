@@ -7,8 +7,17 @@
 //     group call, merge_topk_kernel on the first device (rlr_merge_topk) -- the path BASELINE.json's north_star
 //     names, reachable from the C ABI without torch or one-process-per-GPU.  librccl is loaded with dlopen on
 //     first use, so the library has no link-time dependency on it.
+// Cross-shard MMR (SURVEY.md 8(e) "MMR on sharded data"): the pool rows of a query live on several GPUs; every shard
+// gathers the rows it owns on its own device (rlr_gather_rows_device: raw rows, binary16 stays binary16), copies them
+// device to device (hipMemcpyPeerAsync: xGMI, no host bounce) to the GPU that owns the query -- queries are dealt
+// round-robin over the shards -- and that GPU runs the Gram + greedy kernels over its receive buffer
+// (rlr_mmr_select_staged).  The engine-level entry points (rlr_multi_engine_*: RagEngine::search /
+// search_with_diversity over the sharded corpus) are csrc/engine_host.h instantiated on these primitives.
 // Built on the single-index C ABI plus HIP runtime calls for the exchange buffers; no device code here.
 #include "../../include/rlr_gpu.h"
+#include "../../include/rlr_engine.h"
+#include "../../include/rlr_lexical.h"
+#include "engine_host.h"
 
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -16,6 +25,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
@@ -128,7 +139,6 @@ struct rlr_multi {
     std::vector<rlr_index *> shard;
     std::vector<int32_t> device;
     std::vector<uint64_t> base; // first global row of each shard (+ total at the end)
-    rlr_index *scratch = nullptr; // f32 pool index on the first device for MMR
     uint64_t n_rows = 0;
     std::vector<Worker *> worker; // shards 1..G-1 (shard 0 runs on the calling thread)
     // RCCL exchange (rlr_multi_set_exchange)
@@ -138,7 +148,24 @@ struct rlr_multi {
     std::vector<hipStream_t> xstream;
     std::vector<void *> d_local, d_gath;
     size_t x_cap = 0; // entries (u64) d_local holds per shard
+    // cross-shard MMR: a few exchange workspaces (stage + receive buffer and a copy stream per shard), leased per call
+    std::mutex wmu;
+    std::condition_variable wcv;
+    std::vector<struct XferWs *> w_free;
+    int w_made = 0;
+    uint32_t row_bytes = 0;
+    // which path the calls took (rlr_multi_stats)
+    std::atomic<uint64_t> n_topk_rccl{0}, n_topk_host{0}, n_topk_fellback{0}, n_mmr_exchanges{0}, mmr_exchange_bytes{0};
+    std::atomic<uint64_t> topk_exchange_ns{0}, mmr_exchange_ns{0};
 };
+
+struct XferWs {
+    std::vector<void *> d_stage, d_recv; // per shard, on its device
+    std::vector<size_t> stage_cap, recv_cap;
+    std::vector<hipStream_t> stream;
+};
+
+constexpr int kMaxXferWs = 4; // concurrent cross-shard MMR calls beyond this wait
 
 namespace {
 
@@ -241,6 +268,7 @@ int32_t search_rccl(rlr_multi *m, const float *queries, uint32_t nq, uint32_t k,
     std::lock_guard<std::mutex> xl(m->xmu);
     const size_t per = static_cast<size_t>(nq) * k;
     if (m->x_cap < per) {
+        m->x_cap = 0; // nothing usable until every buffer of the new size exists
         for (size_t g = 0; g < G; ++g) {
             RLR_X_HIP(hipSetDevice(m->device[g]));
             if (m->d_local[g]) (void)hipFree(m->d_local[g]);
@@ -283,6 +311,261 @@ int32_t search_rccl(rlr_multi *m, const float *queries, uint32_t nq, uint32_t k,
     return RLR_OK;
 }
 
+
+void xfer_destroy(rlr_multi *m, XferWs *w)
+{
+    if (!w)
+        return;
+    for (size_t g = 0; g < w->stream.size(); ++g) {
+        (void)hipSetDevice(m->device[g]);
+        if (w->stream[g]) {
+            (void)hipStreamSynchronize(w->stream[g]);
+            (void)hipStreamDestroy(w->stream[g]);
+        }
+        if (w->d_stage[g]) (void)hipFree(w->d_stage[g]);
+        if (w->d_recv[g]) (void)hipFree(w->d_recv[g]);
+    }
+    delete w;
+}
+
+int32_t xfer_acquire(rlr_multi *m, XferWs **out)
+{
+    std::unique_lock<std::mutex> lk(m->wmu);
+    for (;;) {
+        if (!m->w_free.empty()) {
+            *out = m->w_free.back();
+            m->w_free.pop_back();
+            return RLR_OK;
+        }
+        if (m->w_made < kMaxXferWs) {
+            m->w_made++;
+            break;
+        }
+        m->wcv.wait(lk);
+    }
+    lk.unlock();
+    const size_t G = m->shard.size();
+    XferWs *w = new XferWs();
+    w->d_stage.assign(G, nullptr);
+    w->d_recv.assign(G, nullptr);
+    w->stage_cap.assign(G, 0);
+    w->recv_cap.assign(G, 0);
+    w->stream.assign(G, nullptr);
+    for (size_t g = 0; g < G; ++g) {
+        hipError_t e = hipSetDevice(m->device[g]);
+        if (e == hipSuccess)
+            e = hipStreamCreateWithFlags(&w->stream[g], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            xfer_destroy(m, w);
+            {
+                std::lock_guard<std::mutex> lk2(m->wmu);
+                m->w_made--;
+            }
+            m->wcv.notify_one();
+            return rlr::set_error(RLR_E_HIP, "exchange stream on device %d: %s", m->device[g], hipGetErrorString(e));
+        }
+    }
+    *out = w;
+    return RLR_OK;
+}
+
+void xfer_release(rlr_multi *m, XferWs *w)
+{
+    {
+        std::lock_guard<std::mutex> lk(m->wmu);
+        m->w_free.push_back(w);
+    }
+    m->wcv.notify_one();
+}
+
+struct XferLease {
+    rlr_multi *m;
+    XferWs *w = nullptr;
+    ~XferLease()
+    {
+        if (w)
+            xfer_release(m, w);
+    }
+};
+
+int32_t dev_reserve(int32_t device, void **p, size_t *cap, size_t bytes)
+{
+    if (*cap >= bytes && *p)
+        return RLR_OK;
+    RLR_X_HIP(hipSetDevice(device));
+    if (*p)
+        (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 20);
+    RLR_X_HIP(rlr::dev_malloc(p, want));
+    *cap = want;
+    return RLR_OK;
+}
+
+// mmr_diversify over nq pools (strided by P) whose rows are GLOBAL rows of the sharded corpus.  Query q is diversified
+// on shard q mod G; each shard gathers the pool rows it owns, device-to-device copies put them into the owners' receive
+// buffers (grouped by source shard), and every owner runs the batched Gram + greedy kernels over its buffer through a
+// slot list that restores the pool order.  Same results as rlr_mmr_select_batch over one index holding all rows.
+int32_t multi_mmr(rlr_multi *m, const uint64_t *pool_rows, const float *pool_scores, const uint32_t *pool_sizes, uint32_t nq,
+                  uint32_t P, uint32_t k, float lambda, uint32_t *order_out, float *mmr_out, uint32_t *n_sel)
+{
+    const size_t G = m->shard.size();
+    for (uint32_t q = 0; q < nq; ++q)
+        n_sel[q] = 0;
+    if (nq == 0 || P == 0)
+        return RLR_OK;
+    if (G == 1) {
+        if (nq == 1)
+            return rlr_mmr_select(m->shard[0], pool_rows, pool_scores, pool_sizes[0], k, lambda, order_out, mmr_out, n_sel);
+        return rlr_mmr_select_batch(m->shard[0], pool_rows, pool_scores, pool_sizes, nq, P, k, lambda, order_out, mmr_out, n_sel);
+    }
+    if (nq > 1 && P > 1024)
+        return rlr::set_error(RLR_E_INVALID, "batched MMR supports pools of at most 1024 candidates (got %u)", P);
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t rb = m->row_bytes;
+    // plan: entries of shard g ordered by (owner, query, position); owner o receives the blocks in source-shard order
+    std::vector<std::vector<uint64_t>> send_rows(G);              // local rows, in send order
+    std::vector<std::vector<size_t>> send_count(G, std::vector<size_t>(G, 0)); // [g][o]
+    for (uint32_t q = 0; q < nq; ++q) {
+        if (pool_sizes[q] > P)
+            return rlr::set_error(RLR_E_INVALID, "pool_sizes[%u] = %u exceeds P = %u", q, pool_sizes[q], P);
+        for (uint32_t j = 0; j < pool_sizes[q]; ++j) {
+            const uint64_t row = pool_rows[static_cast<size_t>(q) * P + j];
+            if (row >= m->n_rows)
+                return rlr::set_error(RLR_E_RANGE, "row %llu out of range", static_cast<unsigned long long>(row));
+            uint32_t g;
+            uint64_t l;
+            shard_of(m, row, &g, &l);
+            send_count[g][q % G]++;
+        }
+    }
+    std::vector<std::vector<size_t>> send_off(G, std::vector<size_t>(G + 1, 0)), recv_off(G, std::vector<size_t>(G + 1, 0));
+    for (size_t g = 0; g < G; ++g)
+        for (size_t o = 0; o < G; ++o)
+            send_off[g][o + 1] = send_off[g][o] + send_count[g][o];
+    for (size_t o = 0; o < G; ++o)
+        for (size_t g = 0; g < G; ++g)
+            recv_off[o][g + 1] = recv_off[o][g] + send_count[g][o];
+    for (size_t g = 0; g < G; ++g)
+        send_rows[g].assign(send_off[g][G], 0);
+    // owners' compact query lists and slot tables
+    std::vector<std::vector<uint32_t>> owned(G);
+    for (uint32_t q = 0; q < nq; ++q)
+        owned[q % G].push_back(q);
+    std::vector<std::vector<uint64_t>> slots(G);
+    std::vector<std::vector<float>> scores(G);
+    std::vector<std::vector<uint32_t>> sizes(G);
+    for (size_t o = 0; o < G; ++o) {
+        slots[o].assign(owned[o].size() * static_cast<size_t>(P), 0);
+        scores[o].assign(owned[o].size() * static_cast<size_t>(P), 0.0f);
+        sizes[o].resize(owned[o].size());
+    }
+    std::vector<std::vector<size_t>> fill(G, std::vector<size_t>(G, 0)); // [g][o]: entries placed so far
+    for (size_t o = 0; o < G; ++o)
+        for (size_t i = 0; i < owned[o].size(); ++i) {
+            const uint32_t q = owned[o][i];
+            sizes[o][i] = pool_sizes[q];
+            for (uint32_t j = 0; j < pool_sizes[q]; ++j) {
+                uint32_t g;
+                uint64_t l;
+                shard_of(m, pool_rows[static_cast<size_t>(q) * P + j], &g, &l);
+                const size_t at = fill[g][o]++;
+                send_rows[g][send_off[g][o] + at] = l;
+                slots[o][i * P + j] = recv_off[o][g] + at;
+                scores[o][i * P + j] = pool_scores[static_cast<size_t>(q) * P + j];
+            }
+        }
+    XferLease lease{m};
+    int32_t st = xfer_acquire(m, &lease.w);
+    if (st != RLR_OK)
+        return st;
+    XferWs *w = lease.w;
+    uint64_t moved = 0;
+    for (size_t g = 0; g < G; ++g) { // buffers first: a copy must never target memory that is still being (re)allocated
+        if ((st = dev_reserve(m->device[g], &w->d_stage[g], &w->stage_cap[g], send_off[g][G] * rb)) != RLR_OK)
+            return st;
+        if ((st = dev_reserve(m->device[g], &w->d_recv[g], &w->recv_cap[g], recv_off[g][G] * rb)) != RLR_OK)
+            return st;
+        moved += send_off[g][G] * rb;
+    }
+    // 1. gather on the owning device, then one device-to-device copy per (source, owner) pair
+    st = for_each_shard(m, [&](uint32_t g) -> int32_t {
+        const size_t n_g = send_off[g][G];
+        if (n_g == 0)
+            return RLR_OK;
+        int32_t s1 = rlr_gather_rows_device(m->shard[g], send_rows[g].data(), static_cast<uint32_t>(n_g), w->d_stage[g]);
+        if (s1 != RLR_OK)
+            return s1;
+        RLR_X_HIP(hipSetDevice(m->device[g]));
+        for (size_t o = 0; o < G; ++o) {
+            const size_t cnt = send_count[g][o];
+            if (cnt == 0)
+                continue;
+            char *dst = static_cast<char *>(w->d_recv[o]) + recv_off[o][g] * rb;
+            const char *src = static_cast<const char *>(w->d_stage[g]) + send_off[g][o] * rb;
+            if (m->device[o] == m->device[g])
+                RLR_X_HIP(hipMemcpyAsync(dst, src, cnt * rb, hipMemcpyDeviceToDevice, w->stream[g]));
+            else
+                RLR_X_HIP(hipMemcpyPeerAsync(dst, m->device[o], src, m->device[g], cnt * rb, w->stream[g]));
+        }
+        RLR_X_HIP(hipStreamSynchronize(w->stream[g]));
+        return RLR_OK;
+    });
+    if (st != RLR_OK)
+        return st;
+    m->n_mmr_exchanges++;
+    m->mmr_exchange_bytes += moved;
+    m->mmr_exchange_ns += static_cast<uint64_t>(
+        std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+    // 2. every owner: Gram + greedy over its receive buffer
+    std::vector<std::vector<uint32_t>> ord(G), nsel(G);
+    std::vector<std::vector<float>> mmrv(G);
+    st = for_each_shard(m, [&](uint32_t o) -> int32_t {
+        const uint32_t nqo = static_cast<uint32_t>(owned[o].size());
+        if (nqo == 0)
+            return RLR_OK;
+        ord[o].assign(static_cast<size_t>(nqo) * P, 0);
+        mmrv[o].assign(static_cast<size_t>(nqo) * P, 0.0f);
+        nsel[o].assign(nqo, 0);
+        if (recv_off[o][G] == 0)
+            return RLR_OK; // (only empty pools)
+        return rlr_mmr_select_staged(m->shard[o], w->d_recv[o], recv_off[o][G], slots[o].data(), scores[o].data(), sizes[o].data(),
+                                     nqo, P, k, lambda, ord[o].data(), mmrv[o].data(), nsel[o].data());
+    });
+    if (st != RLR_OK)
+        return st;
+    for (size_t o = 0; o < G; ++o)
+        for (size_t i = 0; i < owned[o].size(); ++i) {
+            const uint32_t q = owned[o][i];
+            n_sel[q] = nsel[o][i];
+            std::memcpy(order_out + static_cast<size_t>(q) * P, ord[o].data() + i * P, nsel[o][i] * sizeof(uint32_t));
+            if (mmr_out)
+                std::memcpy(mmr_out + static_cast<size_t>(q) * P, mmrv[o].data() + i * P, nsel[o][i] * sizeof(float));
+        }
+    return RLR_OK;
+}
+
+// the sharded corpus as a backend of engine_host.h
+struct MultiBackend {
+    rlr_multi *m;
+    uint64_t n_rows;
+    uint32_t dim;
+    int32_t topk(const float *queries, uint32_t nq, uint32_t k, uint64_t *rows, float *cos, uint32_t *n) const
+    {
+        return rlr_multi_search_topk(m, queries, nq, k, -1.0f, rows, cos, n);
+    }
+    int32_t score_rows(const float *query, const uint64_t *rows, uint32_t n, float *cos) const
+    {
+        return rlr_multi_score_rows(m, query, rows, n, cos);
+    }
+    int32_t mmr(const uint64_t *pool_rows, const float *pool_scores, const uint32_t *pool_sizes, uint32_t nq, uint32_t P,
+                uint32_t k, float lambda, uint32_t *order, uint32_t *n_sel) const
+    {
+        return multi_mmr(m, pool_rows, pool_scores, pool_sizes, nq, P, k, lambda, order, nullptr, n_sel);
+    }
+};
+
 // (score desc, NaN last, global row asc)
 bool hit_before(float sa, uint64_t ra, float sb, uint64_t rb)
 {
@@ -324,11 +607,21 @@ int32_t rlr_multi_create(uint32_t dim, int32_t dtype, int32_t n_devices, const i
         w->start();
         m->worker.push_back(w);
     }
-    const int32_t st = rlr_index_create(dim, RLR_F32, device_ids[0], &m->scratch);
+    const int32_t st = rlr_index_row_bytes(m->shard[0], &m->row_bytes);
     if (st != RLR_OK) {
         rlr_multi_destroy(m);
         return st;
     }
+    // the winner-row exchange copies device to device: map the peers where the platform allows it (a refusal only
+    // means the runtime stages the copy itself)
+    for (int32_t a = 0; a < n_devices; ++a)
+        for (int32_t b = 0; b < n_devices; ++b) {
+            int can = 0;
+            if (device_ids[a] == device_ids[b] || hipDeviceCanAccessPeer(&can, device_ids[a], device_ids[b]) != hipSuccess || !can)
+                continue;
+            if (hipSetDevice(device_ids[a]) == hipSuccess && hipDeviceEnablePeerAccess(device_ids[b], 0) != hipSuccess)
+                (void)hipGetLastError(); // (already enabled counts as an error)
+        }
     set_bases(m, 0);
     *out = m;
     return RLR_OK;
@@ -343,9 +636,10 @@ int32_t rlr_multi_destroy(rlr_multi *m)
         delete w;
     }
     exchange_teardown(m);
+    for (XferWs *w : m->w_free)
+        xfer_destroy(m, w);
     for (rlr_index *ix : m->shard)
         rlr_index_destroy(ix);
-    rlr_index_destroy(m->scratch);
     delete m;
     return RLR_OK;
 }
@@ -364,8 +658,10 @@ int32_t rlr_multi_set_exchange(rlr_multi *m, int32_t mode)
         for (size_t b = a + 1; b < G; ++b)
             if (m->device[a] == m->device[b])
                 return rlr::set_error(RLR_E_INVALID, "RCCL exchange needs one shard per device (device %d holds two)", m->device[a]);
-    if (!rccl().ok)
-        return rlr::set_error(RLR_E_NO_DEVICE, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    if (!rccl().ok) {
+        const char *why = dlerror(); // (reading it clears it)
+        return rlr::set_error(RLR_E_NO_DEVICE, "librccl.so could not be loaded: %s", why ? why : "symbols missing");
+    }
     std::lock_guard<std::mutex> xl(m->xmu);
     if (m->comm.empty()) {
         m->comm.assign(G, nullptr);
@@ -378,8 +674,13 @@ int32_t rlr_multi_set_exchange(rlr_multi *m, int32_t mode)
         m->d_local.assign(G, nullptr);
         m->d_gath.assign(G, nullptr);
         for (size_t g = 0; g < G; ++g) {
-            RLR_X_HIP(hipSetDevice(m->device[g]));
-            RLR_X_HIP(hipStreamCreateWithFlags(&m->xstream[g], hipStreamNonBlocking));
+            hipError_t e = hipSetDevice(m->device[g]);
+            if (e == hipSuccess)
+                e = hipStreamCreateWithFlags(&m->xstream[g], hipStreamNonBlocking);
+            if (e != hipSuccess) { // no half-built exchange: a retry starts from scratch
+                exchange_teardown(m);
+                return rlr::set_error(RLR_E_HIP, "exchange stream on device %d: %s", m->device[g], hipGetErrorString(e));
+            }
         }
     }
     m->exchange = 1;
@@ -425,12 +726,19 @@ int32_t rlr_multi_search_topk(rlr_multi *m, const float *queries, uint32_t n_que
     const size_t G = m->shard.size();
     if (m->exchange == 1) {
         bool handled = false;
+        const auto t0 = std::chrono::steady_clock::now();
         const int32_t xs = search_rccl(m, queries, n_queries, k, guard_eps, rows_out, cos_out, n_out, &handled);
         if (xs != RLR_OK)
             return xs;
-        if (handled)
+        if (handled) {
+            m->n_topk_rccl++;
+            m->topk_exchange_ns += static_cast<uint64_t>(
+                std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
             return RLR_OK;
+        }
+        m->n_topk_fellback++; // outside the merge kernel's shape, or a shard's guard band overflowed: host merge below
     }
+    m->n_topk_host++;
     std::vector<std::vector<uint64_t>> r(G);
     std::vector<std::vector<float>> c(G);
     std::vector<std::vector<uint32_t>> cnt(G);
@@ -544,20 +852,161 @@ int32_t rlr_multi_mmr_select(rlr_multi *m, const uint64_t *pool_rows, const floa
         return RLR_OK;
     if (!pool_rows || !pool_scores || !order_out)
         return RLR_E_INVALID;
-    if (m->shard.size() == 1)
-        return rlr_mmr_select(m->shard[0], pool_rows, pool_scores, P, k, lambda, order_out, mmr_out, n_out);
-    // winner-row exchange: P x dim f32 to the device that runs this query's MMR
-    std::vector<float> pool(static_cast<size_t>(P) * m->dim);
-    int32_t st = rlr_multi_fetch_rows(m, pool_rows, P, pool.data());
+    // winner-row exchange: the pool rows go device to device to the shard that runs this query's MMR
+    return multi_mmr(m, pool_rows, pool_scores, &P, 1, P, k, lambda, order_out, mmr_out, n_out);
+}
+
+int32_t rlr_multi_mmr_select_batch(rlr_multi *m, const uint64_t *pool_rows, const float *pool_scores, const uint32_t *pool_sizes,
+                                   uint32_t n_queries, uint32_t P, uint32_t k, float lambda, uint32_t *order_out, float *mmr_out,
+                                   uint32_t *n_out)
+{
+    if (!m || (n_queries && (!pool_rows || !pool_scores || !pool_sizes || !order_out || !n_out)))
+        return RLR_E_INVALID;
+    return multi_mmr(m, pool_rows, pool_scores, pool_sizes, n_queries, P, k, lambda, order_out, mmr_out, n_out);
+}
+
+int32_t rlr_multi_stats(rlr_multi *m, rlr_multi_stats_t *out, int32_t reset)
+{
+    if (!m || !out)
+        return RLR_E_INVALID;
+    out->n_topk_rccl = m->n_topk_rccl.load();
+    out->n_topk_host_merge = m->n_topk_host.load();
+    out->n_topk_rccl_fell_back = m->n_topk_fellback.load();
+    out->topk_rccl_ms = static_cast<double>(m->topk_exchange_ns.load()) * 1e-6;
+    out->n_mmr_exchanges = m->n_mmr_exchanges.load();
+    out->mmr_exchange_bytes = m->mmr_exchange_bytes.load();
+    out->mmr_exchange_ms = static_cast<double>(m->mmr_exchange_ns.load()) * 1e-6;
+    if (reset) {
+        m->n_topk_rccl = 0;
+        m->n_topk_host = 0;
+        m->n_topk_fellback = 0;
+        m->topk_exchange_ns = 0;
+        m->n_mmr_exchanges = 0;
+        m->mmr_exchange_bytes = 0;
+        m->mmr_exchange_ns = 0;
+    }
+    return RLR_OK;
+}
+
+// ---- RagEngine::search / search_with_diversity over the sharded corpus (include/rlr_engine.h) --------------------------
+
+static int32_t multi_backend(rlr_multi *m, MultiBackend *be)
+{
+    be->m = m;
+    be->n_rows = m->n_rows;
+    be->dim = m->dim;
+    return RLR_OK;
+}
+
+int32_t rlr_multi_engine_search(rlr_multi *m, const float *query_raw, uint32_t dq, uint32_t top_k,
+                                const rlr_query_weights *weights, const uint64_t *lex_rows, const float *lex_scores,
+                                uint32_t n_lex, int32_t stage, rlr_search_hit *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!m || !n_out || (!query_raw && dq) || (n_lex && (!lex_rows || !lex_scores)))
+        return RLR_E_INVALID;
+    *n_out = 0;
+    rlr_resolved_weights w;
+    rlr_resolve_weights(weights, &w);
+    MultiBackend be;
+    multi_backend(m, &be);
+    std::vector<rlr_host::Cand> res;
+    const int32_t st = rlr_host::generic_search(be, query_raw, dq, top_k, w, lex_rows, lex_scores, n_lex, stage, res);
     if (st != RLR_OK)
         return st;
-    st = rlr_index_upload(m->scratch, pool.data(), P, 0);
+    if (!res.empty() && !out)
+        return RLR_E_INVALID;
+    rlr_host::emit(res, out, cap, n_out);
+    return RLR_OK;
+}
+
+int32_t rlr_multi_engine_search_with_diversity(rlr_multi *m, const float *query_raw, uint32_t dq, uint32_t top_k,
+                                               float diversity_factor, const rlr_query_weights *weights,
+                                               const uint64_t *lex_rows, const float *lex_scores, uint32_t n_lex,
+                                               rlr_search_hit *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!m || !n_out || (!query_raw && dq) || (n_lex && (!lex_rows || !lex_scores)))
+        return RLR_E_INVALID;
+    *n_out = 0;
+    if (diversity_factor < 0.0f) diversity_factor = 0.0f; // f32::clamp(0.0, 1.0) (:725); NaN takes the MMR branch
+    if (diversity_factor > 1.0f) diversity_factor = 1.0f;
+    rlr_resolved_weights w;
+    rlr_resolve_weights(weights, &w);
+    MultiBackend be;
+    multi_backend(m, &be);
+    std::vector<rlr_host::Cand> res;
+    const int32_t st = rlr_host::generic_search_with_diversity(be, query_raw, dq, top_k, diversity_factor, w, lex_rows, lex_scores,
+                                                               n_lex, res);
     if (st != RLR_OK)
         return st;
-    std::vector<uint64_t> ids(P);
-    for (uint32_t i = 0; i < P; ++i)
-        ids[i] = i;
-    return rlr_mmr_select(m->scratch, ids.data(), pool_scores, P, k, lambda, order_out, mmr_out, n_out);
+    if (!res.empty() && !out)
+        return RLR_E_INVALID;
+    rlr_host::emit(res, out, cap, n_out);
+    return RLR_OK;
+}
+
+int32_t rlr_multi_engine_search_text(rlr_multi *m, rlr_lexical *lex, const float *query_raw, uint32_t dq,
+                                     const char *query_tokens, size_t tokens_len, uint32_t top_k, float diversity_factor,
+                                     int32_t stage, const rlr_query_weights *weights, rlr_search_hit *out, uint32_t cap,
+                                     uint32_t *n_out)
+{
+    if (!m || !lex || !n_out || (!query_raw && dq) || (tokens_len && !query_tokens))
+        return RLR_E_INVALID;
+    *n_out = 0;
+    if (diversity_factor < 0.0f) diversity_factor = 0.0f;
+    if (diversity_factor > 1.0f) diversity_factor = 1.0f;
+    const bool diversify = !(diversity_factor == 0.0f);
+    // the top_k `search` works with (:490, :735) and its lexical limit `top_k.saturating_mul(5)` (:505)
+    const uint32_t k_seen = std::max<uint32_t>(diversify ? rlr_host::pool_size_of(top_k) : top_k, 1u);
+    const uint32_t limit = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(k_seen) * 5, 0xFFFFFFFFull));
+    const uint32_t lcap = limit == 0 ? RLR_LEXICAL_MAX_LIMIT : std::min<uint32_t>(limit, RLR_LEXICAL_MAX_LIMIT);
+    std::vector<uint64_t> lrows(lcap);
+    std::vector<float> lscores(lcap);
+    uint32_t n_lex = 0;
+    const int32_t st = rlr_lexical_score(lex, query_tokens, tokens_len, limit, lrows.data(), lscores.data(), &n_lex);
+    if (st != RLR_OK)
+        return st;
+    return diversify ? rlr_multi_engine_search_with_diversity(m, query_raw, dq, top_k, diversity_factor, weights, lrows.data(),
+                                                               lscores.data(), n_lex, out, cap, n_out)
+                     : rlr_multi_engine_search(m, query_raw, dq, top_k, weights, lrows.data(), lscores.data(), n_lex, stage, out,
+                                               cap, n_out);
+}
+
+int32_t rlr_multi_engine_search_with_diversity_batch(rlr_multi *m, const float *queries_raw, uint32_t dq, uint32_t n_queries,
+                                                     uint32_t top_k, float diversity_factor, const rlr_query_weights *weights,
+                                                     rlr_search_hit *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!m || !n_out || (n_queries && !queries_raw && dq) || (n_queries && cap && !out))
+        return RLR_E_INVALID;
+    for (uint32_t q = 0; q < n_queries; ++q)
+        n_out[q] = 0;
+    if (n_queries == 0)
+        return RLR_OK;
+    if (diversity_factor < 0.0f) diversity_factor = 0.0f;
+    if (diversity_factor > 1.0f) diversity_factor = 1.0f;
+    rlr_resolved_weights w;
+    rlr_resolve_weights(weights, &w);
+    MultiBackend be;
+    multi_backend(m, &be);
+    std::vector<std::vector<rlr_host::Cand>> results;
+    const int32_t st = rlr_host::generic_search_with_diversity_batch(be, queries_raw, dq, n_queries, top_k, diversity_factor, w,
+                                                                     results);
+    if (st != RLR_OK)
+        return st;
+    for (uint32_t q = 0; q < n_queries; ++q)
+        rlr_host::emit(results[q], out + static_cast<size_t>(q) * cap, cap, &n_out[q]);
+    return RLR_OK;
+}
+
+int32_t rlr_multi_engine_embedding_candidates(rlr_multi *m, const float *query_raw, uint32_t dq, uint32_t count,
+                                              uint64_t *rows_out, float *scores_out, uint32_t *n_out)
+{
+    if (!m || !n_out || (!query_raw && dq))
+        return RLR_E_INVALID;
+    *n_out = 0;
+    if (m->n_rows == 0 || count == 0)
+        return RLR_OK;
+    const std::vector<float> q = rlr_host::prepare_query(query_raw, dq, m->dim);
+    return rlr_multi_search_topk(m, q.data(), 1, count, -1.0f, rows_out, scores_out, n_out);
 }
 
 } // extern "C"

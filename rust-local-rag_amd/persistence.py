@@ -141,6 +141,11 @@ def _read_state(path: str, dim: int, native: bool):
             state = json.loads(C.string_at(c.meta_json, c.meta_len).decode("utf-8"))
         finally:
             N.lib().rlr_json_free_corpus(C.byref(c))
+        chunks = state.get("chunks", {}) if isinstance(state, dict) else {}
+        if rows.shape[0] != (len(chunks) if isinstance(chunks, dict) else 0):
+            # the two readers disagree about what the file's chunk map holds: never pair rows with the wrong chunks
+            raise N.RlrError(N.RLR_E_INVALID, f"{path}: {rows.shape[0]} embedding rows for "
+                                              f"{len(chunks) if isinstance(chunks, dict) else 0} chunks")
         return state, rows
     with open(path, encoding="utf-8") as f:
         state = json.load(f)

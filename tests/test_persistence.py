@@ -195,7 +195,39 @@ def test_streaming_reader_equals_the_json_module_on_hostile_documents(rlr, tmp_p
     open(path, "w").write('{"chunks": {"k": {"embedding": [1, 1], "embedding": [2]}}, "version": 2, "model": "m"}')
     rows, meta = _native_read(rlr, path, 3)
     assert rows.tolist() == [[2.0, 0.0, 0.0]]
-    # malformed input is an error, not a guess
+    # the document is a MAP (serde_json HashMap, Python dict): a repeated chunk id keeps its first position and takes
+    # the last value, two spellings of one id are one id, a repeated "chunks" member starts over -- rows must stay
+    # paired with the chunks json.loads sees
+    dup_docs = [
+        '{"version": 2, "chunks": {"a": {"embedding": [1, 1]}, "b": {"embedding": [2]}, "a": {"embedding": [3]}, "c": {"embedding": [4]}}}',
+        '{"version": 2, "chunks": {"a": {"embedding": [1, 1]}, "b": {"embedding": [2]}, "\\u0061": {"text": "no embedding now"}}}',
+        '{"version": 2, "chunks": {"a": {"embedding": [1]}, "a": 5, "b": {"embedding": [2]}}}',
+        '{"chunks": {"x": {"embedding": [9]}, "y": {"embedding": [8]}}, "version": 2, "chunks": {"p": {"embedding": [1, 2, 3]}}}',
+        '{"chunks": {"x": {"embedding": [9]}}, "ch\\u0075nks": {"q": {"embedding": [7]}, "r": {}}}',
+        '{"chunks": {"x": {"embedding": [9]}}, "chunks": null, "version": 2}',
+    ]
+    for i, doc in enumerate(dup_docs):
+        path = str(tmp_path / f"dupid{i}.json")
+        open(path, "w").write(doc)
+        rows, meta = _native_read(rlr, path, 3)
+        want_state, want_rows = persistence._read_state(path, 3, native=False)
+        assert json.loads(meta) == {k: ({ck: ({**cv, "embedding": []} if isinstance(cv, dict) and "embedding" in cv else cv)
+                                         for ck, cv in v.items()} if k == "chunks" and isinstance(v, dict) else v)
+                                    for k, v in want_state.items()}, doc
+        assert rows.shape == want_rows.shape and np.array_equal(bits(rows), bits(want_rows)), doc
+    # malformed input is an error, not a guess: numbers follow the JSON grammar (serde_json and the json module refuse
+    # inf / nan / 01 / 1. / .5 / +1, doubled and trailing commas, nested arrays)
+    for lit in ("inf", "-inf", "Infinity", "nan", "NaN", "01", "1.", ".5", "+1", "1e", "1e+", "0x10", "--1", "[1]", '"1"', "1,,2", "1,"):
+        path = str(tmp_path / "badnum.json")
+        open(path, "w").write('{"chunks": {"k": {"embedding": [%s]}}}' % lit)
+        with pytest.raises(rlr.RlrError):
+            _native_read(rlr, path, 3)
+    # literals beyond binary64: +-inf or +-0 by magnitude, with or without an exponent (as serde_json's f64 path)
+    path = str(tmp_path / "huge.json")
+    open(path, "w").write('{"chunks": {"k": {"embedding": [%s, -%s, 1e-400, -0.%s1, 1e400, 0.%s1e500]}}}'
+                          % ("9" * 400, "9" * 400, "0" * 400, "0" * 20))
+    rows, _ = _native_read(rlr, path, 6)   # (the json module cannot be the comparator here: a 400-digit integer is a Python int)
+    assert rows[0, 0] == np.inf and rows[0, 1] == -np.inf and rows[0, 2] == 0 and bits(rows)[0, 3] == 0x80000000 and rows[0, 4] == np.inf and rows[0, 5] == np.inf
     for bad in ('{"chunks": {"k": {"embedding": [1, 2', '{"chunks": {"k": {"embedding": [1, x]}}}', "[1, 2]", ""):
         path = str(tmp_path / "bad.json")
         open(path, "w").write(bad)
