@@ -65,6 +65,12 @@ class ProfileC(C.Structure):
                 ("n_mmr", C.c_uint64), ("mmr_ms", C.c_double)]
 
 
+class MultiStatsC(C.Structure):
+    _fields_ = [("n_topk_rccl", C.c_uint64), ("n_topk_host_merge", C.c_uint64), ("n_topk_rccl_fell_back", C.c_uint64),
+                ("topk_rccl_ms", C.c_double), ("n_mmr_exchanges", C.c_uint64), ("mmr_exchange_bytes", C.c_uint64),
+                ("mmr_exchange_ms", C.c_double)]
+
+
 # every symbol include/*.h declares: (name, restype, argtypes)
 _H = C.c_void_p
 PROTOTYPES = [
@@ -116,6 +122,13 @@ PROTOTYPES = [
     ("rlr_multi_score_rows", C.c_int32, [_H, f32p, u64p, C.c_uint32, f32p]),
     ("rlr_multi_fetch_rows", C.c_int32, [_H, u64p, C.c_uint32, f32p]),
     ("rlr_multi_mmr_select", C.c_int32, [_H, u64p, f32p, C.c_uint32, C.c_uint32, C.c_float, u32p, f32p, u32p]),
+    ("rlr_multi_mmr_select_batch", C.c_int32, [_H, u64p, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, u32p, f32p,
+                                               u32p]),
+    ("rlr_multi_stats", C.c_int32, [_H, C.POINTER(MultiStatsC), C.c_int32]),
+    ("rlr_gather_rows_device", C.c_int32, [_H, u64p, C.c_uint32, C.c_void_p]),
+    ("rlr_index_row_bytes", C.c_int32, [_H, u32p]),
+    ("rlr_mmr_select_staged", C.c_int32, [_H, C.c_void_p, C.c_uint64, u64p, f32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_float, u32p, f32p, u32p]),
     ("rlr_profile_enable", C.c_int32, [_H, C.c_int32]),
     ("rlr_profile_read", C.c_int32, [_H, C.POINTER(ProfileC), C.c_int32]),
     # rlr_engine.h
@@ -136,6 +149,18 @@ PROTOTYPES = [
                                               C.POINTER(QueryWeightsC), C.POINTER(SearchHitC), f32p, i32p, C.c_uint32,
                                               u32p]),
     ("rlr_engine_embedding_candidates", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, u64p, f32p, u32p]),
+    ("rlr_multi_engine_search", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.POINTER(QueryWeightsC), u64p, f32p,
+                                            C.c_uint32, C.c_int32, C.POINTER(SearchHitC), C.c_uint32, u32p]),
+    ("rlr_multi_engine_search_with_diversity", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float,
+                                                           C.POINTER(QueryWeightsC), u64p, f32p, C.c_uint32,
+                                                           C.POINTER(SearchHitC), C.c_uint32, u32p]),
+    ("rlr_multi_engine_search_text", C.c_int32, [_H, _H, f32p, C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32, C.c_float,
+                                                 C.c_int32, C.POINTER(QueryWeightsC), C.POINTER(SearchHitC), C.c_uint32,
+                                                 u32p]),
+    ("rlr_multi_engine_search_with_diversity_batch", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
+                                                                 C.POINTER(QueryWeightsC), C.POINTER(SearchHitC),
+                                                                 C.c_uint32, u32p]),
+    ("rlr_multi_engine_embedding_candidates", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, u64p, f32p, u32p]),
     # rlr_lexical.h
     ("rlr_lexical_create", C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
     ("rlr_lexical_destroy", None, [_H]),

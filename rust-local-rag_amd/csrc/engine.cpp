@@ -328,6 +328,7 @@ int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *qu
     const uint64_t want3 = static_cast<uint64_t>(k_seen) * 3;
     const uint64_t initial_k = std::min<uint64_t>(N, want3);                                            // :544
     const uint64_t need = (diversify || !stage) ? std::min<uint64_t>(initial_k, k_seen) : initial_k;    // :667-698
+    bool retry_exact = false;
     if (w.embedding > 0.0f && need <= 1024) {
         // 1. the cosine scan .. sort goes onto the index' stream; 2. the BM25 kernels onto the lexical index' own stream
         // -- the device runs them side by side, and the host's launch calls for the second batch overlap the scan;
@@ -336,6 +337,7 @@ int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *qu
         const uint32_t nd = static_cast<uint32_t>(need);
         rlr::HybridTicket *ticket = nullptr;
         int32_t fb = 0;
+        bool sampled_gave_up = false;
         st = rlr::search_hybrid_begin(idx, q.data(), nd, top_k, diversity_factor, diversify ? 1 : 0, w.embedding, w.lexical,
                                       std::min<uint32_t>(limit, RLR_LEXICAL_MAX_LIMIT), -1.0f, &ticket, &fb);
         if (st != RLR_OK)
@@ -364,14 +366,18 @@ int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *qu
                 emit(res, out, cap, n_out);
                 return RLR_OK;
             }
+            sampled_gave_up = fb == 3;
         }
+        retry_exact = sampled_gave_up;
     }
     // not covered by the fused kernels (or handed back): the pairs on the host, then the entry points that take them
     const uint32_t lcap = limit == 0 ? RLR_LEXICAL_MAX_LIMIT : std::min<uint32_t>(limit, RLR_LEXICAL_MAX_LIMIT);
     std::vector<uint64_t> lrows(lcap);
     std::vector<float> lscores(lcap);
     uint32_t n_lex = 0;
-    st = rlr_lexical_score(lex, query_tokens, tokens_len, limit, lrows.data(), lscores.data(), &n_lex);
+    // (handed back by the BM25 selection's sample, status 3: counted as a retry, straight to the exact passes)
+    st = retry_exact ? rlr::lexical_score_exact(lex, query_tokens, tokens_len, limit, lrows.data(), lscores.data(), &n_lex)
+                     : rlr_lexical_score(lex, query_tokens, tokens_len, limit, lrows.data(), lscores.data(), &n_lex);
     if (st != RLR_OK)
         return st;
     return diversify ? rlr_engine_search_with_diversity(idx, query_raw, dq, top_k, diversity_factor, weights, lrows.data(),

@@ -2508,10 +2508,21 @@ static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t nee
     std::memcpy(h_q, query, ix->dim * sizeof(float));
     stage_query_norms(ix, c, query, 1);
     c->hist_dirty = true;
+    // from here on work may be queued on `s`: an error exit drains it before the lease hands the context back
+    struct Drain {
+        hipStream_t s;
+        bool armed = true;
+        ~Drain()
+        {
+            if (armed)
+                (void)hipStreamSynchronize(s);
+        }
+    } drain{s};
     RLR_HIP(hipMemcpyAsync(c->d_query, h_q, t->q_bytes, hipMemcpyHostToDevice, s));
     uint64_t *d_meta = c->d_out + fetch;
     RLR_HIP(enqueue_query(ix, c, 0, p, c->d_out, d_meta, t->timed));
     if (t->timed) RLR_HIP(hipEventRecord(c->bev[0], s));
+    drain.armed = false;
     *out = t.release();
     return RLR_OK;
 }

@@ -1066,8 +1066,30 @@ int32_t rlr_lexical_segments(rlr_lexical *lx, uint64_t *main_postings, uint64_t 
     return RLR_OK;
 }
 
+// first_attempt = 1: skip the sampled selection (a fused search already saw it hand this query back)
+static int32_t lexical_score_from(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, uint64_t *rows_out,
+                                  float *scores_out, uint32_t *n_out, int first_attempt);
+
 int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, uint64_t *rows_out,
                           float *scores_out, uint32_t *n_out)
+{
+    return lexical_score_from(lx, query_tokens, len, limit, rows_out, scores_out, n_out, 0);
+}
+
+extern "C++" {
+namespace rlr {
+int32_t lexical_score_exact(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, uint64_t *rows_out,
+                            float *scores_out, uint32_t *n_out)
+{
+    if (lx)
+        lx->n_select_retries++; // the fused search's sampled selection gave up on this query
+    return lexical_score_from(lx, query_tokens, len, limit, rows_out, scores_out, n_out, 1);
+}
+} // namespace rlr
+} // extern "C++"
+
+static int32_t lexical_score_from(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, uint64_t *rows_out,
+                                  float *scores_out, uint32_t *n_out, int first_attempt)
 {
     if (!lx)
         return set_error(RLR_E_INVALID, "lexical handle is null");
@@ -1076,7 +1098,7 @@ int32_t rlr_lexical_score(rlr_lexical *lx, const char *query_tokens, size_t len,
     *n_out = 0;
     if (len && !query_tokens)
         return set_error(RLR_E_INVALID, "query_tokens is null");
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = first_attempt; attempt < 2; ++attempt) {
         rlr::LexPending p;
         LEX_TRY(rlr::lexical_enqueue(lx, query_tokens, len, limit, &p, /*need_sorted=*/true, /*exact_passes=*/attempt == 1));
         if (p.limit == 0) // empty index, no tokens, or no term of the query is known (:2170-2177, :2196)

@@ -34,6 +34,10 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *tokens, size_t len, uint32_
 constexpr uint32_t kLexicalRetry = 0xFFFFFFFFu;
 // copy the result to the host (synchronises the scoring stream); valid between enqueue and finish
 int32_t lexical_fetch(LexPending *p, uint64_t *rows_out, float *scores_out, uint32_t *n_out);
+// rlr_lexical_score without the sampled attempt, for a query whose fused search came back with kLexicalRetry (status 3):
+// counts the retry (rlr_lexical_segments: select_retries) and goes straight to the exact radix passes
+int32_t lexical_score_exact(rlr_lexical *lx, const char *tokens, size_t len, uint32_t limit, uint64_t *rows_out,
+                            float *scores_out, uint32_t *n_out);
 // hand the workspace back once every consumer of d_packed has finished (the caller synchronised them);
 // ok = false: something failed after the enqueue -- the workspace is re-zeroed before its next use
 void lexical_finish(LexPending *p, bool ok);

@@ -295,6 +295,96 @@ class MultiGpuIndex:
                                              order.ctypes.data_as(N.u32p), _fp(mmr), C.byref(n)))
         return order[: n.value], mmr[: n.value]
 
+    def mmr_select_batch(self, pool_rows, pool_scores, pool_sizes, k: int, lam: float):
+        """pools strided by P = pool_rows.shape[1]; -> (order [nq, P], mmr [nq, P], n_selected [nq])"""
+        pool_rows = _u64(pool_rows)
+        nq, P = pool_rows.shape
+        pool_scores = _f32(pool_scores).reshape(nq, P)
+        sizes = np.ascontiguousarray(pool_sizes, dtype=np.uint32)
+        order = np.zeros((max(nq, 1), max(P, 1)), dtype=np.uint32)
+        mmr = np.zeros((max(nq, 1), max(P, 1)), dtype=np.float32)
+        n = np.zeros(max(nq, 1), dtype=np.uint32)
+        N.check(self._L.rlr_multi_mmr_select_batch(self._h, _up(pool_rows), _fp(pool_scores), sizes.ctypes.data_as(N.u32p), nq, P, k,
+                                                   lam, order.ctypes.data_as(N.u32p), _fp(mmr), n.ctypes.data_as(N.u32p)))
+        return order[:nq], mmr[:nq], n[:nq]
+
+    def stats(self, reset: bool = False) -> dict:
+        st = N.MultiStatsC()
+        N.check(self._L.rlr_multi_stats(self._h, C.byref(st), int(reset)))
+        return {name: getattr(st, name) for name, _ in N.MultiStatsC._fields_}
+
+    # ---- RagEngine::search / search_with_diversity over the sharded corpus (rlr_multi_engine_*) ----
+    # results: numpy records (row, score, embedding_score, lexical_score, initial_score), global rows
+    _HIT = np.dtype([("row", "<u8"), ("score", "<f4"), ("embedding_score", "<f4"), ("lexical_score", "<f4"),
+                     ("initial_score", "<f4")])
+
+    @staticmethod
+    def _lex_args(lex_rows, lex_scores):
+        if lex_rows is None or len(lex_rows) == 0:
+            return np.zeros(1, np.uint64), np.zeros(1, np.float32), 0
+        lr, ls = _u64(lex_rows).ravel(), _f32(lex_scores).ravel()
+        return lr, ls, int(lr.size)
+
+    def engine_search(self, query, top_k: int, weights=None, lex_rows=None, lex_scores=None, stage: int = 0):
+        q = _f32(query).ravel()
+        cap = max(3 * max(top_k, 1), 1)
+        hits = (N.SearchHitC * cap)()
+        n = C.c_uint32()
+        lr, ls, nl = self._lex_args(lex_rows, lex_scores)
+        wc = weights.to_c() if weights is not None else None
+        N.check(self._L.rlr_multi_engine_search(self._h, _fp(q), q.size, top_k, C.byref(wc) if wc is not None else None, _up(lr),
+                                                _fp(ls), nl, stage, hits, cap, C.byref(n)))
+        return np.frombuffer(hits, dtype=self._HIT, count=n.value).copy()
+
+    def engine_search_with_diversity(self, query, top_k: int, diversity_factor: float, weights=None, lex_rows=None,
+                                     lex_scores=None):
+        q = _f32(query).ravel()
+        cap = max(3 * max(top_k, 1), top_k + 10)
+        hits = (N.SearchHitC * cap)()
+        n = C.c_uint32()
+        lr, ls, nl = self._lex_args(lex_rows, lex_scores)
+        wc = weights.to_c() if weights is not None else None
+        N.check(self._L.rlr_multi_engine_search_with_diversity(self._h, _fp(q), q.size, top_k, float(diversity_factor),
+                                                               C.byref(wc) if wc is not None else None, _up(lr), _fp(ls), nl,
+                                                               hits, cap, C.byref(n)))
+        return np.frombuffer(hits, dtype=self._HIT, count=n.value).copy()
+
+    def engine_search_text(self, lexical, query, tokens: str, top_k: int, diversity_factor: float, weights=None, stage: int = 0):
+        """lexical: a LexicalIndex over the global rows; tokens: the host's tokenize(query), space separated"""
+        q = _f32(query).ravel()
+        cap = max(3 * max(top_k, 1), top_k + 10)
+        hits = (N.SearchHitC * cap)()
+        n = C.c_uint32()
+        tok = tokens.encode("utf-8")
+        wc = weights.to_c() if weights is not None else None
+        N.check(self._L.rlr_multi_engine_search_text(self._h, lexical._h, _fp(q), q.size, tok, len(tok), top_k,
+                                                     float(diversity_factor), stage, C.byref(wc) if wc is not None else None,
+                                                     hits, cap, C.byref(n)))
+        return np.frombuffer(hits, dtype=self._HIT, count=n.value).copy()
+
+    def engine_search_with_diversity_batch(self, queries, top_k: int, diversity_factor: float, weights=None):
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        nq, dq = q.shape
+        cap = max(3 * max(top_k, 1), top_k + 10)
+        hits = (N.SearchHitC * (cap * max(nq, 1)))()
+        n_out = np.zeros(max(nq, 1), dtype=np.uint32)
+        wc = weights.to_c() if weights is not None else None
+        N.check(self._L.rlr_multi_engine_search_with_diversity_batch(self._h, _fp(q), dq, nq, top_k, float(diversity_factor),
+                                                                     C.byref(wc) if wc is not None else None, hits, cap,
+                                                                     n_out.ctypes.data_as(N.u32p)))
+        allh = np.frombuffer(hits, dtype=self._HIT, count=cap * max(nq, 1)).reshape(max(nq, 1), cap)
+        return [allh[i, : int(n_out[i])].copy() for i in range(nq)]
+
+    def engine_embedding_candidates(self, query, count: int):
+        q = _f32(query).ravel()
+        rows = np.zeros(max(count, 1), dtype=np.uint64)
+        sc = np.zeros(max(count, 1), dtype=np.float32)
+        n = C.c_uint32()
+        N.check(self._L.rlr_multi_engine_embedding_candidates(self._h, _fp(q), q.size, count, _up(rows), _fp(sc), C.byref(n)))
+        return rows[: n.value], sc[: n.value]
+
 
 def default_guard_eps(dim: int) -> float:
     return float(N.lib().rlr_default_guard_eps(dim))

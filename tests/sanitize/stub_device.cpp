@@ -178,6 +178,10 @@ int32_t lexical_fetch(LexPending *, uint64_t *, float *, uint32_t *n_out)
     return RLR_OK;
 }
 void lexical_finish(LexPending *, bool) {}
+int32_t lexical_score_exact(rlr_lexical *lx, const char *t, size_t len, uint32_t limit, uint64_t *rows, float *scores, uint32_t *n_out)
+{
+    return rlr_lexical_score(lx, t, len, limit, rows, scores, n_out);
+}
 int32_t search_hybrid_begin(rlr_index *, const float *, uint32_t, uint32_t, float, int32_t, float, float, uint32_t, float,
                             HybridTicket **ticket, int32_t *fallback)
 {

@@ -198,6 +198,26 @@ def fuzz_multi(n_target: int, seed0: int):
             o1, m1 = one.mmr_select(r1[0][:P], sc, kk, lam)
             om, mm = mi.mmr_select(r1[0][:P], sc, kk, lam)
             assert np.array_equal(o1, om) and np.array_equal(bits(m1[1:]), bits(mm[1:])), ("mmr", ctx)
+        # the engine-level entry points over the shards (rlr_multi_engine_*) against the oracle's search over the whole corpus
+        k2, lam2 = int(rng.choice([0, 1, 7, 40])), float(rng.choice([0.0, 0.3, 0.7, 1.0]))
+        n_lex = int(rng.choice([0, 0, 3, 25]))
+        lex = [(int(r), float(np.float32(x))) for r, x in zip(rng.integers(0, n + 2, size=n_lex), rng.random(n_lex) * 5)]
+        lr, ls = [r for r, _ in lex], [x for _, x in lex]
+        w_e = float(rng.choice([0.7, 0.7, 1.0, 0.0, 1e-40]))
+        w = rlr.QueryWeights(embedding=w_e)
+        for i in range(min(nq, 2)):
+            wr, wc, we, wl = O.search_with_diversity(rows, qs[i], k2, lam2, w_e=w_e, lex=lex)
+            h = mi.engine_search_with_diversity(qs[i], k2, lam2, weights=w, lex_rows=lr, lex_scores=ls)
+            assert [int(r) for r in h["row"]] == [int(r) for r in wr] and np.array_equal(bits(h["score"]), bits(wc)) and \
+                np.array_equal(bits(h["embedding_score"]), bits(we)) and np.array_equal(bits(h["lexical_score"]), bits(wl)), ("engine", i, k2, lam2, w_e, n_lex, ctx)
+            wr, wc, we, wl = O.search(rows, qs[i], k2, w_e=w_e, lex=lex, stage=1)
+            h = mi.engine_search(qs[i], k2, weights=w, lex_rows=lr, lex_scores=ls, stage=1)
+            assert [int(r) for r in h["row"]] == [int(r) for r in wr] and np.array_equal(bits(h["score"]), bits(wc)), ("engine stage 1", i, k2, w_e, n_lex, ctx)
+        hb = mi.engine_search_with_diversity_batch(qs, k2, lam2, weights=w)
+        for i in range(nq):
+            wr, wc, we, _ = O.search_with_diversity(rows, qs[i], k2, lam2, w_e=w_e)
+            assert [int(r) for r in hb[i]["row"]] == [int(r) for r in wr] and np.array_equal(bits(hb[i]["score"]), bits(wc)) and \
+                np.array_equal(bits(hb[i]["embedding_score"]), bits(we)), ("engine batch", i, k2, lam2, w_e, ctx)
         one.close()
         mi.close()
         n_cases += 1
