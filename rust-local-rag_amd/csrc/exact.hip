@@ -1078,6 +1078,108 @@ hipError_t launch_compact_rows(const void *src, void *dst, uint32_t pitch16, con
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same reference-order Gram matrices on the f32 MATRIX cores, for binary16 rows.  A K = 1 f32 matrix instruction
+// computes d = fl(c + a * b) per element, one correctly rounded step; the product of two binary16 values is exact in f32
+// (11-bit x 11-bit significands), so fl(c + a * b) IS the reference's `s = s + fl(a * b)` and a chain of these instructions
+// over k = 0 .. dim-1 is dot_product's strict left-to-right sum, bit for bit -- for 2 x 32 x 32 pairs per instruction
+// (v_mfma_f32_32x32x1_2b_f32: lanes 0-31 carry block 0's row elements, lanes 32-63 block 1's).  Checked on the device
+// against the sequential chain over 2 x 10^5 pairs with cancellation, tiny terms and binary16 subnormals
+// (scratch/mmr_nom/mfma_f32_chain_probe.hip: 0 differ; the K = 2 and K = 4 forms step through k in order too).  The f32
+// matrix rate equals the f32 vector rate, but an instruction needs two operand registers for 2048 products where the
+// register-tiled VALU kernel above is bound by its LDS fragment reads (30 of 157 TFLOP/s): 3.3 -> ~1 ms per 1024 pools of
+// 308 x 1024-d (config 5).  f32-stored rows stay on the VALU kernel: their products are not exact, and a fused step would
+// round once where the reference rounds twice.
+// One wave = two 32 x 32 tiles (bi <= bj) of one pool; a lane streams its A row and its B row 16 bytes (8 k-steps) at a
+// time, next piece in flight behind the current 8 instructions; all tiles of a pool run on one XCD (its rows stay in that L2).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float v32f __attribute__((ext_vector_type(32)));
+constexpr int kGmK = 64;               // binary16 elements per staged K chunk
+constexpr int kGmPitch = kGmK * 2 + 16; // bytes per staged row: 16-byte reads of consecutive rows land in different slots
+
+// Workgroup = ONE wave = the two tiles (2p, J) and (2p + 1, J), J >= 2p: lanes 0-31 carry the first, lanes 32-63 the second.
+// Its 64 + 32 rows are staged through a wave-private LDS block per 64-wide K chunk with coalesced loads (8 lanes per 128-byte
+// row piece); the next chunk waits in registers behind the current chunk's 64 matrix instructions.  No barrier anywhere: with
+// four-wave workgroups sharing their staged rows the waves of the two resident workgroups ran in lock step from barrier to
+// barrier and ragged workgroups left SIMDs idle (57 % matrix-pipe occupancy, 1.58 ms per 1024 pools of 300 x 1024-d); and a lane
+// streaming its own row straight from global memory makes 64 cache-line requests per instruction (4.3 ms, worse than the VALU
+// kernel's 3.3).  The row pair's one tile below the diagonal is computed twice, everything else once; all waves of a pool run
+// on one XCD (its rows come from HBM once).
+__global__ __launch_bounds__(64) void gram_mfma_f32_kernel(const unsigned char *__restrict__ rows, uint32_t pitch_bytes,
+                                                           const uint32_t *__restrict__ list, uint32_t P, uint32_t n_pools,
+                                                           uint32_t jobs_per_pool, float *__restrict__ gram)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_rows[96 * kGmPitch]; // rows 0..63: A (2p, 2p + 1), 64..95: B (J)
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t pool = (slot / jobs_per_pool) * 8 + xcd;
+    if (pool >= n_pools)
+        return;
+    const uint32_t nb = (P + 31) / 32;
+    uint32_t p = 0, rem = slot % jobs_per_pool; // job -> (row pair p, column block 2p + rem): pair p owns nb - 2p jobs
+    while (rem >= nb - 2 * p) {
+        rem -= nb - 2 * p;
+        ++p;
+    }
+    const uint32_t I0 = 2 * p, J = 2 * p + rem;
+    list += static_cast<size_t>(pool) * P;
+    gram += static_cast<size_t>(pool) * P * P;
+    const uint32_t lane = threadIdx.x;
+    // twelve 16-byte units per lane and chunk: units 0..511 = A (64 rows x 8 segments), 512..767 = B (32 rows x 8)
+    const unsigned char *src[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const uint32_t u = lane + 64 * i, rr = u >> 3, seg = u & 7; // rr = staged row 0..95
+        const uint32_t row = min(rr < 64 ? I0 * 32 + rr : J * 32 + (rr - 64), P - 1);
+        src[i] = rows + static_cast<size_t>(list[row]) * pitch_bytes + seg * 16;
+    }
+    const uint32_t seg = lane & 7;
+    const uint32_t row_units = pitch_bytes / 16; // a row's last chunk may be short: units beyond the pitch read as zero
+    const uint32_t n_chunks = (row_units + 7) / 8;
+    uint4 pre[12];
+    auto fetch = [&](uint32_t c) {
+        const bool in = c * 8 + seg < row_units;
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            pre[i] = in ? *reinterpret_cast<const uint4 *>(src[i] + static_cast<size_t>(c) * (kGmK * 2)) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    v32f acc;
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        acc[i] = 0.0f;
+    const unsigned char *la = s_rows + lane * kGmPitch;               // A row = lane (block = lane >> 5)
+    const unsigned char *lb = s_rows + (64 + (lane & 31)) * kGmPitch; // B row
+    fetch(0);
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            *reinterpret_cast<uint4 *>(s_rows + ((lane + 64 * i) >> 3) * kGmPitch + seg * 16) = pre[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the block is private to this wave: LDS is in order, no barrier
+        if (c + 1 < n_chunks)
+            fetch(c + 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint4 ca = *reinterpret_cast<const uint4 *>(la + u * 16), cb = *reinterpret_cast<const uint4 *>(lb + u * 16);
+            const uint32_t wa[4] = {ca.x, ca.y, ca.z, ca.w}, wb[4] = {cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x1f32(h2f(static_cast<uint16_t>(wa[j] & 0xFFFF)), h2f(static_cast<uint16_t>(wb[j] & 0xFFFF)), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x1f32(h2f(static_cast<uint16_t>(wa[j] >> 16)), h2f(static_cast<uint16_t>(wb[j] >> 16)), acc, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // this chunk's reads before the next chunk's writes
+    }
+    // accumulator register v of lane l: block v / 16, A row 8 ((v % 16) / 4) + 4 (l / 32) + v % 4, B row l % 32
+    const uint32_t jcol = J * 32 + (lane & 31);
+#pragma unroll
+    for (int v = 0; v < 32; ++v) {
+        const uint32_t i = (I0 + v / 16) * 32 + 8 * ((v % 16) / 4) + 4 * (lane >> 5) + (v % 4);
+        if (i < P && jcol < P) {
+            gram[static_cast<size_t>(i) * P + jcol] = acc[v];
+            gram[static_cast<size_t>(jcol) * P + i] = acc[v];
+        }
+    }
+}
+
 template <int SRC>
 static hipError_t launch_gram_src(const float *pool, uint32_t P, uint32_t dim, float *gram, uint32_t n_queries,
                                   const void *rows, uint32_t pitch16, const uint32_t *list, hipStream_t s)
@@ -1122,8 +1224,21 @@ hipError_t launch_gram_rows(const void *rows, uint32_t pitch16, uint32_t dim, in
 {
     if (P == 0 || n_queries == 0)
         return hipSuccess;
-    if (dtype == RLR_F16)
+    if (dtype == RLR_F16) {
+        // enough pools to fill the chip (two 32 x 32 tiles per wave, 1024 k-steps each): the f32 matrix cores
+        static const bool valu_only = getenv("RLR_GRAM_VALU") != nullptr;
+        if (n_queries >= 16 && !valu_only) {
+            const uint32_t nb = (P + 31) / 32;
+            uint32_t jobs_per_pool = 0;
+            for (uint32_t pr = 0; 2 * pr < nb; ++pr)
+                jobs_per_pool += nb - 2 * pr;
+            const uint32_t pools8 = (n_queries + 7) / 8 * 8;
+            hipLaunchKernelGGL(gram_mfma_f32_kernel, dim3(pools8 * jobs_per_pool), dim3(64), 0, s, static_cast<const unsigned char *>(rows),
+                               pitch16 * 16u, list, P, n_queries, jobs_per_pool, gram);
+            return hipGetLastError();
+        }
         return launch_gram_src<2>(nullptr, P, dim, gram, n_queries, rows, pitch16, list, s);
+    }
     return launch_gram_src<1>(nullptr, P, dim, gram, n_queries, rows, pitch16, list, s);
 }
 

@@ -28,7 +28,10 @@ sizes = np.full(nq, 308, np.uint32)
 if "--cold" not in sys.argv:
     ix.mmr_select_batch(r[:, :300].copy(), sc[:, :300].copy(), np.full(nq, 300, np.uint32), k, lam)
 rr, ss, zz = r[:, :300].copy(), sc[:, :300].copy(), np.full(nq, 300, np.uint32)
+ix.profile_read(reset=True); ix.profile_enable(True)
 t0 = time.perf_counter(); order, mmr, nn = ix.mmr_select_batch(rr, ss, zz, k, lam); t_mmr = time.perf_counter() - t0
+pm = ix.profile_read(); ix.profile_enable(False)
+mmr_info = {"mmr_kernels_ms": pm.mmr_ms}
 # single-path spot check of 3 queries
 ok = True
 for i in (0, 511, 1023):
@@ -39,4 +42,4 @@ print(json.dumps({"rows": n, "dim": dim, "dtype": "f16", "queries": nq, "fill_s"
                   "gemm_ms": p.batch_gemm_ms, "other_ms": p.batch_other_ms, "fallbacks": p.n_batch_fallbacks,
                   "gemm_GBps": p.batch_gemm_bytes / (p.batch_gemm_ms * 1e-3) / 1e9 if p.batch_gemm_ms else None,
                   "gemm_TFLOPs": p.batch_gemm_flops / (p.batch_gemm_ms * 1e-3) / 1e12 if p.batch_gemm_ms else None,
-                  "mmr_batch_ms": t_mmr * 1e3, "batched_equals_single_path": ok}))
+                  "mmr_batch_ms": t_mmr * 1e3, "mmr": mmr_info, "batched_equals_single_path": ok}))
