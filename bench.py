@@ -105,6 +105,30 @@ def pmc_traffic(bytes_per_launch, kernel):
     return best
 
 
+def batched_traffic(bytes_per_launch, kernel):
+    """HBM bytes of the batch's main GEMM pass from the committed rocprofv3 counter passes of the same shape
+    (profiles/rNN_*_kernels.json, `counters_by_ordinal`: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE per launch of that
+    ordinal inside a batch); the newest summary whose fetch bytes are within 10 % of this launch's operand bytes."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernels.json"))):
+        try:
+            cbo = json.load(open(f)).get("counters_by_ordinal", {})
+        except Exception:
+            continue
+        for name, by_ord in cbo.items():
+            if kernel not in name:
+                continue
+            for o, c in by_ord.items():
+                fetch = c.get("FETCH_SIZE", {}).get("bytes_corrected_x2")
+                if fetch is None or abs(fetch - bytes_per_launch) > 0.10 * bytes_per_launch:
+                    continue
+                write = c.get("WRITE_SIZE", {}).get("bytes", 0.0)
+                best = (fetch + write, os.path.basename(f) + f" ({name}, launch {o} of a batch)")
+    return best
+
+
 def batched_roofline(prof, dim, nq, image):
     """roofline object of the dominant launch of a batch (the filtered main GEMM pass), from the library's HIP
     events on its own stream.  `bound` is the roof with the larger ideal time for this launch: the operand bytes
@@ -118,7 +142,10 @@ def batched_roofline(prof, dim, nq, image):
     hbm = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS}
     mfma = {"achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F16_PEAK_TFLOPS}
     main = dict(mfma if t_mfma >= t_hbm else hbm)
-    main.update({"bound": "mfma" if t_mfma >= t_hbm else "hbm", "traffic": None,
+    traffic = batched_traffic(b, batch_kernel_name(dim, nq, image))
+    main.update({"bound": "mfma" if t_mfma >= t_hbm else "hbm", "traffic": traffic[0] if traffic else None,
+                 "traffic_source": ("profiles/" + traffic[1] + ": FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of "
+                                    "this shape") if traffic else None,
                  "kernel": batch_kernel_name(dim, nq, image) + " (the filtered main pass of a batch)",
                  "kernel_ms": ms, "bytes_per_launch": b, "flops_per_launch": fl,
                  "hbm": hbm, "mfma": mfma,

@@ -9,6 +9,12 @@
       python profiles/summarize.py kernels <out tag> <kt dir> "<command>" <substr,substr,...> [--pmc dir ...]
       (counters are reported for the FIRST substring's kernel only)
       -> <out tag>_kernel_stats.csv, <out tag>_kernels.json
+      The --stats table lumps every dispatch of a kernel into one row, but a batch launches the same GEMM kernel over a short
+      row range (bootstrap) and over the rest of the corpus (the main pass the roofline claims are about) with the SAME
+      persistent grid.  So the per-dispatch trace (<kt dir>/*_kernel_trace.csv) is also read: it is cut into batches at every
+      dispatch of the anchor kernel (prep_queries_kernel: the first launch of a batch) and the FIRST substring's kernel is
+      reported per ordinal inside its batch ("dispatch_groups": calls / avg / min / max of the 1st, 2nd, ... launch per
+      batch); the counter passes are grouped the same way ("counters_by_ordinal").
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE reports
 exactly half of the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact for 16-B/4-B
@@ -49,6 +55,37 @@ def stats_rows(d_kt):
     return fs[-1], list(csv.DictReader(open(fs[-1])))  # newest: a re-used directory keeps older runs' files
 
 
+def ordinal_groups(rows, kernel_substr, anchor="prep_queries_kernel", name_key="Kernel_Name"):
+    """rows: per-dispatch records in dispatch order -> {kernel name: {ordinal within its batch: [records]}}; a batch starts at
+    every dispatch of `anchor` (no anchor in the trace: the whole run is one batch and the ordinal is the running count)"""
+    groups = collections.defaultdict(lambda: collections.defaultdict(list))
+    seen = collections.Counter()
+    for r in rows:
+        name = r[name_key]
+        if anchor in name:
+            seen.clear()
+        if kernel_substr in name:
+            seen[name] += 1
+            groups[name][seen[name]].append(r)
+    return groups
+
+
+def trace_rows(d_kt):
+    fs = sorted(glob.glob(os.path.join(d_kt, "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    if not fs:
+        return []
+    rows = list(csv.DictReader(open(fs[-1])))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return rows
+
+
+def short_name(name):
+    key = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("rlr::", "").split("(")[0]
+    if key.startswith("_Z"):  # a mangled name the tool left as it was: keep the readable middle
+        key = next((w for w in ("prep_queries_kernel", "build_image_kernel", "gemm_resident_kernel") if w in key), key)
+    return key
+
+
 def headline():
     tag, d_kt, d_fetch, d_write, command = sys.argv[1:6]
     kernel = sys.argv[6] if len(sys.argv) > 6 else "scan_"
@@ -87,10 +124,7 @@ def kernels():
         for r in hit:
             entry = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
                      "max_us": float(r["MaxNs"]) / 1e3, "pct_of_gpu_time": float(r["Percentage"])}
-            key = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("rlr::", "").split("(")[0]
-            if key.startswith("_Z"):  # a mangled name the tool left as it was: keep the readable middle
-                key = next((w for w in ("prep_queries_kernel", "build_image_kernel", "gemm_resident_kernel") if w in key), key)
-            out["kernels"][key] = entry
+            out["kernels"][short_name(r["Name"])] = entry
         if pmc_dirs and sub == subs.split(",")[0]:
             # counters of the FIRST kernel of the list only (the dominant one); `max` = its largest launch (a batch
             # launches the same kernel over a small and a large row range: the large one is the one the claims are about)
@@ -103,6 +137,36 @@ def kernels():
                 counters["FETCH_SIZE"]["max_launch_bytes_corrected_x2"] = 2.0 * 1024.0 * counters["FETCH_SIZE"]["max_launch"]
             if counters:
                 out["counters"] = {"kernel": kname, "values": counters}
+            # the same kernel per ordinal inside a batch: durations from the per-dispatch trace, counters from the passes
+            dg = {}
+            for name, by_ord in ordinal_groups(trace_rows(d_kt), sub).items():
+                lst = []
+                for o in sorted(by_ord):
+                    us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in by_ord[o]]
+                    lst.append({"ordinal_in_batch": o, "calls": len(us), "avg_us": sum(us) / len(us), "min_us": min(us), "max_us": max(us)})
+                dg[short_name(name)] = lst
+            if dg:
+                out["dispatch_groups"] = dg
+            cbo = {}
+            for d in pmc_dirs:
+                fs = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+                if not fs:
+                    continue
+                recs = list(csv.DictReader(open(fs[-1])))
+                # one record per (dispatch, counter): walk the dispatches in order, once per counter
+                for cname in sorted({r["Counter_Name"] for r in recs}):
+                    one = sorted((r for r in recs if r["Counter_Name"] == cname), key=lambda r: int(r["Dispatch_Id"]))
+                    for name, by_ord in ordinal_groups(one, sub).items():
+                        for o in sorted(by_ord):
+                            v = [float(r["Counter_Value"]) for r in by_ord[o]]
+                            e = cbo.setdefault(short_name(name), {}).setdefault(str(o), {})
+                            e[cname] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+                            if cname == "FETCH_SIZE":
+                                e[cname]["bytes_corrected_x2"] = 2.0 * 1024.0 * sum(v) / len(v)
+                            if cname == "WRITE_SIZE":
+                                e[cname]["bytes"] = 1024.0 * sum(v) / len(v)
+            if cbo:
+                out["counters_by_ordinal"] = cbo
     with open(os.path.join(HERE, f"{tag}_kernels.json"), "w") as fo:
         json.dump(out, fo, indent=1)
     print(json.dumps(out, indent=1))
