@@ -64,21 +64,36 @@ __device__ inline uint32_t lds_kth_key(const uint64_t *s_c, uint32_t n, uint32_t
 }
 
 // k-th largest full 64-bit key of s_c[0, n) (keys are unique where the caller needs exactly k winners): six radix
-// passes over LDS (11 x 5 + 9 bits), same structure as lds_kth_key.  All threads must call it.
+// passes over LDS (11-bit digits, laid out as described inside), same structure as lds_kth_key.  All threads must call it.
 //
 // `slack`: the passes stop as soon as the bin holding the k-th key has at most `slack` keys ranked BELOW it (bin
 // population - rank inside the bin <= slack); the bin's lower edge is returned then, so between k and k + slack keys are
 // >= the result.  slack = 0 still yields exactly k keys (it stops when the whole bin belongs to the top k -- with unique
 // keys usually after three of the six passes); a threshold that may admit a few more uses a larger slack.
 __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32_t k, uint32_t *s_hist, uint32_t *s_sel,
-                                         uint32_t nthreads, uint32_t slack = 0)
+                                         uint32_t nthreads, uint32_t slack = 0, uint32_t row_bits = 32)
 {
-    uint64_t prefix = 0, mask = 0;
+    // `row_bits`: the low word is 0xFFFFFFFF - row with row < 2^row_bits, so its bits [31, row_bits) are ones in EVERY key: they
+    // belong to the result but need no pass.  The digits are laid out over the 32 score bits (11 + 11 + 10) and then over
+    // the row_bits significant row bits from the top (11 at a time) -- with BM25's massive score ties the select runs deep
+    // into the row bits, and at 100 k rows the fixed 11-bit grid spent a whole pass on constant bits.
+    const uint64_t const_ones = row_bits >= 32 ? 0ull : ((0xFFFFFFFFull >> row_bits) << row_bits);
+    uint64_t prefix = const_ones, mask = const_ones;
     uint32_t rank = k;
+    uint32_t next_hi = 64; // the digit of this pass covers bits [next_hi - bits, next_hi)
 #pragma unroll 1
-    for (int pass = 0; pass < 6; ++pass) {
-        const uint32_t shift = pass < 5 ? 53u - 11u * pass : 0u;
-        const uint32_t nb = pass < 5 ? 2048u : 512u;
+    for (int pass = 0; pass < 7; ++pass) {
+        uint32_t bits;
+        if (next_hi > 32) {
+            bits = next_hi == 42 ? 10u : 11u; // 64..53, 53..42, 42..32
+        } else {
+            if (next_hi == 32)
+                next_hi = row_bits < 32 ? row_bits : 32;
+            if (next_hi == 0)
+                break;
+            bits = next_hi < 11 ? next_hi : 11u;
+        }
+        const uint32_t shift = next_hi - bits, nb = 1u << bits;
         for (uint32_t i = threadIdx.x; i < nb; i += nthreads)
             s_hist[i] = 0;
         __syncthreads();
@@ -89,10 +104,13 @@ __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32
         }
         __syncthreads();
         if (threadIdx.x < 64) {
-            const uint32_t W = nb / 64, lane = threadIdx.x;
+            // lane l owns bins [l * W, (l + 1) * W) (W >= 1: digits narrower than 6 bits leave the upper lanes without bins)
+            const uint32_t W = nb >= 64 ? nb / 64 : 1u, lane = threadIdx.x;
+            const bool owns = lane * W < nb;
             uint32_t mine = 0;
-            for (uint32_t b = 0; b < W; ++b)
-                mine += s_hist[lane * W + b];
+            if (owns)
+                for (uint32_t b = 0; b < W; ++b)
+                    mine += s_hist[lane * W + b];
             uint32_t incl = mine; // sum over lanes >= lane
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -101,7 +119,7 @@ __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32
                     incl += o;
             }
             const uint32_t above = incl - mine;
-            if (above < rank && rank <= incl) {
+            if (owns && above < rank && rank <= incl) {
                 uint32_t acc = above;
                 for (int b = static_cast<int>(W) - 1; b >= 0; --b) {
                     const uint32_t h = s_hist[lane * W + b];
@@ -121,7 +139,8 @@ __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32
         rank = s_sel[1];
         const bool done = s_sel[2] - rank <= slack; // (uniform) everything the bin holds below the k-th key is tolerated
         __syncthreads();
-        if (done)
+        next_hi = shift;
+        if (done || shift == 0)
             break;
     }
     return prefix;

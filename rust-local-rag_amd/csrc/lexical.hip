@@ -146,6 +146,87 @@ __device__ inline void lds_sort_desc(uint64_t *s, uint32_t n_pad)
     }
 }
 
+// All the query's terms in ONE launch (it was one launch per term and segment: ~6 x 5 us of dependent launches and as many
+// host-side launch calls on the critical path of a hybrid search).  The f32 sum order per row must stay the term order
+// (`*scores.entry(doc) += score` in query-term order, :2195-2219), so the ROWS are partitioned instead of the terms: workgroup w
+// owns the rows [w n / G, (w + 1) n / G); every posting list is sorted by row, so the workgroup's share of each list is one
+// contiguous range found by a binary search (all terms and both segments at once, one lane each), and it walks the terms in
+// order with a workgroup barrier in between -- no row is ever touched by two workgroups, no grid-wide synchronisation.
+constexpr int kTermsPerLaunch = 16;
+struct TermBatch {
+    uint32_t n_terms;
+    uint32_t cnt_m[kTermsPerLaunch], cnt_d[kTermsPerLaunch];
+    uint64_t off_m[kTermsPerLaunch], off_d[kTermsPerLaunch];
+    float idf[kTermsPerLaunch];
+};
+
+__device__ inline uint32_t lower_bound_rows(const uint32_t *__restrict__ rows, uint32_t cnt, uint32_t key)
+{
+    uint32_t lo = 0, hi = cnt; // first index with rows[i] >= key
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rows[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void bm25_terms_kernel(TermBatch tb, const uint32_t *__restrict__ post_row,
+                                                         const uint32_t *__restrict__ post_tf, const uint32_t *__restrict__ dpost_row,
+                                                         const uint32_t *__restrict__ dpost_tf, const uint32_t *__restrict__ doc_len,
+                                                         uint32_t n_rows, float avg, float *__restrict__ scores,
+                                                         uint32_t *__restrict__ touched, LexControl *__restrict__ ctl)
+{
+    __shared__ uint32_t s_range[kTermsPerLaunch][4]; // [term][main lo, main hi, appended lo, appended hi]
+    const uint32_t r0 = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * n_rows / gridDim.x);
+    const uint32_t r1 = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * n_rows / gridDim.x);
+    if (threadIdx.x < 4 * kTermsPerLaunch) {
+        const uint32_t t = threadIdx.x >> 2, which = threadIdx.x & 3;
+        uint32_t v = 0;
+        if (t < tb.n_terms) {
+            const bool delta = which >= 2;
+            const uint32_t cnt = delta ? tb.cnt_d[t] : tb.cnt_m[t];
+            if (cnt)
+                v = lower_bound_rows((delta ? dpost_row + tb.off_d[t] : post_row + tb.off_m[t]), cnt, (which & 1) ? r1 : r0);
+        }
+        s_range[t][which] = v;
+    }
+    __syncthreads();
+    for (uint32_t t = 0; t < tb.n_terms; ++t) {
+        const float idf = tb.idf[t];
+#pragma unroll
+        for (int seg = 0; seg < 2; ++seg) { // a row lives in exactly one segment: no barrier between the two
+            const uint32_t lo = s_range[t][2 * seg], hi = s_range[t][2 * seg + 1];
+            const uint32_t *rows = seg ? dpost_row + tb.off_d[t] : post_row + tb.off_m[t];
+            const uint32_t *tfs = seg ? dpost_tf + tb.off_d[t] : post_tf + tb.off_m[t];
+            for (uint32_t i0 = lo; i0 < hi; i0 += 256) { // (uniform bounds: every wave runs the same trips)
+                const uint32_t i = i0 + threadIdx.x;
+                bool first_touch = false;
+                uint32_t row = 0;
+                if (i < hi) {
+                    row = rows[i];
+                    const float dl = static_cast<float>(doc_len[row]);
+                    const float tf = static_cast<float>(tfs[i]);
+                    const float denom = tf + kK1 * ((1.0f - kB) + kB * (dl / avg));
+                    if (dl != 0.0f && denom != 0.0f) {
+                        const float sc = idf * (tf * (kK1 + 1.0f)) / denom;
+                        const float old = scores[row];
+                        const float now = old + sc; // `*scores.entry(doc).or_insert(0.0) += score`
+                        scores[row] = now;
+                        first_touch = old == 0.0f && now > 0.0f;
+                    }
+                }
+                const uint32_t slot = wave_append_slot(first_touch, &ctl->n_touched);
+                if (first_touch)
+                    touched[slot] = row;
+            }
+        }
+        __syncthreads(); // the next term adds to the sums this one wrote (other threads' rows included)
+    }
+}
+
 // `results.sort_by(score desc)` + `truncate(limit)` (:2218-2222) when everything fits one workgroup
 template <bool FROM_TOUCHED>
 __global__ __launch_bounds__(1024) void lex_sort_kernel(const float *__restrict__ scores,
@@ -286,7 +367,8 @@ constexpr uint32_t kLexRetry = 0xFFFFFFFFu;
 constexpr uint32_t kSampleMax = 8192, kFastLimitMax = 4096;
 
 __global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restrict__ scores, const uint32_t *__restrict__ touched,
-                                                          LexControl *__restrict__ ctl, uint32_t limit, uint32_t r_forced)
+                                                          LexControl *__restrict__ ctl, uint32_t limit, uint32_t r_forced,
+                                                          uint32_t row_bits)
 {
     __shared__ uint64_t s_k[kSampleMax];
     __shared__ uint32_t s_hist[2048];
@@ -321,7 +403,7 @@ __global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restric
     __syncthreads();
     const float mu = static_cast<float>(limit) * static_cast<float>(s) / static_cast<float>(n);
     const uint32_t r = r_forced ? min(s, r_forced) : min(s, static_cast<uint32_t>(mu + 4.5f * sqrtf(mu)) + 8u);
-    const uint64_t thr = lds_kth_key64(s_k, s, r, s_hist, s_pick, 1024, /*slack=*/8); // a few sample keys more: harmless
+    const uint64_t thr = lds_kth_key64(s_k, s, r, s_hist, s_pick, 1024, /*slack=*/8, row_bits); // a few sample keys more: harmless
     if (threadIdx.x == 0)
         ctl->thr = thr;
 }
@@ -350,7 +432,7 @@ __global__ __launch_bounds__(256) void lex_filter_kernel(const float *__restrict
 template <bool SORTED>
 __global__ __launch_bounds__(1024) void lex_final_kernel(const uint64_t *__restrict__ cand, const LexControl *__restrict__ ctl,
                                                          uint32_t limit, uint64_t *__restrict__ out_keys,
-                                                         uint32_t *__restrict__ out_n)
+                                                         uint32_t *__restrict__ out_n, uint32_t row_bits)
 {
     __shared__ uint64_t s[kMaxLimit];
     __shared__ uint64_t s_win[SORTED ? kFastLimitMax : 1]; // the winners, to be sorted (the unordered form writes them out directly)
@@ -370,7 +452,7 @@ __global__ __launch_bounds__(1024) void lex_final_kernel(const uint64_t *__restr
     __syncthreads();
     uint64_t kth = 0;
     if (m > want)
-        kth = lds_kth_key64(s, m, want, s_hist, s_pick, 1024); // keys are unique: exactly `want` of them are >= kth
+        kth = lds_kth_key64(s, m, want, s_hist, s_pick, 1024, 0, row_bits); // keys are unique: exactly `want` of them are >= kth
     for (uint32_t i = threadIdx.x; i < m; i += 1024) {
         const uint64_t v = s[i];
         if (v >= kth) {
@@ -1244,19 +1326,42 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     // for a consumer on another stream until the workspace is handed back
     LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), s));
     const uint32_t max_blocks = static_cast<uint32_t>(lx->n_cu) * 8;
+    static const bool per_term = getenv("RLR_LEX_PER_TERM") != nullptr; // (A/B switch: one launch per term and segment)
+    // workgroups of the row-partitioned kernel: one per CU while each still owns a few hundred rows
+    const uint32_t row_wgs = std::max<uint32_t>(1u, std::min<uint32_t>(static_cast<uint32_t>(lx->n_cu), static_cast<uint32_t>(n_rows / 256)));
+    TermBatch tb;
+    tb.n_terms = 0;
+    auto flush_terms = [&]() {
+        if (tb.n_terms)
+            hipLaunchKernelGGL(bm25_terms_kernel, dim3(row_wgs), dim3(256), 0, s, tb, lx->d_post_row, lx->d_post_tf, lx->d_dpost_row,
+                               lx->d_dpost_tf, lx->d_doc_len, static_cast<uint32_t>(n_rows), avg, ws->d_scores, ws->d_touched,
+                               ws->d_ctl);
+        tb.n_terms = 0;
+    };
     for (uint32_t t : terms) {
         const float df = static_cast<float>(lx->df[t]);
         float idf = std::log((n_docs - df + 0.5f) / (df + 0.5f)); // f32 ln (:2198-2200)
         idf = idf > 0.0f ? idf : 0.0f;                            // f32::max(0.0): NaN -> 0
         // the term's postings in the main segment, then in the appended one (a row is in exactly one of them)
         const uint32_t cnt_m = t < lx->main_df.size() ? lx->main_df[t] : 0u;
+        const uint32_t cnt_d = lx->dterm_off.empty() ? 0u : static_cast<uint32_t>(lx->dterm_off[t + 1] - lx->dterm_off[t]);
+        if (!per_term) {
+            const uint32_t at = tb.n_terms++;
+            tb.cnt_m[at] = cnt_m;
+            tb.off_m[at] = cnt_m ? lx->term_off[t] : 0;
+            tb.cnt_d[at] = cnt_d;
+            tb.off_d[at] = cnt_d ? lx->dterm_off[t] : 0;
+            tb.idf[at] = idf;
+            if (tb.n_terms == kTermsPerLaunch)
+                flush_terms(); // (more than 16 terms: the next launch continues in term order)
+            continue;
+        }
         if (cnt_m) {
             const uint64_t off = lx->term_off[t];
             const uint32_t blocks = std::min<uint32_t>((cnt_m + 255) / 256, max_blocks);
             hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_post_row + off, lx->d_post_tf + off, cnt_m,
                                lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
         }
-        const uint32_t cnt_d = lx->dterm_off.empty() ? 0u : static_cast<uint32_t>(lx->dterm_off[t + 1] - lx->dterm_off[t]);
         if (cnt_d) {
             const uint64_t off = lx->dterm_off[t];
             const uint32_t blocks = std::min<uint32_t>((cnt_d + 255) / 256, max_blocks);
@@ -1264,6 +1369,7 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
                                cnt_d, lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
         }
     }
+    flush_terms();
     LEX_HIP(hipGetLastError());
     uint32_t *d_out_n = reinterpret_cast<uint32_t *>(ws->d_out + kMaxLimit);
     const uint32_t blocks_u = std::min<uint32_t>(static_cast<uint32_t>((upper + 255) / 256), max_blocks);
@@ -1281,13 +1387,16 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
         // says kLexRetry when that list overflowed or came out short
         // RLR_LEX_SAMPLE_RANK (a test switch): the sample rank to use instead of mu + 4.5 sqrt(mu) + 8 -- 1 makes the
         // threshold the largest sample key, the candidate list short, and every such query take the retry
+        uint32_t row_bits = 0; // rows < 2^row_bits: the digits of the LDS radix selects skip the constant bits above
+        while (row_bits < 32 && (n_rows - 1) >> row_bits)
+            ++row_bits;
         static const uint32_t r_forced = getenv("RLR_LEX_SAMPLE_RANK") ? static_cast<uint32_t>(atoi(getenv("RLR_LEX_SAMPLE_RANK"))) : 0u;
-        hipLaunchKernelGGL(lex_sample_kernel, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl, lim, r_forced);
+        hipLaunchKernelGGL(lex_sample_kernel, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl, lim, r_forced, row_bits);
         hipLaunchKernelGGL(lex_filter_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl, ws->d_sel);
         if (need_sorted)
-            hipLaunchKernelGGL(lex_final_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_sel, ws->d_ctl, lim, ws->d_out, d_out_n);
+            hipLaunchKernelGGL(lex_final_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_sel, ws->d_ctl, lim, ws->d_out, d_out_n, row_bits);
         else
-            hipLaunchKernelGGL(lex_final_kernel<false>, dim3(1), dim3(1024), 0, s, ws->d_sel, ws->d_ctl, lim, ws->d_out, d_out_n);
+            hipLaunchKernelGGL(lex_final_kernel<false>, dim3(1), dim3(1024), 0, s, ws->d_sel, ws->d_ctl, lim, ws->d_out, d_out_n, row_bits);
         out->may_retry = true;
     } else {
         LEX_TRY(dev_grow(&ws->d_keys, &ws->keys_cap, upper));
