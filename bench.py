@@ -59,6 +59,10 @@ def parse():
                     help="single queries nominate over the binary16 image too (half the scan bytes; same results)")
     ap.add_argument("--q8-scan", action="store_true",
                     help="single queries nominate over the 8-bit copy (a quarter of the scan bytes; same results)")
+    ap.add_argument("--in-process", action="store_true",
+                    help="ONE process driving --gpus N devices through rlr_multi (persistent shard workers, ncclAllGather of the "
+                         "partial top-k lists + merge kernel behind the C ABI) instead of one rank per GPU over torch.distributed: "
+                         "the form a single-process Rust server uses (INTEGRATION.md section 5)")
     ap.add_argument("--batch", type=int, default=1,
                     help="queries per step; >= 16 takes the matrix-core (MFMA) batched path (BASELINE config 3 uses 256)")
     return ap.parse_args()
@@ -419,9 +423,53 @@ def config_c5_share(rlr, torch):
             "timed_passes": reps, "fallback_queries": p.n_batch_fallbacks, "roofline": batched_roofline(p, dim, nq, True)}
 
 
+def in_process(args):
+    """headline workload, rows sharded over args.gpus devices of THIS process (rlr_multi, RCCL exchange)"""
+    import gc
+
+    rlr = importlib.import_module("rust-local-rag_amd")
+    if rlr.device_count() < args.gpus:
+        raise SystemExit(f"--in-process --gpus {args.gpus}: only {rlr.device_count()} device(s) visible")
+    qs = queries_without_oracle(rlr, args.dim, args.warmup + args.steps, args.seed)
+    mi = rlr.MultiGpuIndex(args.dim, list(range(args.gpus)), args.dtype)
+    t0 = time.perf_counter()
+    mi.fill_synthetic(args.rows, args.seed)
+    fill_s = time.perf_counter() - t0
+    mi.set_exchange("rccl")
+    gc.collect()
+    gc.freeze()
+    t_settle = time.perf_counter()
+    while args.settle_ms > 0 and (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        mi.search_topk(qs[0], args.k)
+    for i in range(args.warmup):
+        mi.search_topk(qs[i], args.k)
+    mi.stats(reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = mi.search_topk(qs[args.warmup + i], args.k)   # returns after the merged result is in host memory
+    elapsed = time.perf_counter() - t0
+    st = mi.stats()
+    elem = 2 if args.dtype == "f16" else 4
+    print(json.dumps({
+        "metric": "queries/sec + achieved HBM GB/s, 768-d cosine top-100 over 10M chunks",
+        "value": args.steps / elapsed, "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.rows} chunks x {args.dim}-d {args.dtype}, 1 query per step, top_k={args.k}",
+                   "parallelism": f"one process, rlr_multi over {args.gpus} device(s), ncclAllGather + merge kernel behind the C ABI"},
+        "aggregate_hbm_GBps": args.rows * args.dim * elem / (elapsed / args.steps) / 1e9,
+        "exchange": {"rccl_calls": st["n_topk_rccl"], "host_merge_calls": st["n_topk_host_merge"],
+                     "rccl_fell_back": st["n_topk_rccl_fell_back"],
+                     "rccl_call_ms": st["topk_rccl_ms"] / max(st["n_topk_rccl"], 1)},
+        "fill_s": fill_s, "top1_row": int(last[0][0][0]) if last[0].size else None}))
+    mi.close()
+
+
 def main():
     args = parse()
     ensure_built()
+    if args.in_process:
+        return in_process(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

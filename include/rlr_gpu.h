@@ -295,6 +295,8 @@ int32_t rlr_multi_set_exchange(rlr_multi *m, int32_t mode);
 /* replace all rows (host memory, n_rows x dim f32), sharded by contiguous ranges */
 int32_t rlr_multi_upload(rlr_multi *m, const float *rows, uint64_t n_rows, int32_t normalize_on_device);
 int32_t rlr_multi_fill_synthetic(rlr_multi *m, uint64_t n_rows, uint64_t seed, uint32_t n_clusters);
+/* rlr_index_enable_batch_image on every shard (the optional nomination copies: same flags, same guarantees) */
+int32_t rlr_multi_enable_batch_image(rlr_multi *m, int32_t enable);
 /* same contract as rlr_search_topk, row numbers are global */
 int32_t rlr_multi_search_topk(rlr_multi *m, const float *queries, uint32_t n_queries, uint32_t k,
                               float guard_eps, uint64_t *rows_out, float *cos_out, uint32_t *n_out);

@@ -118,6 +118,7 @@ PROTOTYPES = [
     ("rlr_multi_set_exchange", C.c_int32, [_H, C.c_int32]),
     ("rlr_multi_upload", C.c_int32, [_H, f32p, C.c_uint64, C.c_int32]),
     ("rlr_multi_fill_synthetic", C.c_int32, [_H, C.c_uint64, C.c_uint64, C.c_uint32]),
+    ("rlr_multi_enable_batch_image", C.c_int32, [_H, C.c_int32]),
     ("rlr_multi_search_topk", C.c_int32, [_H, f32p, C.c_uint32, C.c_uint32, C.c_float, u64p, f32p, u32p]),
     ("rlr_multi_score_rows", C.c_int32, [_H, f32p, u64p, C.c_uint32, f32p]),
     ("rlr_multi_fetch_rows", C.c_int32, [_H, u64p, C.c_uint32, f32p]),

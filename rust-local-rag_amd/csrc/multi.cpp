@@ -718,6 +718,13 @@ int32_t rlr_multi_fill_synthetic(rlr_multi *m, uint64_t n_rows, uint64_t seed, u
     });
 }
 
+int32_t rlr_multi_enable_batch_image(rlr_multi *m, int32_t enable)
+{
+    if (!m)
+        return RLR_E_INVALID;
+    return for_each_shard(m, [&](uint32_t g) { return rlr_index_enable_batch_image(m->shard[g], enable); });
+}
+
 int32_t rlr_multi_search_topk(rlr_multi *m, const float *queries, uint32_t n_queries, uint32_t k, float guard_eps,
                               uint64_t *rows_out, float *cos_out, uint32_t *n_out)
 {

@@ -11,6 +11,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace rlr {
 
@@ -314,6 +315,131 @@ __global__ __launch_bounds__(kSelThreads) void collect_find2_kernel(const float 
     }
 }
 
+// ---- batched select, fused: one workgroup per query ------------------------------------------------------------------
+// hist1 -> find1 -> hist2 -> find2 -> collect were five launches (three of them a pass of every workgroup over every query's
+// sample scores with global-memory histograms and candidate counters).  A sample is 65 k - 150 k scores per query, 0.3 - 0.6 MB:
+// one workgroup of 1024 threads reads it three times out of L2 with its histograms and its candidate counter in LDS and
+// leaves exactly what the five kernels left -- SelectState (bin1, k2, bin2, key_lo, n_cand), tau, and the candidates at or
+// above the floor as packed (score, row) words.
+__global__ __launch_bounds__(1024) void batch_select_fused_kernel(const float *__restrict__ scores, uint32_t n, size_t score_stride,
+                                                                  SelectState *__restrict__ st, float two_eps,
+                                                                  float *__restrict__ tau_out, uint64_t *__restrict__ cand,
+                                                                  uint32_t cand_stride)
+{
+    __shared__ uint32_t s_hist[kHistBins];
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_res[2];
+    __shared__ uint32_t s_count;
+    scores += blockIdx.x * score_stride;
+    cand += static_cast<size_t>(blockIdx.x) * cand_stride;
+    st += blockIdx.x;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t n4 = n / 4;
+    const float4 *s4 = reinterpret_cast<const float4 *>(scores);
+    // rank-th largest key's bin in s_hist (2048 bins, two per thread), from the top: wave suffix scan + the 16 wave totals
+    auto find_bin = [&](uint32_t rank, uint32_t *bin_out, uint32_t *rank_in_bin) {
+        const uint32_t lo = s_hist[2 * t], hi = s_hist[2 * t + 1];
+        const uint32_t sum = lo + hi;
+        uint32_t suf = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_down(suf, off);
+            if (lane + off < 64)
+                suf += v;
+        }
+        if (lane == 0)
+            s_wave[wave] = suf;
+        if (t == 0) {
+            s_res[0] = 0;
+            s_res[1] = 1;
+        }
+        __syncthreads();
+        uint32_t above = suf - sum; // keys in bins above this thread's two
+        for (uint32_t w = wave + 1; w < 16; ++w)
+            above += s_wave[w];
+        if (above < rank && rank <= above + hi) {
+            s_res[0] = 2 * t + 1;
+            s_res[1] = rank - above;
+        } else if (above + hi < rank && rank <= above + hi + lo) {
+            s_res[0] = 2 * t;
+            s_res[1] = rank - above - hi;
+        }
+        __syncthreads();
+        *bin_out = s_res[0];
+        *rank_in_bin = s_res[1];
+        __syncthreads();
+    };
+    // digit 1
+    s_hist[2 * t] = 0;
+    s_hist[2 * t + 1] = 0;
+    if (t == 0)
+        s_count = 0;
+    __syncthreads();
+    for (uint32_t i = t; i < n4; i += 1024) {
+        const float4 v = s4[i];
+        atomicAdd(&s_hist[score_key(v.x) >> 21], 1u);
+        atomicAdd(&s_hist[score_key(v.y) >> 21], 1u);
+        atomicAdd(&s_hist[score_key(v.z) >> 21], 1u);
+        atomicAdd(&s_hist[score_key(v.w) >> 21], 1u);
+    }
+    for (uint32_t i = n4 * 4 + t; i < n; i += 1024)
+        atomicAdd(&s_hist[score_key(scores[i]) >> 21], 1u);
+    __syncthreads();
+    uint32_t bin1, k2;
+    find_bin(st->k, &bin1, &k2);
+    // digit 2 of the scores inside bin1
+    s_hist[2 * t] = 0;
+    s_hist[2 * t + 1] = 0;
+    __syncthreads();
+    for (uint32_t i = t; i < n4; i += 1024) {
+        const float4 v = s4[i];
+        const uint32_t k0 = score_key(v.x), k1 = score_key(v.y), k2_ = score_key(v.z), k3 = score_key(v.w);
+        if ((k0 >> 21) == bin1) atomicAdd(&s_hist[(k0 >> 10) & (kHistBins - 1)], 1u);
+        if ((k1 >> 21) == bin1) atomicAdd(&s_hist[(k1 >> 10) & (kHistBins - 1)], 1u);
+        if ((k2_ >> 21) == bin1) atomicAdd(&s_hist[(k2_ >> 10) & (kHistBins - 1)], 1u);
+        if ((k3 >> 21) == bin1) atomicAdd(&s_hist[(k3 >> 10) & (kHistBins - 1)], 1u);
+    }
+    for (uint32_t i = n4 * 4 + t; i < n; i += 1024) {
+        const uint32_t k0 = score_key(scores[i]);
+        if ((k0 >> 21) == bin1) atomicAdd(&s_hist[(k0 >> 10) & (kHistBins - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t bin2, rk;
+    find_bin(k2, &bin2, &rk);
+    const uint32_t key_lo = band_floor_key(bin1, bin2, two_eps);
+    // collect: everything at or above the floor
+    const uint32_t cap = st->cap;
+    for (uint32_t i = t; i < n4; i += 1024) {
+        const float4 v = s4[i];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (score_key(e[j]) >= key_lo) {
+                const uint32_t slot = atomicAdd(&s_count, 1u);
+                if (slot < cap)
+                    cand[slot] = pack_result(e[j], i * 4 + j);
+            }
+    }
+    for (uint32_t i = n4 * 4 + t; i < n; i += 1024) {
+        const float v = scores[i];
+        if (score_key(v) >= key_lo) {
+            const uint32_t slot = atomicAdd(&s_count, 1u);
+            if (slot < cap)
+                cand[slot] = pack_result(v, i);
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        st->bin1 = bin1;
+        st->k2 = k2;
+        st->bin2 = bin2;
+        st->key_lo = key_lo;
+        st->n_cand = s_count;
+        if (tau_out)
+            tau_out[blockIdx.x] = key_lo == 0 ? -__builtin_inff() : key_score(key_lo);
+    }
+}
+
 // ---- descending sort of packed u64 ------------------------------------------------
 constexpr int kSortLds = 4096; // entries sorted inside one workgroup's LDS (32 KB)
 
@@ -378,6 +504,14 @@ hipError_t launch_batch_select(const float *scores, uint32_t n, size_t score_str
                                float two_eps, float *tau_out, uint64_t *cand, uint32_t cand_stride, int n_cu,
                                hipStream_t s)
 {
+    // one workgroup per query while the queries alone fill the chip and a sample stays L2-sized: three passes over its own
+    // 4 n bytes with every counter in LDS (RLR_BATCH_SELECT_SPLIT=1: the five-launch form)
+    static const bool split = getenv("RLR_BATCH_SELECT_SPLIT") != nullptr;
+    if (!split && q_count >= 64 && n <= (1u << 20) && (score_stride % 4) == 0) {
+        hipLaunchKernelGGL(batch_select_fused_kernel, dim3(q_count), dim3(1024), 0, s, scores, n, score_stride, st, two_eps, tau_out,
+                           cand, cand_stride);
+        return hipGetLastError();
+    }
     uint32_t bx = (n / 4 + kSelThreads - 1) / kSelThreads;
     const uint32_t bx_cap = std::max<uint32_t>(1u, static_cast<uint32_t>(n_cu) * 8 / std::max(q_count, 1u));
     bx = std::max(1u, std::min(bx, bx_cap));

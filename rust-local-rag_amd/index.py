@@ -253,6 +253,10 @@ class MultiGpuIndex:
     def fill_synthetic(self, n_rows: int, seed: int, n_clusters: int = 0) -> None:
         N.check(self._L.rlr_multi_fill_synthetic(self._h, n_rows, seed, n_clusters))
 
+    def enable_batch_image(self, flags: int = 1) -> None:
+        """rlr_index_enable_batch_image on every shard (1: binary16 image for batches, 3: + single queries, 4: 8-bit copy)"""
+        N.check(self._L.rlr_multi_enable_batch_image(self._h, flags))
+
     def set_exchange(self, mode: str) -> None:
         """"host": per-shard lists merged on the host (default); "rccl": ncclAllGather of the packed partial top-k
         lists + merge kernel on the first device (one shard per device; librccl loaded on first use)"""

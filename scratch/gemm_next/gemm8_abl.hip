@@ -28,6 +28,7 @@ constexpr int F_NODMA = 16;    // timing only: no DMA in the loop
 constexpr int F_SCHED = 32;    // sched_barrier(0) around the MFMA cluster
 constexpr int F_NOLDS = 64;    // timing only: no ds_read in the loop (operands read once)
 constexpr int F_NOMFMA = 128;  // timing only: no MFMA (the ds_reads are kept alive)
+constexpr int F_ASM_ACC = 512; // 4-wave kernel: the 64 accumulator tiles pinned to AGPRs (inline-asm MFMAs with "a" constraints)
 constexpr int F_PRIO_HI = 256; // static s_setprio 1 for waves 4-7, no per-cluster flips
 
 template <int ABL>
@@ -444,8 +445,12 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(const char *__restrict__ A,
         fb[BUF][i] = L[(SL) * 2048 + (2 + wn) * 512 + i * 64 + lane];                     \
     }
 #define W4_COMPUTE(BUF)                                                                   \
-    _Pragma("unroll") for (int rb = 0; rb < 8; ++rb) _Pragma("unroll") for (int cb = 0; cb < 8; ++cb) \
-        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[BUF][rb], fb[BUF][cb], acc[rb][cb], 0, 0, 0);
+    _Pragma("unroll") for (int rb = 0; rb < 8; ++rb) _Pragma("unroll") for (int cb = 0; cb < 8; ++cb) { \
+        if constexpr ((ABL & F_ASM_ACC) != 0)                                             \
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[rb][cb]) : "v"(fa[BUF][rb]), "v"(fb[BUF][cb])); \
+        else                                                                              \
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[BUF][rb], fb[BUF][cb], acc[rb][cb], 0, 0, 0); \
+    }
 
     // prologue: k-steps 0..3 in flight; k-step 0 landed, its fragments in register set 0
     stage(); stage(); stage(); stage();
@@ -608,6 +613,8 @@ int main(int argc, char **argv)
         {"4w", run_4w<0>},
         {"4w+ntA", run_4w<F_NT_A>},
         {"4w+sched", run_4w<F_SCHED>},
+        {"4w+asmacc", run_4w<F_ASM_ACC>},
+        {"4w+asmacc+nt", run_4w<F_ASM_ACC | F_NT_A>},
     };
     const int nv = sizeof(vs) / sizeof(vs[0]);
     for (int rep = 0; rep < 5; ++rep) {

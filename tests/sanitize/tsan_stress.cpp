@@ -143,6 +143,44 @@ int main(int argc, char **argv)
         CHECK(rlr_lexical_remove_rows(lx, drop.data(), static_cast<uint32_t>(drop.size())));
         n_rows -= drop.size();
     }
+    // the sharded corpus: four shards on the one (stub) device, persistent shard workers, more callers than exchange
+    // workspaces; the cross-shard MMR's gather / device-to-device copies / staged MMR run from several host threads at once
+    {
+        rlr_multi *m = nullptr;
+        const int32_t devs[4] = {0, 0, 0, 0};
+        CHECK(rlr_multi_create(dim, RLR_F32, 4, devs, &m));
+        CHECK(rlr_multi_upload(m, rows.data(), 6000, 1));
+        std::vector<std::thread> ts;
+        for (int t = 0; t < 8; ++t)
+            ts.emplace_back([&, t] {
+                uint64_t s = 99 + t;
+                std::vector<float> q(dim);
+                std::vector<rlr_search_hit> hits(400);
+                std::vector<uint64_t> prow(4 * 32);
+                std::vector<float> psc(4 * 32), mmr(4 * 32);
+                std::vector<uint32_t> order(4 * 32), nsel(4), sizes(4, 32);
+                for (int it = 0; it < iters / 2; ++it) {
+                    for (auto &v : q)
+                        v = static_cast<float>(static_cast<int64_t>(next(&s) % 2001) - 1000) / 1000.0f;
+                    uint32_t n = 0;
+                    if ((t + it) % 2) {
+                        // (kernels do nothing on the stub, so the rows a search returns are not valid pool rows: the engine call may
+                        // refuse them -- what is under test is the shard workers and the merge, not the answer)
+                        (void)rlr_multi_engine_search_with_diversity(m, q.data(), dim, 10, 0.5f, nullptr, nullptr, nullptr, 0, hits.data(), 400, &n);
+                    } else {
+                        for (size_t i = 0; i < prow.size(); ++i) {
+                            prow[i] = next(&s) % 6000;
+                            psc[i] = 1.0f - 0.01f * static_cast<float>(i % 32);
+                        }
+                        CHECK(rlr_multi_mmr_select_batch(m, prow.data(), psc.data(), sizes.data(), 4, 32, 8, 0.4f, order.data(), mmr.data(), nsel.data()));
+                    }
+                }
+            });
+        for (auto &t : ts)
+            t.join();
+        printf("multi engine, 8 threads done\n");
+        CHECK(rlr_multi_destroy(m));
+    }
     rlr_lexical_destroy(lx);
     CHECK(rlr_index_destroy(ix));
     if (g_fail.load()) {

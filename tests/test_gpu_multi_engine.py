@@ -84,6 +84,8 @@ def test_multi_engine_batch_with_cross_shard_mmr(rlr, oracle, dtype, devices):
     mi.upload(rows)
     qs = np.stack([oracle.synth_query(dim, seed=3400 + i) for i in range(nq)])
     qs[0] = rows[3]
+    if dtype == "f16":
+        mi.enable_batch_image(1)           # the shards' batched searches nominate over their binary16 images
     for k, lam in ((10, 0.7), (100, 0.3), (5, 0.0)):
         got = mi.engine_search_with_diversity_batch(qs, k, lam)
         assert len(got) == nq
