@@ -1094,21 +1094,24 @@ hipError_t launch_compact_rows(const void *src, void *dst, uint32_t pitch16, con
 // time, next piece in flight behind the current 8 instructions; all tiles of a pool run on one XCD (its rows stay in that L2).
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float v32f __attribute__((ext_vector_type(32)));
-constexpr int kGmK = 64;               // binary16 elements per staged K chunk
-constexpr int kGmPitch = kGmK * 2 + 16; // bytes per staged row: 16-byte reads of consecutive rows land in different slots
 
 // Workgroup = ONE wave = the two tiles (2p, J) and (2p + 1, J), J >= 2p: lanes 0-31 carry the first, lanes 32-63 the second.
-// Its 64 + 32 rows are staged through a wave-private LDS block per 64-wide K chunk with coalesced loads (8 lanes per 128-byte
-// row piece); the next chunk waits in registers behind the current chunk's 64 matrix instructions.  No barrier anywhere: with
+// Its 64 + 32 rows are staged through a wave-private LDS block per K chunk with coalesced loads (consecutive lanes cover a row's
+// piece); the next chunk waits in registers behind the current chunk's matrix instructions.  No barrier anywhere: with
 // four-wave workgroups sharing their staged rows the waves of the two resident workgroups ran in lock step from barrier to
 // barrier and ragged workgroups left SIMDs idle (57 % matrix-pipe occupancy, 1.58 ms per 1024 pools of 300 x 1024-d); and a lane
 // streaming its own row straight from global memory makes 64 cache-line requests per instruction (4.3 ms, worse than the VALU
 // kernel's 3.3).  The row pair's one tile below the diagonal is computed twice, everything else once; all waves of a pool run
 // on one XCD (its rows come from HBM once).
+// UPR = 16-byte units per row and chunk: the K chunk is 8 UPR binary16 elements (UPR = 4: 7.7 KB of LDS per wave, five waves per SIMD
+// fit; UPR = 8: 13.8 KB, 2.75 per SIMD -- RLR_GRAM_CHUNK=64 selects it for A/B runs).
+template <int UPR>
 __global__ __launch_bounds__(64) void gram_mfma_f32_kernel(const unsigned char *__restrict__ rows, uint32_t pitch_bytes,
                                                            const uint32_t *__restrict__ list, uint32_t P, uint32_t n_pools,
                                                            uint32_t jobs_per_pool, float *__restrict__ gram)
 {
+    constexpr int kGmPitch = UPR * 16 + 16; // bytes per staged row: 16-byte reads of consecutive rows land in different slots
+    constexpr int kPer = 96 * UPR / 64;     // 16-byte units per lane and chunk
     __shared__ __attribute__((aligned(16))) unsigned char s_rows[96 * kGmPitch]; // rows 0..63: A (2p, 2p + 1), 64..95: B (J)
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint32_t pool = (slot / jobs_per_pool) * 8 + xcd;
@@ -1124,23 +1127,23 @@ __global__ __launch_bounds__(64) void gram_mfma_f32_kernel(const unsigned char *
     list += static_cast<size_t>(pool) * P;
     gram += static_cast<size_t>(pool) * P * P;
     const uint32_t lane = threadIdx.x;
-    // twelve 16-byte units per lane and chunk: units 0..511 = A (64 rows x 8 segments), 512..767 = B (32 rows x 8)
-    const unsigned char *src[12];
+    // kPer 16-byte units per lane and chunk: unit u = staged row u / UPR (0..63: A, 64..95: B), segment u % UPR
+    const unsigned char *src[kPer];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const uint32_t u = lane + 64 * i, rr = u >> 3, seg = u & 7; // rr = staged row 0..95
+    for (int i = 0; i < kPer; ++i) {
+        const uint32_t u = lane + 64 * i, rr = u / UPR, seg = u % UPR; // rr = staged row 0..95
         const uint32_t row = min(rr < 64 ? I0 * 32 + rr : J * 32 + (rr - 64), P - 1);
         src[i] = rows + static_cast<size_t>(list[row]) * pitch_bytes + seg * 16;
     }
-    const uint32_t seg = lane & 7;
+    const uint32_t seg = lane % UPR;
     const uint32_t row_units = pitch_bytes / 16; // a row's last chunk may be short: units beyond the pitch read as zero
-    const uint32_t n_chunks = (row_units + 7) / 8;
-    uint4 pre[12];
+    const uint32_t n_chunks = (row_units + UPR - 1) / UPR;
+    uint4 pre[kPer];
     auto fetch = [&](uint32_t c) {
-        const bool in = c * 8 + seg < row_units;
+        const bool in = c * UPR + seg < row_units;
 #pragma unroll
-        for (int i = 0; i < 12; ++i)
-            pre[i] = in ? *reinterpret_cast<const uint4 *>(src[i] + static_cast<size_t>(c) * (kGmK * 2)) : make_uint4(0u, 0u, 0u, 0u);
+        for (int i = 0; i < kPer; ++i)
+            pre[i] = in ? *reinterpret_cast<const uint4 *>(src[i] + static_cast<size_t>(c) * (UPR * 16)) : make_uint4(0u, 0u, 0u, 0u);
     };
     v32f acc;
 #pragma unroll
@@ -1151,13 +1154,13 @@ __global__ __launch_bounds__(64) void gram_mfma_f32_kernel(const unsigned char *
     fetch(0);
     for (uint32_t c = 0; c < n_chunks; ++c) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i)
-            *reinterpret_cast<uint4 *>(s_rows + ((lane + 64 * i) >> 3) * kGmPitch + seg * 16) = pre[i];
+        for (int i = 0; i < kPer; ++i)
+            *reinterpret_cast<uint4 *>(s_rows + ((lane + 64 * i) / UPR) * kGmPitch + seg * 16) = pre[i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the block is private to this wave: LDS is in order, no barrier
         if (c + 1 < n_chunks)
             fetch(c + 1);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UPR; ++u) {
             const uint4 ca = *reinterpret_cast<const uint4 *>(la + u * 16), cb = *reinterpret_cast<const uint4 *>(lb + u * 16);
             const uint32_t wa[4] = {ca.x, ca.y, ca.z, ca.w}, wb[4] = {cb.x, cb.y, cb.z, cb.w};
 #pragma unroll
@@ -1233,8 +1236,13 @@ hipError_t launch_gram_rows(const void *rows, uint32_t pitch16, uint32_t dim, in
             for (uint32_t pr = 0; 2 * pr < nb; ++pr)
                 jobs_per_pool += nb - 2 * pr;
             const uint32_t pools8 = (n_queries + 7) / 8 * 8;
-            hipLaunchKernelGGL(gram_mfma_f32_kernel, dim3(pools8 * jobs_per_pool), dim3(64), 0, s, static_cast<const unsigned char *>(rows),
-                               pitch16 * 16u, list, P, n_queries, jobs_per_pool, gram);
+            static const bool wide_chunk = getenv("RLR_GRAM_CHUNK") && atoi(getenv("RLR_GRAM_CHUNK")) == 64;
+            if (wide_chunk)
+                hipLaunchKernelGGL(gram_mfma_f32_kernel<8>, dim3(pools8 * jobs_per_pool), dim3(64), 0, s, static_cast<const unsigned char *>(rows),
+                                   pitch16 * 16u, list, P, n_queries, jobs_per_pool, gram);
+            else
+                hipLaunchKernelGGL(gram_mfma_f32_kernel<4>, dim3(pools8 * jobs_per_pool), dim3(64), 0, s, static_cast<const unsigned char *>(rows),
+                                   pitch16 * 16u, list, P, n_queries, jobs_per_pool, gram);
             return hipGetLastError();
         }
         return launch_gram_src<2>(nullptr, P, dim, gram, n_queries, rows, pitch16, list, s);

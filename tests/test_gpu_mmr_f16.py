@@ -11,8 +11,8 @@ from conftest import bits
 pytestmark = pytest.mark.gpu
 
 
-def check_pools(oracle, rows, prow, psc, sizes, order, mmr, nsel, k, lam, what):
-    for q in range(prow.shape[0]):
+def check_pools(oracle, rows, prow, psc, sizes, order, mmr, nsel, k, lam, what, step=1):
+    for q in range(0, prow.shape[0], step):
         sz = int(sizes[q])
         if sz == 0:
             assert int(nsel[q]) == 0, (what, q)
@@ -32,7 +32,7 @@ def test_batched_mmr_on_the_f32_matrix_cores_matches_the_oracle(rlr, oracle, dim
     ix.upload(rows)
     rng = np.random.default_rng(P * 31 + dim)
     for lam in (0.3, 0.7, 1.0):
-        k = int(rng.choice([1, 5, min(100, P), P]))
+        k = int(rng.choice([1, 5, min(100, P), min(160, P)]))   # (the oracle's literal loop is O(k^2 P dim) on one core)
         prow = np.zeros((m, P), np.uint64)
         psc = np.zeros((m, P), np.float32)
         sizes = np.full(m, P, np.uint32)
@@ -44,9 +44,10 @@ def test_batched_mmr_on_the_f32_matrix_cores_matches_the_oracle(rlr, oracle, dim
         sizes[2] = 1
         sizes[8] = 0
         sizes[9] = min(P, 32)
-        sizes[10] = min(P, 33)
+        sizes[3] = min(P, 33)
         order, mmr, nsel = ix.mmr_select_batch(prow, psc, sizes, k, lam)
-        check_pools(oracle, rows, prow, psc, sizes, order, mmr, nsel, k, lam, ("search pools", dim, P, lam, k))
+        # every pool up to 320 candidates, every third beyond (pools 0, 3, 6, 9: full, ragged and tile-edge sizes among them)
+        check_pools(oracle, rows, prow, psc, sizes, order, mmr, nsel, k, lam, ("search pools", dim, P, lam, k), step=1 if P <= 320 else 3)
     ix.close()
 
 
