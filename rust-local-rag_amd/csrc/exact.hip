@@ -13,6 +13,7 @@
 #include "../../include/rlr_gpu.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace rlr {
@@ -950,6 +951,11 @@ bool batch_rescore_fits(uint32_t pitch16, uint32_t dim, int dtype)
     return 2 * q_bytes + 16 <= 60 * 1024; // the query + one candidate row of products
 }
 
+// (Round 3 tried two "wide" batched re-scores -- one lane per candidate over 128-byte row pieces of 256 candidates, and over the whole
+// staged rows of 32 candidates -- to get rid of the one-adding-lane-per-candidate shape below.  Both were bit-identical and both SLOWER
+// on the same box: config 3's finish 0.23 instead of 0.14 ms per 256 queries, config 5's 1.39 instead of 1.06 ms per 1024: the
+// piecewise form pays a DRAM page activation per 128 bytes, the whole-row form serialises 32 LDS-latency-bound chains per workgroup.
+// The staged kernel stays.)
 // batched staged re-score; false when the staged layout does not fit LDS for this row size
 bool launch_batch_rescore(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, const float *queries,
                           uint32_t q_pitch, uint32_t n_queries, uint64_t *band, uint32_t band_stride,
