@@ -105,6 +105,7 @@ struct GemmArgs {
     SelectState *st;             // filter mode: per-query counters / capacity
     float *scores;               // materialise mode: [query][score_stride], column = row - row_begin
     size_t score_stride;
+    uint32_t *sync;              // gemm8, several query blocks: 256 zeroed words, one arrival counter per sibling group (or null)
 };
 
 // ---- epilogue shared by the GEMM kernels: D layout is col = lane & 15 (query), row = 4*(lane >> 4) + reg
@@ -453,7 +454,7 @@ __device__ __forceinline__ void lds_write_b32(uint32_t addr, uint32_t v)
 
 // VAR (RLR_GEMM8_VARIANT, same-box A/B): bit 0 = s_setprio pair around each MFMA cluster (+2-5 % time: off), bit 1 = no
 // sched_barrier behind the phase's lgkmcnt(0) (-1 %), bit 2 = non-temporal DMA for the once-read row half-tiles
-// (-2.5 %).  Built: 6 (default) and 0.
+// (-2.5 % at 256 queries; only used while a row tile has one reader).  Built: 6 (default) and 0.
 template <bool MATERIALISE, int VAR>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char *__restrict__ image, uint32_t n_tiles)
 {
@@ -486,6 +487,25 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char
         s_bbase = qfrag + static_cast<size_t>(s % nqb) * qb_bytes;
     };
     set_stage_unit(0);
+    // Sibling re-synchronisation (several query blocks).  The nqb units of one row tile are consecutive list entries, i.e. they run
+    // on nqb neighbouring workgroups of this XCD in the same iteration, and the tile's second..n-th read is meant to hit the XCD's L2.
+    // Nothing keeps the neighbours in step, though: their drift grows with every unit (the epilogues differ per query block), a line
+    // lives ~30 us in the 4 MB L2 at this streaming rate, and rocprofv3 showed the image fetched 1.65 times per batch over 1.6 M rows
+    // and 2.85 times over 6.25 M (FETCH_SIZE).  So every kSyncEvery-th unit the group's workgroups meet before staging on: wave 0
+    // adds 1 to the group's counter (no-return atomic) and polls it with scalar loads (lgkmcnt, not the vmcnt the DMA ring is counted
+    // on) until all nqb have arrived -- or 256 polls have passed: a sibling that never comes (a grid that is not fully resident) costs
+    // time, never a hang.
+    constexpr uint32_t kSyncEvery = 4;
+    const bool sib_sync = a.sync != nullptr && nqb > 1 && nqb <= J && (J % nqb) == 0;
+    const uint32_t *sync_word = sib_sync ? a.sync + xcd * 32 + j / nqb : nullptr;
+    auto sibling_meet = [&](uint32_t unit) {
+        if (lane == 0)
+            __hip_atomic_fetch_add(const_cast<uint32_t *>(sync_word), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t want = nqb * (unit / kSyncEvery);
+        uint32_t seen = 0;
+        for (int tries = 0; tries < 256 && seen < want; ++tries)
+            asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(sync_word) : "memory");
+    };
     auto stage = [&]() {
         const bool is_a = s_i == 0 || s_i == 3;
         char *dst = lds + s_slot * kHalfBytes + wave * 1024;
@@ -493,7 +513,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char
         const char *src = is_a ? s_abase + (static_cast<size_t>(s_t) * 2 + (s_i == 3)) * kHalfBytes
                                : s_bbase + (static_cast<size_t>(s_t) * 2 * 16 + (s_i == 2) * 8) * 1024;
         const uint32_t second = is_a ? 8192u : 16384u;
-        if ((VAR & 4) && is_a) {
+        // non-temporal only while a row tile has ONE reader (<= 256 queries).  With several query blocks the units of a tile run
+        // side by side on one XCD and their 2nd..n-th read is meant to hit its L2: streamed with `nt` the lines are gone before the
+        // siblings arrive -- config 5's share fetched the image 3.2 times per batch (rocprofv3 FETCH_SIZE, profiles/r03_c5_share_*)
+        if ((VAR & 4) && is_a && nqb == 1) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + tid * 16),
                                              (__attribute__((address_space(3))) void *)(dst), 16, 0, 2);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + second + tid * 16),
@@ -507,8 +530,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char
             s_i = 0;
             if (++s_t == T) {
                 s_t = 0;
-                if (++s_it < n_it) // past the end: the last unit again, into slots nobody reads any more
+                if (++s_it < n_it) { // past the end: the last unit again, into slots nobody reads any more
                     set_stage_unit(s_it);
+                    if (sib_sync && wave == 0 && (s_it % kSyncEvery) == 0)
+                        sibling_meet(s_it);
+                }
             }
         }
     };
@@ -1166,7 +1192,7 @@ static uint32_t persistent_grid()
 hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin,
                                 uint32_t row_end, const void *qfrag, uint32_t n_queries, const float *tau,
                                 uint64_t *cand, uint32_t cand_stride, SelectState *st, float *scores,
-                                size_t score_stride, const void *image, hipStream_t s)
+                                size_t score_stride, const void *image, hipStream_t s, uint32_t *sync_ws)
 {
     if (row_end <= row_begin)
         return hipSuccess;
@@ -1185,6 +1211,7 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
     a.st = st;
     a.scores = scores;
     a.score_stride = score_stride;
+    a.sync = nullptr;
     const uint32_t n_rt = (row_end - row_begin + kBM - 1) / kBM;
     const uint32_t grid = ((n_rt + 7) / 8) * 8 * a.n_qblocks;
     const bool mat = scores != nullptr;
@@ -1208,6 +1235,14 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
         const uint32_t n_units = n_rt * a.n_qblocks;
         const uint32_t g8 = std::max<uint32_t>(8, std::min<uint32_t>(persistent_grid(), (n_units + 7) / 8 * 8));
         const char *img = static_cast<const char *>(image);
+        static const bool no_sync = getenv("RLR_GEMM8_NO_SIBLING_SYNC") != nullptr;
+        // sibling groups only exist on a grid of one workgroup per CU (all of them resident at once)
+        if (sync_ws && a.n_qblocks > 1 && g8 == persistent_grid() && !no_sync) {
+            const hipError_t e = hipMemsetAsync(sync_ws, 0, 256 * sizeof(uint32_t), s);
+            if (e != hipSuccess)
+                return e;
+            a.sync = sync_ws;
+        }
         static const int var = [] {
             const char *v = getenv("RLR_GEMM8_VARIANT");
             return v ? static_cast<int>(strtol(v, nullptr, 0)) : 6; // same-box A/B: 6 is 2-4 % faster than 0, 1 is slower

@@ -105,6 +105,7 @@ struct Ctx {
     SelectState *d_bstate = nullptr;
     uint32_t *d_bhist = nullptr;    // q x 2 x kHistBins
     uint32_t *d_bstatus = nullptr;
+    uint32_t *d_gsync = nullptr;   // 256 words: sibling-group arrival counters of the persistent batched GEMM (gemm.hip)
     uint32_t bq_cap = 0;            // queries the four arrays above are sized for
     uint64_t *d_bcand = nullptr;    // q x fin_cap packed candidates
     uint64_t bcand_cap = 0;         // entries
@@ -257,6 +258,7 @@ void ctx_free(Ctx *c)
     (void)hipFree(c->d_bstate);
     (void)hipFree(c->d_bhist);
     (void)hipFree(c->d_bstatus);
+    (void)hipFree(c->d_gsync);
     (void)hipFree(c->d_bcand);
     (void)hipFree(c->d_sample);
     for (auto &e : c->bev)
@@ -1401,6 +1403,8 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
         RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_bstatus), static_cast<size_t>(nq) * sizeof(uint32_t)));
         c->bq_cap = nq;
     }
+    if (!c->d_gsync)
+        RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_gsync), 256 * sizeof(uint32_t)));
     RLR_TRY(grow(&c->d_bcand, &c->bcand_cap, static_cast<uint64_t>(nq) * fin_cap));
     RLR_TRY(grow(&c->d_sample, &c->sample_cap, static_cast<uint64_t>(nq) * s_stride));
 
@@ -1451,14 +1455,14 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
         // 2b. rows [S1, S2) against the small sample's threshold, then tighten it
         RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, static_cast<uint32_t>(S1),
                                      static_cast<uint32_t>(S2), c->d_qfrag, nq, c->d_tau, c->d_bcand, fin_cap, c->d_bstate,
-                                     nullptr, 0, image, s));
+                                     nullptr, 0, image, s, c->d_gsync));
         RLR_HIP(launch_batch_tighten(c->d_bcand, fin_cap, c->d_bstate, nq, p.k, two_eps, c->d_tau, s));
         rest_begin = static_cast<uint32_t>(S2);
     }
     // 3. the rest of the corpus, filtered in the GEMM epilogue
     if (timed) RLR_HIP(hipEventRecord(c->bev[4], s));
     RLR_HIP(launch_gemm_nominate(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, rest_begin, n, c->d_qfrag, nq,
-                                 c->d_tau, c->d_bcand, fin_cap, c->d_bstate, nullptr, 0, image, s));
+                                 c->d_tau, c->d_bcand, fin_cap, c->d_bstate, nullptr, 0, image, s, c->d_gsync));
     if (timed) RLR_HIP(hipEventRecord(c->bev[3], s));
     // 4. per-query finish: band, reference-order re-score, order, emit
     RLR_HIP(launch_batch_finish(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, ix->q_pitch, nq, c->d_bcand, fin_cap,

@@ -72,7 +72,7 @@ hipError_t launch_prep_queries(const float *q, uint32_t n_queries, uint32_t q_pi
 hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim, int dtype, uint32_t row_begin,
                                 uint32_t row_end, const void *qfrag, uint32_t n_queries, const float *tau,
                                 uint64_t *cand, uint32_t cand_stride, SelectState *st, float *scores,
-                                size_t score_stride, const void *image, hipStream_t s);
+                                size_t score_stride, const void *image, hipStream_t s, uint32_t *sync_ws = nullptr);
 // optional binary16 nomination image of the corpus in GEMM-fragment order (see gemm.hip)
 size_t image_bytes(uint32_t dim, uint64_t n_rows);
 // whether launch_gemm_nominate serves rows of this width from the image (else it reads the row-major matrix)
