@@ -35,6 +35,9 @@ run lex_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_lex_kt -- pyt
 run multi8_kt --kernel-trace --stats --output-format csv -d $O/${TAG}_multi8_kt -- python3 $R/bench.py --batch 8 --steps 20 --warmup 3 --no-cpu --settle-ms 0
 grep -h '"metric"' $O/${TAG}_multi8_kt.log | tail -1 > $O/${TAG}_bench_batch8_under_rocprof.json
 cd $R
+timeout -k 10 300 python3 $R/scratch/time_multi_engine.py > $O/${TAG}_multi_engine_time.json 2> $O/${TAG}_multi_engine_time.err < /dev/null; echo "multi engine timing rc=$?"
+timeout -k 10 200 python3 $R/bench.py --in-process --gpus 1 --steps 30 --warmup 3 2>/dev/null | tail -1 > $O/${TAG}_bench_inprocess_n1.json
+timeout -k 10 200 python3 $R/scratch/time_mmr_f16.py 5 > $O/${TAG}_mmr_f16_time.json 2>/dev/null
 timeout -k 10 600 python3 $R/bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err < /dev/null
 echo "default bench rc=$?"; head -c 300 $O/${TAG}_bench_n1.json; echo
 ls $O | grep "^${TAG}_" | head -40

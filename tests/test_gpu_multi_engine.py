@@ -78,7 +78,7 @@ def test_multi_engine_batch_with_cross_shard_mmr(rlr, oracle, dtype, devices):
     """BASELINE config 5's shape in small: a batch of queries, top-k with MMR, pools spanning every shard; each query equal
     to the oracle's search_with_diversity over the whole corpus (and the plain batch to its search)."""
     f16 = dtype == "f16"
-    n, dim, nq = 12_007, (1024 if f16 else 768), 37
+    n, dim, nq = 9_007, (1024 if f16 else 768), 21
     rows = corpus(oracle, n, dim, f16, seed=3301)
     mi = rlr.MultiGpuIndex(dim, devices, dtype)
     mi.upload(rows)
