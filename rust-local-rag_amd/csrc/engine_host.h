@@ -59,6 +59,38 @@ inline std::vector<float> prepare_query(const float *query_raw, uint32_t dq, uin
     return q;
 }
 
+// prepare_query for a batch: the same per-query arithmetic (normalize's strict left-to-right f32 sum of squares, then one
+// division per element, :1763-1771), eight queries at a time so that eight independent chains are in flight -- one dependent
+// chain per query costs 4 cycles per element (1.2 ms for config 5's 1024 x 1024-d batch).  out: nq x dim, zero-extended / cut.
+inline void prepare_queries(const float *queries_raw, uint32_t dq, uint32_t nq, uint32_t dim, float *out)
+{
+    for (uint32_t q0 = 0; q0 < nq; q0 += 8) {
+        const uint32_t m = std::min<uint32_t>(8, nq - q0);
+        float s[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        const float *v[8];
+        for (uint32_t j = 0; j < 8; ++j)
+            v[j] = queries_raw + static_cast<size_t>(q0 + (j < m ? j : 0)) * dq;
+        for (uint32_t i = 0; i < dq; ++i)
+            for (uint32_t j = 0; j < 8; ++j) {
+                const float p = v[j][i] * v[j][i];
+                s[j] = s[j] + p;
+            }
+        for (uint32_t j = 0; j < m; ++j) {
+            float *o = out + static_cast<size_t>(q0 + j) * dim;
+            const uint32_t n = std::min(dq, dim);
+            if (s[j] > 1e-20f) {
+                const float norm = std::sqrt(s[j]);
+                for (uint32_t i = 0; i < n; ++i)
+                    o[i] = v[j][i] / norm;
+            } else {
+                std::memcpy(o, v[j], n * sizeof(float));
+            }
+            for (uint32_t i = n; i < dim; ++i)
+                o[i] = 0.0f;
+        }
+    }
+}
+
 // The lexical map of search() (:505-506, a HashMap: a repeated chunk keeps its LAST score) as ascending unique rows,
 // and max_lexical (:515-519: over every pair, floored at f32::EPSILON).
 struct LexPrep {
@@ -289,10 +321,7 @@ int32_t generic_search_with_diversity_batch(const B &be, const float *queries_ra
         return RLR_OK;
     }
     std::vector<float> qn(static_cast<size_t>(n_queries) * be.dim);
-    for (uint32_t q = 0; q < n_queries; ++q) {
-        const std::vector<float> v = prepare_query(queries_raw + static_cast<size_t>(q) * dq, dq, be.dim);
-        std::memcpy(qn.data() + static_cast<size_t>(q) * be.dim, v.data(), be.dim * sizeof(float));
-    }
+    prepare_queries(queries_raw, dq, n_queries, be.dim, qn.data());
     const uint32_t fetch = static_cast<uint32_t>(std::min<uint64_t>(N, need + 8));
     std::vector<uint64_t> rows(static_cast<size_t>(n_queries) * fetch);
     std::vector<float> cosv(static_cast<size_t>(n_queries) * fetch);

@@ -106,6 +106,7 @@ struct Ctx {
     uint32_t *d_bhist = nullptr;    // q x 2 x kHistBins
     uint32_t *d_bstatus = nullptr;
     uint32_t *d_gsync = nullptr;   // 256 words: sibling-group arrival counters of the persistent batched GEMM (gemm.hip)
+    void *h_batch = nullptr;       // pinned: SelectState[bq_cap] | status[bq_cap] (pageable staging makes the async copies synchronous)
     uint32_t bq_cap = 0;            // queries the four arrays above are sized for
     uint64_t *d_bcand = nullptr;    // q x fin_cap packed candidates
     uint64_t bcand_cap = 0;         // entries
@@ -264,6 +265,7 @@ void ctx_free(Ctx *c)
     for (auto &e : c->bev)
         if (e) (void)hipEventDestroy(e);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_batch) (void)hipHostFree(c->h_batch);
     if (c->h_assert) (void)hipHostFree(c->h_assert);
     delete c;
 }
@@ -503,14 +505,26 @@ struct SearchPlan {
 // The guard bands are error bounds for unit-norm operands; every term of them is linear in |row| * |query|.
 // Rows stored with normalize_on_device = 0 and queries the caller did not normalise widen the band by that
 // product (norms rounded up); unit-norm data -- the reference's invariant, rag_engine.rs:359 / :494 -- gives 1.
+// sum of squares in binary64 with eight independent partial sums: the value only feeds an upper bound with its own slack, so
+// the order is free -- and one dependent chain per query was 0.2 ms of host time in front of every 256-query batch of 768-d
+// queries (1.2 ms in front of config 5's 1024 x 1024-d), more than the whole select-and-finish tail.
+static double sumsq_f64(const float *v, uint32_t n)
+{
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int j = 0; j < 8; ++j)
+            a[j] += static_cast<double>(v[i + j]) * v[i + j];
+    for (; i < n; ++i)
+        a[0] += static_cast<double>(v[i]) * v[i];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 float band_scale(const rlr_index *ix, const float *queries, uint32_t nq)
 {
     double qmax = 0.0;
     for (uint32_t q = 0; q < nq; ++q) {
-        double s2 = 0.0;
-        const float *v = queries + static_cast<size_t>(q) * ix->dim;
-        for (uint32_t i = 0; i < ix->dim; ++i)
-            s2 += static_cast<double>(v[i]) * v[i];
+        const double s2 = sumsq_f64(queries + static_cast<size_t>(q) * ix->dim, ix->dim);
         if (s2 > qmax) // (a NaN query compares false: its scores are NaN and order last whatever the band)
             qmax = s2;
     }
@@ -1135,10 +1149,7 @@ void stage_query_norms(const rlr_index *ix, Ctx *c, const float *queries, uint32
         return;
     c->q_norm.resize(nq);
     for (uint32_t q = 0; q < nq; ++q) {
-        double s2 = 0.0;
-        const float *v = queries + static_cast<size_t>(q) * ix->dim;
-        for (uint32_t i = 0; i < ix->dim; ++i)
-            s2 += static_cast<double>(v[i]) * v[i];
+        const double s2 = sumsq_f64(queries + static_cast<size_t>(q) * ix->dim, ix->dim);
         c->q_norm[q] = std::isfinite(s2) ? static_cast<float>(std::sqrt(s2) * 1.000001) : 1.0f;
     }
 }
@@ -1347,7 +1358,7 @@ bool batch_eligible(const rlr_index *ix, uint32_t nq, uint32_t k)
 // and leaves k packed results per query in d_out; h_status[q] != 0 marks queries the caller must
 // re-run through the single-query pipeline.
 int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const SearchPlan &p, uint64_t *d_out,
-                    std::vector<uint32_t> &h_status)
+                    std::vector<uint32_t> &h_status, uint64_t *h_res_out)
 {
     hipStream_t s = c->stream;
     const uint32_t n = static_cast<uint32_t>(ix->n_rows);
@@ -1392,6 +1403,8 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
         (void)hipFree(c->d_bstate);
         (void)hipFree(c->d_bhist);
         (void)hipFree(c->d_bstatus);
+        if (c->h_batch) (void)hipHostFree(c->h_batch);
+        c->h_batch = nullptr;
         c->d_tau = nullptr;
         c->d_bstate = nullptr;
         c->d_bhist = nullptr;
@@ -1401,6 +1414,7 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
         RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_bstate), static_cast<size_t>(nq) * sizeof(SelectState)));
         RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_bhist), static_cast<size_t>(nq) * 2 * kHistBins * sizeof(uint32_t)));
         RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_bstatus), static_cast<size_t>(nq) * sizeof(uint32_t)));
+        RLR_HIP(hipHostMalloc(&c->h_batch, static_cast<size_t>(nq) * (sizeof(SelectState) + sizeof(uint32_t)), hipHostMallocDefault));
         c->bq_cap = nq;
     }
     if (!c->d_gsync)
@@ -1408,15 +1422,16 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     RLR_TRY(grow(&c->d_bcand, &c->bcand_cap, static_cast<uint64_t>(nq) * fin_cap));
     RLR_TRY(grow(&c->d_sample, &c->sample_cap, static_cast<uint64_t>(nq) * s_stride));
 
-    std::vector<SelectState> h_st(nq);
-    for (auto &st : h_st) {
-        std::memset(&st, 0, sizeof(st));
-        st.k = std::min<uint32_t>(p.k, static_cast<uint32_t>(S));
-        st.cap = fin_cap;
+    SelectState *h_st = static_cast<SelectState *>(c->h_batch);
+    uint32_t *h_stat = reinterpret_cast<uint32_t *>(h_st + c->bq_cap);
+    for (uint32_t i = 0; i < nq; ++i) {
+        std::memset(&h_st[i], 0, sizeof(SelectState));
+        h_st[i].k = std::min<uint32_t>(p.k, static_cast<uint32_t>(S));
+        h_st[i].cap = fin_cap;
     }
     const float *dq = c->d_query + static_cast<size_t>(q0) * ix->q_pitch;
     const bool timed = ix->profiling;
-    RLR_HIP(hipMemcpyAsync(c->d_bstate, h_st.data(), nq * sizeof(SelectState), hipMemcpyHostToDevice, s));
+    RLR_HIP(hipMemcpyAsync(c->d_bstate, h_st, nq * sizeof(SelectState), hipMemcpyHostToDevice, s));
     RLR_HIP(hipMemsetAsync(c->d_bhist, 0, static_cast<size_t>(nq) * 2 * kHistBins * sizeof(uint32_t), s));
     RLR_HIP(hipMemsetAsync(c->d_bstatus, 0xFF, static_cast<size_t>(nq) * sizeof(uint32_t), s));
     if (timed) RLR_HIP(hipEventRecord(c->bev[0], s));
@@ -1468,9 +1483,11 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     RLR_HIP(launch_batch_finish(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, dq, ix->q_pitch, nq, c->d_bcand, fin_cap,
                                 c->d_bstate, p.k, two_eps, d_out, c->d_bstatus, s));
     if (timed) RLR_HIP(hipEventRecord(c->ev[3], s));
-    h_status.assign(nq, 0);
-    RLR_HIP(hipMemcpyAsync(h_status.data(), c->d_bstatus, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    RLR_HIP(hipMemcpyAsync(h_stat, c->d_bstatus, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (h_res_out) // the batch's results ride on the same synchronisation (queries handed back are fetched again by the caller)
+        RLR_HIP(hipMemcpyAsync(h_res_out, d_out, static_cast<size_t>(nq) * p.k * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     RLR_HIP(hipStreamSynchronize(s));
+    h_status.assign(h_stat, h_stat + nq);
     uint64_t fallbacks = 0;
     for (uint32_t v : h_status)
         fallbacks += v != 0;
@@ -1560,7 +1577,8 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
         std::vector<uint32_t> status;
         for (uint32_t q0 = 0; q0 < nq; q0 += kBatchMaxQueries) {
             const uint32_t m = std::min(kBatchMaxQueries, nq - q0);
-            RLR_TRY(run_batched(ix, c, q0, m, p, d_out + static_cast<size_t>(q0) * p.k, status));
+            RLR_TRY(run_batched(ix, c, q0, m, p, d_out + static_cast<size_t>(q0) * p.k, status,
+                                d_out_user ? nullptr : h_res + static_cast<size_t>(q0) * p.k));
             for (uint32_t i = 0; i < m; ++i)
                 if (status[i] != 0)
                     redo.push_back(q0 + i);
@@ -1575,8 +1593,10 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
                 RLR_TRY(big_query(ix, c, q, p, nc, /*rescan=*/false, d_out + static_cast<size_t>(q) * p.k));
             }
         }
-        RLR_TRY(fetch_results(0, n_res));
-        RLR_HIP(hipStreamSynchronize(s));
+        if (!redo.empty()) { // (their results changed after the batch's own copy)
+            RLR_TRY(fetch_results(0, n_res));
+            RLR_HIP(hipStreamSynchronize(s));
+        }
         c->hist_dirty = false;
         if (h_results)
             *h_results = h_res;
@@ -1974,12 +1994,17 @@ int32_t rlr_search_topk(rlr_index *ix, const float *queries, uint32_t n_queries,
         return fail(RLR_E_INTERNAL, "search produced no result buffer");
     for (uint32_t q = 0; q < n_queries; ++q) {
         n_out[q] = p.k;
+        // unpack_result, written without branches so that the loop vectorises (a batch of 1024 x 308 results is 315 k of them)
+        const uint64_t *__restrict__ src = h + static_cast<size_t>(q) * p.k;
+        uint64_t *__restrict__ ro = rows_out + static_cast<size_t>(q) * k;
+        uint32_t *__restrict__ co = reinterpret_cast<uint32_t *>(cos_out + static_cast<size_t>(q) * k);
         for (uint32_t i = 0; i < p.k; ++i) {
-            float sc;
-            uint32_t r;
-            unpack_result(h[static_cast<size_t>(q) * p.k + i], &sc, &r);
-            rows_out[static_cast<size_t>(q) * k + i] = r;
-            cos_out[static_cast<size_t>(q) * k + i] = sc;
+            const uint64_t w = src[i];
+            const uint32_t key = static_cast<uint32_t>(w >> 32);
+            const uint32_t neg = static_cast<uint32_t>(static_cast<int32_t>(key) >> 31);        // all ones: key of a value >= +0
+            const uint32_t bits = key ^ (0xFFFFFFFFu ^ (neg & 0x7FFFFFFFu));                     // key_score(): & 0x7FFFFFFF or ~
+            co[i] = key == 0u ? 0x7FC00000u : bits;
+            ro[i] = 0xFFFFFFFFu - static_cast<uint32_t>(w);
         }
     }
     return RLR_OK;
