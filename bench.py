@@ -109,31 +109,33 @@ def pmc_traffic(bytes_per_launch, kernel):
     return best
 
 
-def batched_traffic(bytes_per_launch, kernel):
-    """HBM bytes of the batch's main GEMM pass from the committed rocprofv3 counter passes of the same shape
-    (profiles/rNN_*_kernels.json, `counters_by_ordinal`: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE per launch of that
-    ordinal inside a batch); the newest summary whose fetch bytes are within 10 % of this launch's operand bytes."""
+def batched_traffic(bytes_per_launch, kernel, tag):
+    """HBM bytes of the batch's main GEMM pass from the committed rocprofv3 counter passes of the same workload
+    (profiles/rNN_<tag>_kernels.json, `counters_by_ordinal`: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE per launch of the
+    LAST ordinal inside a batch = the filtered main pass); the newest round's summary.  PMC counters cannot be read from
+    inside the process; a figure outside [0.9, 4] x the operand bytes would mean another shape and is not quoted."""
     import glob
 
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernels.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_kernels.json"))):
         try:
             cbo = json.load(open(f)).get("counters_by_ordinal", {})
         except Exception:
             continue
         for name, by_ord in cbo.items():
-            if kernel not in name:
+            if kernel not in name or "<true" in name or not by_ord:
                 continue
-            for o, c in by_ord.items():
-                fetch = c.get("FETCH_SIZE", {}).get("bytes_corrected_x2")
-                if fetch is None or abs(fetch - bytes_per_launch) > 0.10 * bytes_per_launch:
-                    continue
-                write = c.get("WRITE_SIZE", {}).get("bytes", 0.0)
-                best = (fetch + write, os.path.basename(f) + f" ({name}, launch {o} of a batch)")
+            o = max(by_ord, key=int)
+            c = by_ord[o]
+            fetch = c.get("FETCH_SIZE", {}).get("bytes_corrected_x2")
+            if fetch is None or not (0.9 * bytes_per_launch <= fetch <= 4.0 * bytes_per_launch):
+                continue
+            write = c.get("WRITE_SIZE", {}).get("bytes", 0.0)
+            best = (fetch + write, os.path.basename(f) + f" ({name}, launch {o} of a batch)")
     return best
 
 
-def batched_roofline(prof, dim, nq, image):
+def batched_roofline(prof, dim, nq, image, tag="batch256_image"):
     """roofline object of the dominant launch of a batch (the filtered main GEMM pass), from the library's HIP
     events on its own stream.  `bound` is the roof with the larger ideal time for this launch: the operand bytes
     once at the HBM peak against 2*Q*rows*dim flops at the dense binary16 MFMA peak (both reported)."""
@@ -146,7 +148,7 @@ def batched_roofline(prof, dim, nq, image):
     hbm = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS}
     mfma = {"achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F16_PEAK_TFLOPS}
     main = dict(mfma if t_mfma >= t_hbm else hbm)
-    traffic = batched_traffic(b, batch_kernel_name(dim, nq, image))
+    traffic = batched_traffic(b, batch_kernel_name(dim, nq, image), tag)
     main.update({"bound": "mfma" if t_mfma >= t_hbm else "hbm", "traffic": traffic[0] if traffic else None,
                  "traffic_source": ("profiles/" + traffic[1] + ": FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of "
                                     "this shape") if traffic else None,
@@ -420,7 +422,7 @@ def config_c5_share(rlr, torch):
             "stages_ms": {"batched_search_pool308": t_search * 1e3, "batched_mmr": t_mmr * 1e3,
                           "gemm_all_launches": p.batch_gemm_ms / reps, "select_and_finish": p.batch_other_ms / reps,
                           "mmr_kernels": p.mmr_ms / reps},
-            "timed_passes": reps, "fallback_queries": p.n_batch_fallbacks, "roofline": batched_roofline(p, dim, nq, True)}
+            "timed_passes": reps, "fallback_queries": p.n_batch_fallbacks, "roofline": batched_roofline(p, dim, nq, True, "c5_share")}
 
 
 def in_process(args):

@@ -2774,11 +2774,18 @@ static int32_t mmr_batch_impl(rlr_index *ix, const uint64_t *pool_rows, const fl
         RLR_TRY(pin_reserve(c, list_bytes + in_bytes + out_bytes + 64));
         if (pool_rows) {
             // unused slots (j >= pool_sizes[q]) gather row 0: never read by the greedy kernel
-            rows_chunk.assign(n_list, 0);
-            for (uint32_t q = 0; q < m; ++q)
-                std::memcpy(rows_chunk.data() + static_cast<size_t>(q) * P, pool_rows + static_cast<size_t>(q0 + q) * P,
-                            pool_sizes[q0 + q] * sizeof(uint64_t));
-            RLR_TRY(upload_list(ix, c, rows_chunk.data(), n_list, d_matrix ? n_matrix : ~0ull));
+            bool all_full = true;
+            for (uint32_t q = 0; q < m && all_full; ++q)
+                all_full = pool_sizes[q0 + q] == P;
+            const uint64_t *src_rows = pool_rows + static_cast<size_t>(q0) * P;
+            if (!all_full) { // (full pools are taken as they stand: no 8 n_list-byte fill + copy in front of every batch)
+                rows_chunk.assign(n_list, 0);
+                for (uint32_t q = 0; q < m; ++q)
+                    std::memcpy(rows_chunk.data() + static_cast<size_t>(q) * P, pool_rows + static_cast<size_t>(q0 + q) * P,
+                                pool_sizes[q0 + q] * sizeof(uint64_t));
+                src_rows = rows_chunk.data();
+            }
+            RLR_TRY(upload_list(ix, c, src_rows, n_list, d_matrix ? n_matrix : ~0ull));
         }
         const uint64_t pool_floats = 0; // (the pool rows are read in place)
         const uint64_t floats = pool_floats + static_cast<uint64_t>(m) * P * P + 3ull * n_list + 2ull * m + 8;
