@@ -493,18 +493,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char
     // lives ~30 us in the 4 MB L2 at this streaming rate, and rocprofv3 showed the image fetched 1.65 times per batch over 1.6 M rows
     // and 2.85 times over 6.25 M (FETCH_SIZE).  So every kSyncEvery-th unit the group's workgroups meet before staging on: wave 0
     // adds 1 to the group's counter (no-return atomic) and polls it with scalar loads (lgkmcnt, not the vmcnt the DMA ring is counted
-    // on) until all nqb have arrived -- or 256 polls have passed: a sibling that never comes (a grid that is not fully resident) costs
-    // time, never a hang.
+    // on) until all nqb have arrived -- or 64 polls have passed: a sibling that never comes (a grid that is not fully resident, e.g. two
+    // batched searches on the device at once) costs some tens of microseconds ONCE -- the workgroup then stops meeting -- never a hang.
     constexpr uint32_t kSyncEvery = 4;
     const bool sib_sync = a.sync != nullptr && nqb > 1 && nqb <= J && (J % nqb) == 0;
     const uint32_t *sync_word = sib_sync ? a.sync + xcd * 32 + j / nqb : nullptr;
+    bool meeting = sib_sync; // (wave-uniform; only wave 0 uses it)
     auto sibling_meet = [&](uint32_t unit) {
-        if (lane == 0)
+        if (lane == 0) // (arrive even after giving up waiting: the siblings that still wait count this workgroup)
             __hip_atomic_fetch_add(const_cast<uint32_t *>(sync_word), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!meeting)
+            return;
         const uint32_t want = nqb * (unit / kSyncEvery);
         uint32_t seen = 0;
-        for (int tries = 0; tries < 256 && seen < want; ++tries)
+        for (int tries = 0; tries < 64 && seen < want; ++tries)
             asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(sync_word) : "memory");
+        meeting = seen >= want;
     };
     auto stage = [&]() {
         const bool is_a = s_i == 0 || s_i == 3;
