@@ -106,6 +106,7 @@ struct GemmArgs {
     float *scores;               // materialise mode: [query][score_stride], column = row - row_begin
     size_t score_stride;
     uint32_t *sync;              // gemm8, several query blocks: 256 zeroed words, one arrival counter per sibling group (or null)
+    uint32_t sync_every;         // ... and the siblings meet before every sync_every-th unit
 };
 
 // ---- epilogue shared by the GEMM kernels: D layout is col = lane & 15 (query), row = 4*(lane >> 4) + reg
@@ -493,9 +494,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char
     // lives ~30 us in the 4 MB L2 at this streaming rate, and rocprofv3 showed the image fetched 1.65 times per batch over 1.6 M rows
     // and 2.85 times over 6.25 M (FETCH_SIZE).  So every kSyncEvery-th unit the group's workgroups meet before staging on: wave 0
     // adds 1 to the group's counter (no-return atomic) and polls it with scalar loads (lgkmcnt, not the vmcnt the DMA ring is counted
-    // on) until all nqb have arrived -- or 64 polls have passed: a sibling that never comes (a grid that is not fully resident, e.g. two
-    // batched searches on the device at once) costs some tens of microseconds ONCE -- the workgroup then stops meeting -- never a hang.
-    constexpr uint32_t kSyncEvery = 4;
+    // on) until all nqb have arrived -- or 512 polls have passed (64 were not enough: siblings legitimately differ by a unit's epilogue, and workgroups
+    // that gave up let the traffic climb back to 2.1 x): a sibling that never comes (a grid that is not fully resident, e.g. two
+    // batched searches on the device at once) costs a few hundred microseconds ONCE -- the workgroup then stops meeting -- never a hang.
+    const uint32_t kSyncEvery = a.sync_every ? a.sync_every : 4u;
     const bool sib_sync = a.sync != nullptr && nqb > 1 && nqb <= J && (J % nqb) == 0;
     const uint32_t *sync_word = sib_sync ? a.sync + xcd * 32 + j / nqb : nullptr;
     bool meeting = sib_sync; // (wave-uniform; only wave 0 uses it)
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char
             return;
         const uint32_t want = nqb * (unit / kSyncEvery);
         uint32_t seen = 0;
-        for (int tries = 0; tries < 64 && seen < want; ++tries)
+        for (int tries = 0; tries < 512 && seen < want; ++tries)
             asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(sync_word) : "memory");
         meeting = seen >= want;
     };
@@ -1216,6 +1218,7 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
     a.scores = scores;
     a.score_stride = score_stride;
     a.sync = nullptr;
+    a.sync_every = 4;
     const uint32_t n_rt = (row_end - row_begin + kBM - 1) / kBM;
     const uint32_t grid = ((n_rt + 7) / 8) * 8 * a.n_qblocks;
     const bool mat = scores != nullptr;
@@ -1246,6 +1249,8 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
             if (e != hipSuccess)
                 return e;
             a.sync = sync_ws;
+            static const uint32_t every = getenv("RLR_GEMM8_SYNC_EVERY") ? static_cast<uint32_t>(std::max(1, atoi(getenv("RLR_GEMM8_SYNC_EVERY")))) : 4u;
+            a.sync_every = every;
         }
         static const int var = [] {
             const char *v = getenv("RLR_GEMM8_VARIANT");
