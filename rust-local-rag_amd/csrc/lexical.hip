@@ -1329,8 +1329,7 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     static const bool per_term = getenv("RLR_LEX_PER_TERM") != nullptr; // (A/B switch: one launch per term and segment)
     // workgroups of the row-partitioned kernel: one per CU while each still owns a few hundred rows
     const uint32_t row_wgs = std::max<uint32_t>(1u, std::min<uint32_t>(static_cast<uint32_t>(lx->n_cu), static_cast<uint32_t>(n_rows / 256)));
-    TermBatch tb;
-    tb.n_terms = 0;
+    TermBatch tb{};
     auto flush_terms = [&]() {
         if (tb.n_terms)
             hipLaunchKernelGGL(bm25_terms_kernel, dim3(row_wgs), dim3(256), 0, s, tb, lx->d_post_row, lx->d_post_tf, lx->d_dpost_row,

@@ -494,22 +494,30 @@ int32_t multi_mmr(rlr_multi *m, const uint64_t *pool_rows, const float *pool_sco
         const size_t n_g = send_off[g][G];
         if (n_g == 0)
             return RLR_OK;
-        int32_t s1 = rlr_gather_rows_device(m->shard[g], send_rows[g].data(), static_cast<uint32_t>(n_g), w->d_stage[g]);
-        if (s1 != RLR_OK)
-            return s1;
-        RLR_X_HIP(hipSetDevice(m->device[g]));
-        for (size_t o = 0; o < G; ++o) {
-            const size_t cnt = send_count[g][o];
-            if (cnt == 0)
-                continue;
-            char *dst = static_cast<char *>(w->d_recv[o]) + recv_off[o][g] * rb;
-            const char *src = static_cast<const char *>(w->d_stage[g]) + send_off[g][o] * rb;
-            if (m->device[o] == m->device[g])
-                RLR_X_HIP(hipMemcpyAsync(dst, src, cnt * rb, hipMemcpyDeviceToDevice, w->stream[g]));
-            else
-                RLR_X_HIP(hipMemcpyPeerAsync(dst, m->device[o], src, m->device[g], cnt * rb, w->stream[g]));
-        }
-        RLR_X_HIP(hipStreamSynchronize(w->stream[g]));
+        const int32_t rc = [&]() -> int32_t {
+            int32_t s1 = rlr_gather_rows_device(m->shard[g], send_rows[g].data(), static_cast<uint32_t>(n_g), w->d_stage[g]);
+            if (s1 != RLR_OK)
+                return s1;
+            RLR_X_HIP(hipSetDevice(m->device[g]));
+            for (size_t o = 0; o < G; ++o) {
+                const size_t cnt = send_count[g][o];
+                if (cnt == 0)
+                    continue;
+                char *dst = static_cast<char *>(w->d_recv[o]) + recv_off[o][g] * rb;
+                const char *src = static_cast<const char *>(w->d_stage[g]) + send_off[g][o] * rb;
+                if (m->device[o] == m->device[g])
+                    RLR_X_HIP(hipMemcpyAsync(dst, src, cnt * rb, hipMemcpyDeviceToDevice, w->stream[g]));
+                else
+                    RLR_X_HIP(hipMemcpyPeerAsync(dst, m->device[o], src, m->device[g], cnt * rb, w->stream[g]));
+            }
+            return RLR_OK;
+        }();
+        // copies already queued must have landed before the workspace can go back to the pool, whatever happened after them
+        const hipError_t e = hipStreamSynchronize(w->stream[g]);
+        if (rc != RLR_OK)
+            return rc;
+        if (e != hipSuccess)
+            return rlr::set_error(RLR_E_HIP, "winner-row exchange on device %d: %s", m->device[g], hipGetErrorString(e));
         return RLR_OK;
     });
     if (st != RLR_OK)
