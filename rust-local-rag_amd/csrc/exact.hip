@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 
 namespace rlr {
 
@@ -453,6 +454,19 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const float4 *__restr
 }
 
 // ---- MMR ----------------------------------------------------------------------------
+__device__ inline bool finite_f(float x)
+{
+    return (__builtin_bit_cast(uint32_t, x) & 0x7F800000u) != 0x7F800000u;
+}
+
+// What the Gram kernels store: the dot product, or -inf where it is not finite.  The greedy loops read a similarity only
+// as `if sim.is_finite() { max_sim = max_sim.max(sim) }` on a max_sim that starts at +0.0, so -inf ("never raises it") stands
+// for every non-finite value and the chain compares without a class test.
+__device__ inline float gram_entry(float dot)
+{
+    return finite_f(dot) ? dot : -__builtin_inff();
+}
+
 // gram[i][j] = dot_ref(pool_i, pool_j), one lane per pair (j <= i computed, mirrored):
 // a*b is commutative and the summation order is the same, so dot(i,j) == dot(j,i) bitwise.
 __global__ __launch_bounds__(64) void gram_kernel(const float *__restrict__ pool, uint32_t P, uint32_t dim,
@@ -493,6 +507,7 @@ __global__ __launch_bounds__(64) void gram_kernel(const float *__restrict__ pool
         float p = a[c] * b[c];
         s = s + p;
     }
+    s = gram_entry(s);
     gram[static_cast<size_t>(i) * P + j] = s;
     gram[static_cast<size_t>(j) * P + i] = s;
 }
@@ -642,15 +657,11 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
         for (int b = 0; b < R; ++b) {
             const uint32_t ri = i0 + ty + 16 * a, cj = j0 + tx + 16 * b;
             if (ri < P && cj < P) {
-                gram[static_cast<size_t>(ri) * P + cj] = acc[a][b];
-                gram[static_cast<size_t>(cj) * P + ri] = acc[a][b]; // dot(i,j) == dot(j,i) bitwise
+                const float g = gram_entry(acc[a][b]);
+                gram[static_cast<size_t>(ri) * P + cj] = g;
+                gram[static_cast<size_t>(cj) * P + ri] = g; // dot(i,j) == dot(j,i) bitwise
             }
         }
-}
-
-__device__ inline bool finite_f(float x)
-{
-    return (__builtin_bit_cast(uint32_t, x) & 0x7F800000u) != 0x7F800000u;
 }
 
 // Greedy selection by one wavefront; `rem` replays the reference's Vec::swap_remove
@@ -879,6 +890,204 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
         const uint32_t n = status ? 0u : min(n_sel, emit.k_cap);
         for (uint32_t i = lane; i < n; i += 64) {
             const uint32_t o = out_order[i];
+            emit.h_out[i] = emit.list[o];
+            emit.h_out[emit.k_cap + i] = __builtin_bit_cast(uint32_t, emit.cosv[o]);
+            emit.h_out[2 * emit.k_cap + i] = __builtin_bit_cast(uint32_t, emit.comb[o]);
+            emit.h_out[3 * emit.k_cap + i] = emit.lexv ? __builtin_bit_cast(uint32_t, emit.lexv[o]) : 0u;
+        }
+        if (lane == 0) {
+            emit.h_out[4 * emit.k_cap] = n;
+            emit.h_out[4 * emit.k_cap + 1] = status;
+        }
+    }
+}
+
+// max over a lane's J values that skips NaN, never below -inf: v_max3_f32 returns the largest non-NaN operand (all values
+// here are quiet NaNs or numbers), a tree two operands wide per step instead of a compare-and-select chain
+template <int J>
+__device__ inline float lane_max_skip_nan(const float (&v)[J])
+{
+    float best = -__builtin_inff();
+    int j = 0;
+#pragma unroll
+    for (; j + 1 < J; j += 2)
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(best) : "v"(best), "v"(v[j]), "v"(v[j + 1]));
+    if (j < J)
+        asm("v_max_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(v[j]));
+    return best;
+}
+
+// The same chain with the tie-break taken off the common path.
+//
+// A pick of the register-resident kernel above is ~190 instructions of one wave alone on its SIMD -- an issue slot every
+// four cycles whatever the instruction, eight when it depends on the one before -- plus the L2 round trip of its Gram-row
+// loads: 0.60 us.  About a third of those instructions keep every candidate's position in the reference's `remaining`
+// vector (swap_remove moves the last entry into the freed slot) and run a second wavefront reduction over positions --
+// needed only when two candidates hold the same maximal MMR value ("first in visiting order wins" under the strict `>`).
+// Here the wave counts the holders of the maximum (one compare and one ballot per slot); a single holder is the pick, and
+// only a tie replays the removals logged so far on a copy of `remaining` in LDS (lane 0, incrementally: each removal is
+// replayed once) and takes the lowest position among the tied.  Non-finite values never reach the compares: a relevance
+// that makes (1 - lambda) * rel non-finite is a NaN slot from the start, the Gram kernels store -inf for a non-finite
+// similarity (gram_entry), the running maximum ignores NaN and -inf by itself, and an MMR value of +inf (overflow) sends
+// that pick through a masked recount.  The logged value is the maximum itself unless it is a zero, whose sign is read
+// from the winner.  Picks and logged values collect in LDS and leave in one burst: the chain holds no global stores.
+// 0.47 us per pick (52 us for 99 picks of 300 against 64.5).  [Also tried: the packed upper triangle of the matrix in
+// LDS, filled by sixteen waves -- 0.44 us per pick, but 3 us more in front of the chain: no gain, dropped.]
+template <int J>
+__global__ __launch_bounds__(256) void mmr_greedy_lazy_kernel(const float *__restrict__ gram, const float *__restrict__ scores,
+                                                              uint32_t P, uint32_t k, float lambda,
+                                                              uint32_t *__restrict__ out_order, float *__restrict__ out_mmr,
+                                                              uint32_t *__restrict__ out_n, const uint32_t *__restrict__ sizes,
+                                                              MmrEmit emit)
+{
+    constexpr uint32_t kSlots = 64 * J;
+    __shared__ uint2 s_log[kSlots];                // pick i: candidate, logged MMR value (bits)
+    __shared__ uint16_t s_rem[kSlots], s_posof[kSlots];
+    {
+        const uint32_t stride = P;
+        gram += static_cast<size_t>(blockIdx.x) * stride * stride;
+        scores += static_cast<size_t>(blockIdx.x) * stride;
+        out_order += static_cast<size_t>(blockIdx.x) * stride;
+        out_mmr += static_cast<size_t>(blockIdx.x) * stride;
+        out_n += blockIdx.x;
+    }
+    const uint32_t g_stride = P;
+    if (sizes)
+        P = sizes[blockIdx.x];
+    if (P == 0) {
+        if (threadIdx.x == 0) {
+            *out_n = 0;
+            if (emit.h_out) { // (an unusable pool arrives here as size 0 with its status in info[1])
+                emit.h_out[4 * emit.k_cap] = 0;
+                emit.h_out[4 * emit.k_cap + 1] = emit.info[1];
+            }
+        }
+        return;
+    }
+    // (the L2 warm-up of mmr_greedy_reg_kernel: every pick reads a different row of a matrix other CUs just wrote)
+    {
+        const float4 *g4 = reinterpret_cast<const float4 *>(gram);
+        const uint32_t n4 = (P * g_stride) / 4;
+        float warm = 0.0f;
+        for (uint32_t i = threadIdx.x * 8; i < n4; i += 256 * 8) // one 128-B line per thread and step
+            warm += g4[i].x;
+        asm volatile("" ::"v"(warm));
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64)
+        return;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t c = lane; c < P; c += 64) { // the reference's `remaining` before any removal
+        s_rem[c] = static_cast<uint16_t>(c);
+        s_posof[c] = static_cast<uint16_t>(c);
+    }
+    float t0[J], ms[J];  // (1 - lambda) * relevance (loop invariant; NaN = not selectable), running max similarity
+    uint32_t idx[J];     // clamped Gram column of the candidate
+    const float one_minus = 1.0f - lambda;
+    const float nan_f = __builtin_bit_cast(float, 0x7FC00000u);
+    const float neg_inf = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const uint32_t c = lane + 64 * j;
+        idx[j] = min(c, P - 1);
+        const float t = one_minus * scores[idx[j]];
+        // selected.push(remaining.swap_remove(0)): candidate 0 goes first
+        t0[j] = ((c < P) & (c != 0) & finite_f(t)) ? t : nan_f;
+        ms[j] = 0.0f;
+    }
+    uint32_t n_sel = 1, last = 0, replayed = 0;
+    s_log[0] = make_uint2(0u, 0x7FC00000u);
+    while (n_sel < k && n_sel < P) {
+        const float *g_last = gram + static_cast<size_t>(last) * g_stride; // row `last` == column `last`
+        float sim[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            sim[j] = g_last[idx[j]]; // empty slots load a valid (clamped) column and ignore it
+        float m0[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            ms[j] = sim[j] > ms[j] ? sim[j] : ms[j]; // `if sim.is_finite() { max_sim = max_sim.max(sim) }`: false for -inf
+            const float t1 = lambda * ms[j];
+            m0[j] = t0[j] - t1;
+        }
+        float wm = wave_max_f32_no_nan(lane_max_skip_nan<J>(m0));
+        if (wm == __builtin_inff()) { // an overflowed value is no candidate (`mmr_score.is_finite()`): recount without those
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                m0[j] = finite_f(m0[j]) ? m0[j] : nan_f;
+            wm = wave_max_f32_no_nan(lane_max_skip_nan<J>(m0));
+        }
+        if (wm == neg_inf) // no finite candidate left
+            break;
+        // the tail of a pick, once per way of finding the winner (a flag array merged from two branches would be packed
+        // into bytes and unpacked again by hipcc, every pick)
+        auto take = [&](const bool (&hit)[J]) {
+            uint32_t win = 0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                win = hit[j] ? lane + 64 * j + 1 : win;
+                t0[j] = hit[j] ? nan_f : t0[j];
+            }
+            // exactly one lane holds the winner: broadcast its candidate index
+            const int src = __builtin_ctzll(__ballot(win != 0));
+            last = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(win), src)) - 1;
+            float wm_raw = wm;
+            if (wm == 0.0f) { // the reference logs the winner's own zero, sign included
+                float z = 0.0f;
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    z = hit[j] ? m0[j] : z;
+                wm_raw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), src));
+            }
+            s_log[n_sel] = make_uint2(last, __builtin_bit_cast(uint32_t, wm_raw)); // (every lane, the same words)
+            n_sel++;
+        };
+        bool hit[J];
+        uint32_t holders = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            hit[j] = m0[j] == wm; // (-0 and +0 compare equal, in the reference too)
+            holders += static_cast<uint32_t>(__builtin_popcountll(__ballot(hit[j])));
+        }
+        if (holders == 1) {
+            take(hit);
+            continue;
+        }
+        // a tie: the lowest position in `remaining` wins
+        if (lane == 0) {
+            for (uint32_t i = replayed; i < n_sel; ++i) { // remaining.swap_remove(position of pick i)
+                const uint32_t w = s_log[i].x, n = P - i;
+                const uint32_t p = s_posof[w], moved = s_rem[n - 1];
+                s_rem[p] = static_cast<uint16_t>(moved);
+                s_posof[moved] = static_cast<uint16_t>(p);
+            }
+        }
+        replayed = n_sel;
+        uint32_t pj[J], bp = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            pj[j] = hit[j] ? static_cast<uint32_t>(s_posof[idx[j]]) : 0xFFFFFFFFu;
+            bp = min(bp, pj[j]);
+        }
+        const uint32_t wp = wave_min_u32(bp);
+        bool first[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            first[j] = pj[j] == wp;
+        take(first);
+    }
+    for (uint32_t i = lane; i < n_sel; i += 64) {
+        const uint2 e = s_log[i];
+        out_order[i] = e.x;
+        out_mmr[i] = __builtin_bit_cast(float, e.y);
+    }
+    if (lane == 0)
+        *out_n = n_sel;
+    if (emit.h_out) { // the picks straight into the caller's (pinned) result block
+        const uint32_t status = emit.info[1];
+        const uint32_t n = status ? 0u : min(n_sel, emit.k_cap);
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t o = s_log[i].x;
             emit.h_out[i] = emit.list[o];
             emit.h_out[emit.k_cap + i] = __builtin_bit_cast(uint32_t, emit.cosv[o]);
             emit.h_out[2 * emit.k_cap + i] = __builtin_bit_cast(uint32_t, emit.comb[o]);
@@ -1183,8 +1392,9 @@ __global__ __launch_bounds__(64) void gram_mfma_f32_kernel(const unsigned char *
     for (int v = 0; v < 32; ++v) {
         const uint32_t i = (I0 + v / 16) * 32 + 8 * ((v % 16) / 4) + 4 * (lane >> 5) + (v % 4);
         if (i < P && jcol < P) {
-            gram[static_cast<size_t>(i) * P + jcol] = acc[v];
-            gram[static_cast<size_t>(jcol) * P + i] = acc[v];
+            const float g = gram_entry(acc[v]);
+            gram[static_cast<size_t>(i) * P + jcol] = g;
+            gram[static_cast<size_t>(jcol) * P + i] = g;
         }
     }
 }
@@ -1265,9 +1475,18 @@ hipError_t launch_mmr_greedy(const float *gram, const float *scores, uint32_t P,
     const MmrEmit emit = emit_in ? *emit_in : MmrEmit{};
     if (emit.h_out && (n_queries != 1 || P == 0 || P > 1024))
         return hipErrorInvalidValue; // the emit tail exists in the register-resident single-pool kernel only
+    // RLR_MMR_GREEDY=reg: every candidate's position kept in registers (the kernel before the lazy tie-break)
+    static const char *g_env = getenv("RLR_MMR_GREEDY");
+    static const bool reg = g_env && !strcmp(g_env, "reg");
 #define RLR_MMR_REG(JV)                                                                                          \
-    hipLaunchKernelGGL(mmr_greedy_reg_kernel<JV>, dim3(n_queries), dim3(256), 0, s, gram, scores, P, k, lambda,   \
-                       out_order, out_mmr, out_n, sizes, emit)
+    do {                                                                                                         \
+        if (reg)                                                                                                 \
+            hipLaunchKernelGGL(mmr_greedy_reg_kernel<JV>, dim3(n_queries), dim3(256), 0, s, gram, scores, P, k, lambda, \
+                               out_order, out_mmr, out_n, sizes, emit);                                          \
+        else                                                                                                     \
+            hipLaunchKernelGGL(mmr_greedy_lazy_kernel<JV>, dim3(n_queries), dim3(256), 0, s, gram, scores, P, k, lambda, \
+                               out_order, out_mmr, out_n, sizes, emit);                                          \
+    } while (0)
     if (P == 0 || (P > 1024 && n_queries == 1 && !sizes))
         hipLaunchKernelGGL(mmr_greedy_kernel, dim3(1), dim3(64), lds, s, gram, scores, P, k, lambda, out_order, out_mmr,
                            out_n);

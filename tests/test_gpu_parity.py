@@ -406,7 +406,7 @@ def test_mmr_select_values_bit_exact(rlr, oracle):
     ix.close()
 
 
-@pytest.mark.parametrize("P", [129, 200, 256, 257, 300, 512, 513, 700, 768, 769, 1000, 1024])
+@pytest.mark.parametrize("P", [65, 129, 200, 256, 257, 283, 284, 300, 512, 513, 700, 768, 769, 1000, 1024])
 def test_mmr_single_pool_sizes_and_awkward_relevance(rlr, oracle, P):
     """pool sizes around every per-lane slot count of the register-resident greedy kernel, relevance with ties / zeros of
     both signs / non-finite values, duplicated rows (similarity ties), every lambda regime -- bit-equal picks and logged MMR
