@@ -512,6 +512,24 @@ __global__ __launch_bounds__(64) void gram_kernel(const float *__restrict__ pool
     gram[static_cast<size_t>(j) * P + i] = s;
 }
 
+// One staged float4 of a pool row (the vector path: dim % 4 == 0): rows as dense f32 (SRC 0, row = pool index), through the
+// index (SRC 1 f32, SRC 2 binary16 widened exactly; row = index row).  Unconditional -- the caller clamps row and column
+// into range and discards what it did not want -- so that a thread's loads are all in flight together: behind a
+// per-element `if` hipcc waited for every row-list entry and every row fragment one after the other.
+template <int SRC>
+__device__ inline float4 gram_load4(const float *pool, const void *rows, uint32_t pitch16, uint32_t dim, uint32_t row, uint32_t col)
+{
+    if constexpr (SRC == 2) {
+        const uint2 h = *reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(rows) + static_cast<size_t>(row) * pitch16 * 8 + col);
+        return make_float4(h2f(static_cast<uint16_t>(h.x)), h2f(static_cast<uint16_t>(h.x >> 16)), h2f(static_cast<uint16_t>(h.y)),
+                           h2f(static_cast<uint16_t>(h.y >> 16)));
+    } else if constexpr (SRC == 1) {
+        return *reinterpret_cast<const float4 *>(static_cast<const float *>(rows) + static_cast<size_t>(row) * pitch16 * 4 + col);
+    } else {
+        return *reinterpret_cast<const float4 *>(pool + static_cast<size_t>(row) * dim + col);
+    }
+}
+
 // Tiled Gram: a workgroup owns a 32 x 32 block of pairs (lower triangle of blocks only), stages
 // 64-column chunks of the 32 + 32 rows in LDS with coalesced loads, and every thread carries four
 // pairs (rows {ty, ty+16} x {tx, tx+16}: conflict-free LDS rows at a 68-float pitch) through the
@@ -560,8 +578,27 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
     // load latency per chunk used to sit between the two barriers)
     constexpr int kPre = 2 * kGT * (kGK / 4) / 256; // float4 per thread per chunk
     float4 pre[kPre];
+    // where thread t's u-th staged float4 comes from: the same row for every chunk (index rows looked up once)
+    uint32_t src_row[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const uint32_t r = (t + 256 * u) / (kGK / 4);
+        const uint32_t row = min(r >= kGT ? j0 + (r - kGT) : i0 + r, P - 1);
+        src_row[u] = SRC == 0 ? row : list[row];
+    }
     auto fetch = [&](uint32_t k0) {
         const uint32_t kc = min(static_cast<uint32_t>(kGK), dim - k0);
+        if (vec) {
+#pragma unroll
+            for (int u = 0; u < kPre; ++u) {
+                const uint32_t idx = t + 256 * u;
+                const uint32_t r = idx / (kGK / 4), c4 = idx % (kGK / 4);
+                const uint32_t row = r >= kGT ? j0 + (r - kGT) : i0 + r;
+                const float4 v = gram_load4<SRC>(pool, rows, pitch16, dim, src_row[u], min(k0 + c4 * 4, dim - 4));
+                pre[u] = (row < P && c4 * 4 < kc) ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
             const uint32_t idx = t + 256 * u;
@@ -571,28 +608,18 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
             if (row < P && c4 * 4 < kc) {
                 const uint32_t col = k0 + c4 * 4;
                 if constexpr (SRC == 2) {
-                    const uint16_t *src = static_cast<const uint16_t *>(rows) + static_cast<size_t>(list[row]) * pitch16 * 8 + col;
-                    if (vec) {
-                        const uint2 h = *reinterpret_cast<const uint2 *>(src);
-                        v = make_float4(h2f(static_cast<uint16_t>(h.x)), h2f(static_cast<uint16_t>(h.x >> 16)),
-                                        h2f(static_cast<uint16_t>(h.y)), h2f(static_cast<uint16_t>(h.y >> 16)));
-                    } else {
-                        v.x = h2f(src[0]);
-                        if (c4 * 4 + 1 < kc) v.y = h2f(src[1]);
-                        if (c4 * 4 + 2 < kc) v.z = h2f(src[2]);
-                        if (c4 * 4 + 3 < kc) v.w = h2f(src[3]);
-                    }
+                    const uint16_t *src = static_cast<const uint16_t *>(rows) + static_cast<size_t>(src_row[u]) * pitch16 * 8 + col;
+                    v.x = h2f(src[0]);
+                    if (c4 * 4 + 1 < kc) v.y = h2f(src[1]);
+                    if (c4 * 4 + 2 < kc) v.z = h2f(src[2]);
+                    if (c4 * 4 + 3 < kc) v.w = h2f(src[3]);
                 } else {
                     const float *src = SRC == 0 ? pool + static_cast<size_t>(row) * dim + col
-                                                : static_cast<const float *>(rows) + static_cast<size_t>(list[row]) * pitch16 * 4 + col;
-                    if (vec) {
-                        v = *reinterpret_cast<const float4 *>(src);
-                    } else {
-                        v.x = src[0];
-                        if (c4 * 4 + 1 < kc) v.y = src[1];
-                        if (c4 * 4 + 2 < kc) v.z = src[2];
-                        if (c4 * 4 + 3 < kc) v.w = src[3];
-                    }
+                                                : static_cast<const float *>(rows) + static_cast<size_t>(src_row[u]) * pitch16 * 4 + col;
+                    v.x = src[0];
+                    if (c4 * 4 + 1 < kc) v.y = src[1];
+                    if (c4 * 4 + 2 < kc) v.z = src[2];
+                    if (c4 * 4 + 3 < kc) v.w = src[3];
                 }
             }
             pre[u] = v;
@@ -616,7 +643,10 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const float *__restrict
         if (more)
             fetch(k0 + kGK);
         const uint32_t n4 = kc / 4;
-        // every sum is still the reference's strict left-to-right chain: k ascends, product rounded, then added
+        // every sum is still the reference's strict left-to-right chain: k ascends, product rounded, then added.
+        // (one pair per thread is one wave per SIMD for a single pool: unrolled, the LDS reads of eight steps in flight together)
+        constexpr int kUnroll = R == 1 ? 8 : 1;
+#pragma unroll kUnroll
         for (uint32_t c = 0; c < n4; ++c) {
             float4 xa[R], yb[R];
 #pragma unroll
@@ -1413,7 +1443,13 @@ static hipError_t launch_gram_src(const float *pool, uint32_t P, uint32_t dim, f
         // 16 x 16 (one pair per thread): 31 -> 17 us at 768-d.  The small tile wins until its blocks outnumber the
         // CUs about six times (measured: 800-row pools still, 1024-row pools no longer; 7 pools of 300 still).
         const uint32_t nb1 = (P + 15) / 16;
-        if (static_cast<uint64_t>(nb1) * (nb1 + 1) / 2 * n_queries <= 1536) {
+        static const bool short_chunks = getenv("RLR_GRAM_SHORT_CHUNKS") != nullptr;
+        if (static_cast<uint64_t>(nb1) * (nb1 + 1) / 2 * n_queries <= 512 && !short_chunks) {
+            // at most two blocks per CU: 384 columns per chunk, two rounds of loads per 768-d pool instead of six (10.3 against
+            // 11.9 us; before the staged loads were batched -- gram_load4 -- the same pool took 17.9)
+            hipLaunchKernelGGL((gram_tiled_kernel<1, SRC, 384>), dim3(nb1 * (nb1 + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P,
+                               dim, gram, rows, pitch16, list);
+        } else if (static_cast<uint64_t>(nb1) * (nb1 + 1) / 2 * n_queries <= 1536) {
             hipLaunchKernelGGL((gram_tiled_kernel<1, SRC, 128>), dim3(nb1 * (nb1 + 1) / 2, 1, n_queries), dim3(256), 0, s, pool, P,
                                dim, gram, rows, pitch16, list);
         } else {

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 rlr = importlib.import_module("rust-local-rag_amd")
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-ix = rlr.GpuIndex(768)
+DIM = int(sys.argv[3]) if len(sys.argv) > 3 else 768
+ix = rlr.GpuIndex(DIM)
 ix.fill_synthetic(20_000, seed=0x5EED0002, n_clusters=40)
 rng = np.random.default_rng(1)
 for i in range(200):
