@@ -1005,6 +1005,16 @@ __global__ __launch_bounds__(256) void batch_finish_kernel(const float4 *__restr
     // guard band below the k-th nominated score
     const float fk = key_score(static_cast<uint32_t>(s_c[k - 1] >> 32));
     const uint32_t key_lo = score_key(fk - two_eps);
+    // The candidates are the rows at or above the floor st.key_lo = (a sample rank's score) - 2 eps.  When that rank is the
+    // k-th, the k-th score of all rows cannot lie below it; run_batched takes a higher rank of a smaller sample (the floor
+    // then admits ~3 k rows instead of the sample having to be 4 x larger), and the rare query whose k-th nominated score
+    // ends up under that rank's score -- its band would reach below the floor, to rows that were never collected -- goes
+    // back to the caller.
+    if (key_lo < st[q].key_lo) {
+        if (threadIdx.x == 0)
+            status[q] = 2u;
+        return;
+    }
     for (uint32_t i = threadIdx.x; i < n_raw; i += 256)
         if (static_cast<uint32_t>(s_c[i] >> 32) >= key_lo)
             atomicMax(&s_band, i + 1);
@@ -1066,6 +1076,13 @@ __global__ __launch_bounds__(1024) void batch_band_kernel(uint64_t *__restrict__
     // the final sort by exact score do not depend on it)
     const float fk = key_score(lds_kth_key(s_c, n_raw, k, s_hist, s_sel, 1024));
     const uint32_t key_lo = score_key(fk - two_eps);
+    if (key_lo < st[q].key_lo) { // the band reaches below the floor the candidates were collected at (see batch_finish_kernel)
+        if (threadIdx.x == 0) {
+            status[q] = 2u;
+            st[q].pad = 0;
+        }
+        return;
+    }
     for (uint32_t i = threadIdx.x; i < n_raw; i += 1024) {
         const uint64_t v = s_c[i];
         if (static_cast<uint32_t>(v >> 32) >= key_lo) {

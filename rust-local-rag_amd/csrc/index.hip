@@ -1370,13 +1370,38 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
                            ix->pitch16 * 4 == ix->dim && !(ix->image_enabled && ix->d_image) && !env_is_one("RLR_NO_MULTI_SCAN");
     const float eps_nom = use_multi ? 0.5f * p.two_eps : nomination_eps(ix->dim, ix->dtype) * p.scale;
     const float two_eps = 2.0f * eps_nom;
-    // sample rows [0, S): large enough that the expected number of later rows above the sample's
-    // k-th score (k * N / S) stays well inside the per-query candidate capacity.
-    uint64_t S = (static_cast<uint64_t>(p.k) * n * 5 / 2 + fin_cap - 1) / fin_cap;
+    // Sample rows [0, S): the floor for the rest of the corpus is the sample's rank-th score, and S is large enough that
+    // the expected number of later rows above it (rank * N / S) stays well inside the per-query candidate capacity.
+    // rank = k needs no check afterwards (k sample rows sit at or above the floor) but a sample of k * N * 2.5 / capacity
+    // rows -- so large that a quarter of it used to be materialised and the rest run as a separate "bootstrap" launch with
+    // a per-query sort to tighten the floor (0.2 ms of a 4.4 ms batch of 256, 1.2 of 13.9 at 1024 x 308).  rank = k / 4
+    // gives the same floor from the quarter alone: the count of rows above it spreads more (relative deviation
+    // 1 / sqrt(rank): 3.3 k +- 0.65 k at rank 25 against a capacity of 8192), and the finish hands a query back when its
+    // k-th nominated score lies under the floor's rank (batch_band_kernel; essentially never: it takes fewer than k rows
+    // where ~3 k are expected).  RLR_BATCH_RANK_DIV=1 restores rank = k with the bootstrap.
+    static const uint32_t rank_div = [] {
+        const char *v = getenv("RLR_BATCH_RANK_DIV");
+        const long d = v ? strtol(v, nullptr, 10) : 4;
+        return static_cast<uint32_t>(d >= 1 && d <= 64 ? d : 4);
+    }();
+    uint32_t rank = std::max<uint32_t>(std::min<uint32_t>(p.k, 16), p.k / rank_div);
+    uint64_t S = (static_cast<uint64_t>(rank) * n * 5 / 2 + fin_cap - 1) / fin_cap;
     S = std::max<uint64_t>(S, std::min<uint64_t>(n, 65536));
     S = (S + 255) / 256 * 256;
-    if (S * 2 >= n || use_multi)
+    if (S * 2 >= n || use_multi) {
         S = n;
+        rank = p.k; // the sample is the corpus: its k-th score is the k-th score
+    } else {
+        // fewer than k rows above the floor <=> the sample holds `rank` of the corpus' best k - 1 rows, a Poisson(k S / N)
+        // count: keep the rank six deviations above that mean (it matters when the 65 536-row minimum makes the sample a
+        // large part of a small corpus; at 10 M rows the mean is 0.8)
+        const double mean_in_sample = static_cast<double>(p.k) * static_cast<double>(S) / n;
+        const uint32_t safe = static_cast<uint32_t>(std::ceil(mean_in_sample + 6.0 * std::sqrt(mean_in_sample) + 6.0));
+        rank = std::min<uint32_t>(p.k, std::max(rank, safe));
+        static const uint32_t forced = getenv("RLR_BATCH_RANK_FORCE") ? static_cast<uint32_t>(atoi(getenv("RLR_BATCH_RANK_FORCE"))) : 0;
+        if (forced) // tests: a rank low enough that queries ARE handed back (too few candidates, or a band below the floor)
+            rank = std::min<uint32_t>(p.k, forced);
+    }
     // Bootstrap: materialising and radix-selecting S rows per query costs 4 passes over nq x S floats
     // (2.4 GB for 1024 queries x 587 k rows).  When S is large, only a quarter of it (S1) goes that way;
     // its threshold filters the rows [S1, S) in the GEMM epilogue (about 3 k extra candidates), one sort
@@ -1384,7 +1409,7 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     // same threshold the full-size sample would have given.
     const uint64_t S2 = S;
     uint64_t S1 = std::max<uint64_t>(65536, (S2 / 4 + 255) / 256 * 256);
-    const bool bootstrap = S2 < n && S1 * 2 <= S2 && !getenv("RLR_BATCH_NO_BOOTSTRAP");
+    const bool bootstrap = rank_div == 1 && S2 < n && S1 * 2 <= S2 && !getenv("RLR_BATCH_NO_BOOTSTRAP");
     if (bootstrap)
         S = S1;
     const uint64_t s_stride = (S + 3) / 4 * 4;
@@ -1426,7 +1451,7 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
     uint32_t *h_stat = reinterpret_cast<uint32_t *>(h_st + c->bq_cap);
     for (uint32_t i = 0; i < nq; ++i) {
         std::memset(&h_st[i], 0, sizeof(SelectState));
-        h_st[i].k = std::min<uint32_t>(p.k, static_cast<uint32_t>(S));
+        h_st[i].k = std::min<uint32_t>(rank, static_cast<uint32_t>(S));
         h_st[i].cap = fin_cap;
     }
     const float *dq = c->d_query + static_cast<size_t>(q0) * ix->q_pitch;

@@ -803,6 +803,45 @@ def test_8bit_scan_kernels_agree(rlr, oracle):
         assert out.returncode == 0 and "agree" in out.stdout, (packed, out.stdout[-1000:], out.stderr[-3000:])
 
 
+def test_batched_floor_from_a_sample_rank_hands_back_what_it_cannot_certify(rlr, oracle):
+    """run_batched takes the floor for the corpus pass from a rank of the sample ABOVE the k-th (rank k/4 of a sample a
+    quarter the size); a query with fewer than k rows above that rank's score -- too few candidates, or a guard band that
+    would reach below the floor -- must come back through the single-query path with the oracle's answer.  The rank is
+    kept six deviations clear of that case, so it is forced low here (RLR_BATCH_RANK_FORCE, read once per process: a
+    child), with the default and with a wide guard band."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import importlib, numpy as np, sys; sys.path.insert(0, '.')\n"
+        "rlr = importlib.import_module('rust-local-rag_amd'); from oracle import oracle as O\n"
+        "n, dim, k = 200_000, 768, 100\n"
+        "rows = O.synth_rows(n, dim, seed=112)\n"
+        "ix = rlr.GpuIndex(dim); ix.fill_synthetic(n, seed=112)\n"
+        "qs = np.stack([O.normalize(O.synth_query(dim, seed=800 + i)) for i in range(24)])\n"
+        "back = []\n"
+        "for eps in (-1.0, 0.02):\n"
+        "    ix.profile_read(reset=True)\n"
+        "    r, c = ix.search_topk(qs, k, guard_eps=eps)\n"
+        "    p = ix.profile_read()\n"
+        "    assert p.n_batches == 1, p\n"
+        "    back.append(int(p.n_batch_fallbacks))\n"
+        "    for i in range(len(qs)):\n"
+        "        s = O.scan(rows, qs[i]); o = np.argsort(-s, kind='stable')[:k]\n"
+        "        assert np.array_equal(r[i], o.astype(np.uint64)) and np.array_equal(c[i].view(np.uint32), s[o].view(np.uint32)), (eps, i)\n"
+        "print('handed back', back)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for rank in ("8", "30", "0"):
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RLR_BATCH_RANK_FORCE=rank),
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "handed back" in out.stdout, (rank, out.stdout[-1000:], out.stderr[-3000:])
+        seen[rank] = eval(out.stdout.strip().splitlines()[-1].split("handed back", 1)[1])
+    assert seen["8"][0] == 24 and seen["8"][1] == 24, seen     # 8 x 3 rows above the floor's rank: every query goes back
+    assert 0 < seen["30"][0] <= 24, seen                        # about the mean of the sample's share of the best 99
+    assert seen["0"] == [0, 0], seen                            # the rank the library picks by itself
+
+
 def test_merge_topk_kernel_matches_torch_merge_and_global_oracle(rlr, oracle):
     """Four shards searched one after the other on the one GPU, their packed results laid out as an
     all-gather would deliver them, merged by rlr_merge_topk: must equal the global oracle and the
