@@ -9,9 +9,9 @@
       python profiles/summarize.py kernels <out tag> <kt dir> "<command>" <substr,substr,...> [--pmc dir ...]
       (counters are reported for the FIRST substring's kernel only)
       -> <out tag>_kernel_stats.csv, <out tag>_kernels.json
-      The --stats table lumps every dispatch of a kernel into one row, but a batch launches the same GEMM kernel over a short
-      row range (bootstrap) and over the rest of the corpus (the main pass the roofline claims are about) with the SAME
-      persistent grid.  So the per-dispatch trace (<kt dir>/*_kernel_trace.csv) is also read: it is cut into batches at every
+      The --stats table lumps every dispatch of a kernel into one row, but a batch may launch the same GEMM kernel more than
+      once with the SAME persistent grid (until late in round 3: over a short row range -- the "bootstrap" -- and over the rest
+      of the corpus, the main pass the roofline claims are about; RLR_BATCH_RANK_DIV=1 still does).  So the per-dispatch trace (<kt dir>/*_kernel_trace.csv) is also read: it is cut into batches at every
       dispatch of the anchor kernel (prep_queries_kernel: the first launch of a batch) and the FIRST substring's kernel is
       reported per ordinal inside its batch ("dispatch_groups": calls / avg / min / max of the 1st, 2nd, ... launch per
       batch); the counter passes are grouped the same way ("counters_by_ordinal").
