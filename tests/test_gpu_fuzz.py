@@ -4,6 +4,7 @@ against the oracle.  Found the sign-of-zero difference in the logged MMR value a
 Every fuzzer runs a fixed NUMBER of cases from its seed (not a wall-clock budget), so the case set is the same on
 every box.  Standalone: python tests/test_gpu_fuzz.py <cases> [seed]."""
 import importlib
+import os
 import sys
 import time
 
@@ -224,6 +225,70 @@ def fuzz_multi(n_target: int, seed0: int):
     return n_cases
 
 
+def fuzz_mmr(n_target: int, seed0: int):
+    """MMR alone, aimed at the greedy kernel's tie-break and at the Gram kernels: pools of 1..1024 candidates drawn (with heavy
+    repetition) from a handful of distinct rows, so similarities and MMR values tie by the dozen; relevance from a small set of
+    values incl. zeros of both signs, non-finite and huge ones; every lambda regime; f32 and binary16 rows, row lengths that are
+    and are not multiples of 4; single pools and batches of pools (ragged sizes) -- picks and logged values bit-equal to the
+    oracle's literal loop."""
+    rlr = importlib.import_module("rust-local-rag_amd")
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(seed0)
+    n_cases = 0
+    while n_cases < n_target:
+        dim = int(rng.choice([8, 32, 96, 100, 128, 257])); f16 = bool(rng.random() < 0.3) and dim % 8 == 0
+        n = int(rng.choice([40, 300, 1500]))
+        seed = int(rng.integers(1, 1 << 30))
+        rows = O.synth_rows(n, dim, seed=seed, n_clusters=int(rng.choice([0, 2, 9])), f16=f16)
+        distinct = int(rng.choice([1, 3, 17, n]))            # how many different rows the corpus really has
+        if distinct < n:
+            rows = rows[rng.integers(0, distinct, size=n)].copy()
+        if rng.random() < 0.3:
+            rows[rng.integers(0, n, 2)] = 0                  # zero rows: every similarity +0 or -0
+        if not f16 and rng.random() < 0.2:
+            rows[rng.integers(0, n), rng.integers(0, dim)] = np.inf   # non-finite similarities
+            rows[rng.integers(0, n), rng.integers(0, dim)] = np.nan
+        ix = rlr.GpuIndex(dim, "f16" if f16 else "f32"); ix.upload(rows)
+        stored = ix.fetch_rows(np.arange(n))
+        for _ in range(4):
+            P = int(rng.choice([1, 2, 3, 63, 64, 65, 128, 129, 300, 320, 321, 512, 513, 1000, 1024]))
+            pool = rng.integers(0, n, size=P).astype(np.uint64)      # (repeats allowed: exact duplicate candidates)
+            levels = np.array([0.0, -0.0, 0.25, 0.5, 0.5, 1.0, -1.0, 3.0e38, -3.0e38, 1e-40], np.float32)
+            sc = levels[rng.integers(0, int(rng.choice([2, 4, len(levels)])), size=P)].astype(np.float32)
+            if rng.random() < 0.5:
+                sc = (rng.standard_normal(P) * 0.3).astype(np.float32)
+                sc[rng.integers(0, P, max(P // 8, 1))] = sc[0]
+            if rng.random() < 0.3 and P > 3:
+                sc[rng.integers(1, P, 3)] = [np.nan, np.inf, -np.inf]
+            lam = float(rng.choice([0.0, 0.3, 0.5, 0.7, 1.0]))
+            kk = int(rng.choice([0, 1, 2, min(P, 100), P, P + 5]))
+            o, m = ix.mmr_select(pool, sc, kk, lam)
+            wo, wm = O.mmr(stored[pool.astype(np.int64)], sc, kk, lam)
+            if not (np.array_equal(o, wo) and np.array_equal(bits(m[1:]), bits(wm[1:]))):
+                print("MMR MISMATCH", dict(dim=dim, f16=f16, n=n, seed=seed, distinct=distinct, P=P, kk=kk, lam=lam, case=n_cases)); raise AssertionError("see the MISMATCH line above")
+        # a batch of pools with ragged sizes (the batched Gram kernels; binary16 rows from 16 pools up take the f32 matrix cores)
+        m_pools = int(rng.choice([3, 9, 17])); Pb = int(rng.choice([5, 64, 130, 308]))
+        prow = rng.integers(0, n, size=(m_pools, Pb)).astype(np.uint64)
+        psc = (rng.integers(0, 5, size=(m_pools, Pb)) * np.float32(0.25)).astype(np.float32)
+        sizes = rng.integers(0, Pb + 1, size=m_pools).astype(np.uint32); sizes[0] = Pb
+        lam = float(rng.choice([0.0, 0.4, 1.0])); kk = int(rng.choice([1, 20, Pb]))
+        ob, mb, nb = ix.mmr_select_batch(prow, psc, sizes, kk, lam)
+        for q in range(m_pools):
+            sz = int(sizes[q])
+            wo, wm = O.mmr(stored[prow[q, :sz].astype(np.int64)], psc[q, :sz], kk, lam) if sz else (np.zeros(0, np.uint32), np.zeros(0, np.float32))
+            if not (int(nb[q]) == len(wo) and np.array_equal(ob[q, :nb[q]], wo) and np.array_equal(bits(mb[q, 1:nb[q]]), bits(wm[1:]))):
+                print("BATCH MMR MISMATCH", dict(dim=dim, f16=f16, n=n, seed=seed, distinct=distinct, Pb=Pb, q=q, sz=sz, kk=kk, lam=lam, case=n_cases)); raise AssertionError("see the MISMATCH line above")
+        ix.close(); n_cases += 1
+        if n_cases % 50 == 0 and os.environ.get("RLR_FUZZ_PROGRESS"):
+            print("mmr fuzz: %d corpora" % n_cases, flush=True)   # (a long run that prints nothing looks hung)
+    return n_cases
+
+
+def test_fuzz_mmr_ties_and_awkward_pools():
+    assert fuzz_mmr(40, 77001) == 40
+
+
 def test_fuzz_multi_shard_index():
     assert fuzz_multi(30, 808) == 30
 
@@ -398,6 +463,9 @@ if __name__ == "__main__":
     sys.path.insert(0, ".")
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "mmr":
+        print("mmr fuzz ok: %d corpora" % fuzz_mmr(cases, seed))
+        sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == "multi":
         print("multi-shard fuzz ok: %d corpora" % fuzz_multi(cases, seed))
         sys.exit(0)
