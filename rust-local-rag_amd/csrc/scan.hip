@@ -454,11 +454,32 @@ ScanPlan plan_scan(const ScanArgs &a)
     group = (group / p.r) * p.r;
     if (group == 0)
         group = p.r;
+    // One workgroup per CU -- one wave per SIMD -- for the row shapes where a wave's own loads in flight (R rows x 3-6 KB) cover
+    // the memory latency: fewer, longer streams reach 0.875 of the HBM peak on 10 M x 768 f32 where four workgroups per CU of
+    // 8-row steps reach 0.846 (scratch/sweep_scan_10m.sh, four interleaved repeats: 4.34-4.41 against 4.53-4.56 ms), and the
+    // gain grows as the corpus shrinks (1 M rows 434 against 468 us, 200 k rows 91 against 120, 100 k rows 51 against 58).
+    // 1536-d rows (two-row steps): f32 7.1 against 6.6 TB/s, binary16 6.85 against 6.6.  Every other shape measured
+    // (256 / 512 / 1024 / 2048-d, the packed and the generic kernel) is level or loses with one wave per SIMD
+    // (scratch/sweep_scan_shapes.sh) and keeps the settings above.  Only when RLR_SCAN_VARIANT leaves all three fields open.
+    if (r_code == 0 && ((v >> 8) & 0xFF) == 0 && ((v >> 16) & 0xFF) == 0) {
+        const uint32_t elems = a.dtype == RLR_F16 ? a.pitch16 * 8 : a.pitch16 * 4;
+        if (elems == a.dim && a.dtype == RLR_F32 && a.pitch16 == 192) {
+            p.r = 4;
+            blocks_per_cu = 1;
+            group = 8;
+        } else if (elems == a.dim && a.dtype == RLR_F32 && a.pitch16 == 384) {
+            blocks_per_cu = 1;
+            group = 8;
+        } else if (elems == a.dim && a.dtype == RLR_F16 && a.pitch16 == 192) {
+            blocks_per_cu = 1;
+            group = 16;
+        }
+    }
     p.group_rows = group;
     const uint32_t n_groups = (a.n_rows + group - 1) / group;
     uint32_t blocks = (n_groups + 3) / 4;
-    if (blocks > max_blocks)
-        blocks = max_blocks;
+    if (blocks > static_cast<uint32_t>(a.n_cu) * blocks_per_cu)
+        blocks = static_cast<uint32_t>(a.n_cu) * blocks_per_cu;
     if (blocks == 0)
         blocks = 1;
     p.blocks = blocks;

@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 rlr = importlib.import_module("rust-local-rag_amd")
 N = rlr._native
-n, dim, k, lam = 100_000, 768, (int(sys.argv[1]) if len(sys.argv) > 1 else 100), 0.3
+n, dim, k, lam = (int(sys.argv[2]) if len(sys.argv) > 2 else 100_000), 768, (int(sys.argv[1]) if len(sys.argv) > 1 else 100), 0.3
 ix = rlr.GpuIndex(dim)
 ix.fill_synthetic(n, seed=0x5EED0002, n_clusters=200)
 rng = np.random.default_rng(1)
