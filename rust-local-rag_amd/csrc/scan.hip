@@ -461,6 +461,9 @@ ScanPlan plan_scan(const ScanArgs &a)
     // 1536-d rows (two-row steps): f32 7.1 against 6.6 TB/s, binary16 6.85 against 6.6.  Every other shape measured
     // (256 / 512 / 1024 / 2048-d, the packed and the generic kernel) is level or loses with one wave per SIMD
     // (scratch/sweep_scan_shapes.sh) and keeps the settings above.  Only when RLR_SCAN_VARIANT leaves all three fields open.
+    // [Tried on top: the wave's row stream software-pipelined (the next step's loads issued before the current step is
+    // reduced, 4..8 rows in flight all the time) -- 4.61 ms whatever the step, group or workgroup count, against 4.45 on the
+    // same box: the bursts with pauses in between suit the memory system better than a steady deeper queue.  Not kept.]
     if (r_code == 0 && ((v >> 8) & 0xFF) == 0 && ((v >> 16) & 0xFF) == 0) {
         const uint32_t elems = a.dtype == RLR_F16 ? a.pitch16 * 8 : a.pitch16 * 4;
         if (elems == a.dim && a.dtype == RLR_F32 && a.pitch16 == 192) {
