@@ -1325,15 +1325,16 @@ hipError_t launch_scan_image(const void *image, uint32_t n_rows, uint32_t dim, c
         return hipSuccess;
     const uint32_t n_chunks = dim / 64;
     const uint32_t n_slots = ((n_rows + kBM - 1) / kBM) * 8;
-    // 3 chunks in flight x 4 workgroups per CU: 6.42 TB/s at 10 M x 768; the other combinations of 2-6 chunks and
-    // 2-16 workgroups per CU measured 6.25-6.43 (scratch/sweep_img.sh)
-    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_slots + 3) / 4, static_cast<uint32_t>(n_cu) * 4));
+    // 4 chunks in flight x ONE workgroup per CU: 6.65-6.96 TB/s at 10 M x 768 (three interleaved repeats; 3 chunks x 4 workgroups,
+    // the round-2 setting: 6.28-6.34 on the same box; scratch/sweep_img2.sh) -- like the f32 scan, one wave per SIMD streams better
+    // than four (scan.hip, plan_scan); round 2 had only swept 2-16 workgroups per CU (6.25-6.43, scratch/sweep_img.sh)
+    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_slots + 3) / 4, static_cast<uint32_t>(n_cu)));
     const size_t lds = static_cast<size_t>(n_chunks) * 8 * 16 + kHistBins * sizeof(uint32_t);
     static const int tune = [] {
         const char *v = getenv("RLR_SCAN_IMAGE_VARIANT"); // chunks in flight | workgroups per CU << 8
         return v ? static_cast<int>(strtol(v, nullptr, 0)) : 0;
     }();
-    const int nc = (tune & 0xFF) ? (tune & 0xFF) : 3;
+    const int nc = (tune & 0xFF) ? (tune & 0xFF) : 4;
     uint32_t grid = blocks;
     if ((tune >> 8) & 0xFF)
         grid = std::max<uint32_t>(1, std::min<uint32_t>((n_slots + 3) / 4, static_cast<uint32_t>(n_cu) * ((tune >> 8) & 0xFF)));

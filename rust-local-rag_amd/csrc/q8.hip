@@ -352,7 +352,7 @@ hipError_t launch_q8_scan(const void *q8, const float *scale, uint32_t n_rows, u
                            hist, n_rows, dim, pg);                                                                   \
         return hipGetLastError();                                                                                    \
     }
-        RLR_Q8_PACKED_CASE(4, 3, 2, 32, 4) // 768-d: 4 rows = 3 loads, 8 rows per iteration
+        RLR_Q8_PACKED_CASE(4, 3, 2, 32, 2) // 768-d: 4 rows = 3 loads, 8 rows per iteration; 2 workgroups per CU 1.19 ms, 3-4: 1.22-1.26, 1: 1.73
         RLR_Q8_PACKED_CASE(8, 3, 1, 32, 4) // 384-d: 8 rows = 3 loads
         RLR_Q8_PACKED_CASE(2, 3, 4, 32, 4) // 1536-d: 2 rows = 3 loads
         RLR_Q8_PACKED_CASE(2, 1, 8, 32, 8) // 512-d: 2 rows per load, 16 rows per iteration
