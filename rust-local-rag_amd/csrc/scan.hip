@@ -635,9 +635,14 @@ bool launch_scan_multi(const ScanArgs &a, uint32_t q_pitch, uint32_t n_queries, 
     int ch = 0;
     if (a.dtype != RLR_F32 || n_queries < 2 || n_queries > 8 || !fixed_shape(a, &ch) || ch > 4)
         return false;
-    const uint32_t group = 32;
+    static const int tune = [] {
+        const char *v = getenv("RLR_SCAN_MULTI_VARIANT"); // workgroups per CU | rows per group << 8 (A/B)
+        return v ? static_cast<int>(strtol(v, nullptr, 0)) : 0;
+    }();
+    const uint32_t group = ((tune >> 8) & 0xFF) ? static_cast<uint32_t>((tune >> 8) & 0xFE) : 32u;
+    const uint32_t wgs = (tune & 0xFF) ? static_cast<uint32_t>(tune & 0xFF) : 4u;
     const uint32_t n_groups = (a.n_rows + group - 1) / group;
-    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_groups + 3) / 4, static_cast<uint32_t>(a.n_cu) * 4));
+    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_groups + 3) / 4, static_cast<uint32_t>(a.n_cu) * wgs));
     const float4 *rows = static_cast<const float4 *>(a.rows);
 #define RLR_MULTI(CHV, QV)                                                                                     \
     hipLaunchKernelGGL((scan_multi_kernel<CHV, QV>), dim3(blocks), dim3(256), 0, s, rows, a.query, q_pitch,    \
