@@ -67,6 +67,8 @@ def fuzz(n_target: int, seed0: int):
             if not (np.array_equal(o, wo) and np.array_equal(bits(m[1:]), bits(wm[1:]))):
                 print("MMR MISMATCH", dict(dim=dim, dtype=dtype, n=n, seed=seed, P=P, kk=kk, lam=lam)); raise AssertionError("see the MISMATCH line above")
         ix.close(); n_cases += 1
+        if n_cases % 100 == 0 and os.environ.get("RLR_FUZZ_PROGRESS"):
+            print("fuzz: %d corpora" % n_cases, flush=True)
     return n_cases, n_q
 
 
