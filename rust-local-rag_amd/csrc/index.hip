@@ -820,13 +820,19 @@ __global__ void emit_kernel(const uint64_t *__restrict__ packed, uint32_t n, uin
 //   info[0] = pool size, info[1] = status (0 ok, 1 guard-band overflow upstream, 2 boundary tie)
 constexpr uint32_t kPoolMax = 1024, kPoolFetchMax = kPoolMax + 8;
 
-__global__ __launch_bounds__(1024) void pool_prepare_kernel(const uint64_t *__restrict__ packed, uint32_t fetch, uint32_t need,
-                                                            uint32_t n_rows, float w_e, float w_l,
+// FROM_CANDIDATES: `packed` is the re-score's unordered candidate list (st->n_cand entries) instead of sort_emit_kernel's
+// output -- the `fetch` best are ranked here (the same rank sort over the same unique keys), one launch and one trip through
+// memory less per search (6.5 + ~2 us of config 2's 160).  More than 1024 candidates (a dense band) report status 1 and
+// the host takes the two-call path, as for a guard-band overflow.
+template <bool FROM_CANDIDATES>
+__global__ __launch_bounds__(1024) void pool_prepare_kernel(const uint64_t *__restrict__ packed, const SelectState *__restrict__ st,
+                                                            uint32_t fetch, uint32_t need, uint32_t n_rows, float w_e, float w_l,
                                                             uint32_t *__restrict__ list, float *__restrict__ comb,
                                                             float *__restrict__ cosv, uint32_t *__restrict__ info)
 {
     __shared__ uint64_t s_key[kPoolFetchMax];
     __shared__ float s_c[kPoolFetchMax], s_e[kPoolFetchMax];
+    __shared__ uint64_t s_raw[FROM_CANDIDATES ? 1024 : 1], s_best[FROM_CANDIDATES ? kPoolFetchMax : 1];
     __shared__ uint32_t s_got;
     __shared__ float s_cneed;
     const uint32_t t = threadIdx.x;
@@ -834,10 +840,31 @@ __global__ __launch_bounds__(1024) void pool_prepare_kernel(const uint64_t *__re
         s_got = 0;
         s_cneed = 0.0f;
     }
+    bool overflow;
+    if constexpr (FROM_CANDIDATES) {
+        const uint32_t n_raw = st->n_cand;
+        overflow = n_raw > st->cap || n_raw > 1024;
+        if (!overflow) {
+            if (t < n_raw)
+                s_raw[t] = packed[t];
+            for (uint32_t i = min(n_raw, fetch) + t; i < fetch; i += 1024)
+                s_best[i] = 0ull; // (valid entries are a prefix, zeros behind: what sort_emit_kernel writes)
+            __syncthreads();
+            if (t < n_raw) {
+                const uint64_t mine = s_raw[t];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < n_raw; ++j)
+                    rank += s_raw[j] > mine;
+                if (rank < fetch)
+                    s_best[rank] = mine;
+            }
+        }
+    } else {
+        overflow = packed[0] == ~0ull;
+    }
     __syncthreads();
-    const bool overflow = packed[0] == ~0ull;
     for (uint32_t i = t; i < fetch; i += 1024) {
-        const uint64_t p = overflow ? 0ull : packed[i];
+        const uint64_t p = overflow ? 0ull : (FROM_CANDIDATES ? s_best[i] : packed[i]);
         uint64_t key = 0;
         if (p != 0) { // valid entries are a prefix: (score desc, row asc), padding zeros behind
             const float e = key_score(static_cast<uint32_t>(p >> 32));
@@ -1194,7 +1221,7 @@ int32_t check_hist_assert(Ctx *c)
 //   -> sort + emit (+ candidate count into *d_meta_q).
 // The context's histograms are zero on entry (cleared at creation and by every re-score).
 hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint64_t *d_out_q, uint64_t *d_meta_q,
-                         bool timed)
+                         bool timed, bool emit = true)
 {
     hipStream_t s = c->stream;
     hipError_t e;
@@ -1245,8 +1272,10 @@ hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p
         e = hipMemsetAsync(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), s);
     }
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rlr::sort_emit_kernel, dim3(1), dim3(1024), 0, s, c->d_packed, st, d_out_q, p.k, d_meta_q, p.unordered);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (emit) { // (a caller that orders the re-scored candidates itself -- pool_prepare_kernel<true> -- skips this launch)
+        hipLaunchKernelGGL(rlr::sort_emit_kernel, dim3(1), dim3(1024), 0, s, c->d_packed, st, d_out_q, p.k, d_meta_q, p.unordered);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if (timed && (e = hipEventRecord(c->ev[3], s)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -2420,10 +2449,16 @@ int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uin
     const bool timed = ix->profiling;
     RLR_HIP(hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s));
     uint64_t *d_meta = c->d_out + fetch;
-    RLR_HIP(enqueue_query(ix, c, 0, p, c->d_out, d_meta, timed));
+    static const bool two_launches = getenv("RLR_POOL_AFTER_SORT") != nullptr; // A/B: sort_emit, then the pool from its output
+    const bool from_candidates = fetch <= 512 && !two_launches;                // (the band of a larger fetch rarely fits 1024)
+    RLR_HIP(enqueue_query(ix, c, 0, p, c->d_out, d_meta, timed, /*emit=*/!from_candidates));
     if (timed) RLR_HIP(hipEventRecord(c->bev[0], s));
-    hipLaunchKernelGGL(rlr::pool_prepare_kernel, dim3(1), dim3(1024), 0, s, c->d_out, fetch, need, n, w_embedding, w_lexical,
-                       c->d_list, d_comb, d_cos, d_info);
+    if (from_candidates)
+        hipLaunchKernelGGL(rlr::pool_prepare_kernel<true>, dim3(1), dim3(1024), 0, s, c->d_packed, c->d_state, fetch, need, n,
+                           w_embedding, w_lexical, c->d_list, d_comb, d_cos, d_info);
+    else
+        hipLaunchKernelGGL(rlr::pool_prepare_kernel<false>, dim3(1), dim3(1024), 0, s, c->d_out, c->d_state, fetch, need, n,
+                           w_embedding, w_lexical, c->d_list, d_comb, d_cos, d_info);
     RLR_HIP(hipGetLastError());
     RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
     rlr::MmrEmit emit; // the greedy kernel writes the picks into the pinned block itself

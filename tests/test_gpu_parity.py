@@ -323,6 +323,25 @@ def test_config2_search_with_diversity_at_100k_matches_oracle(rlr, oracle):
     eng.close()
 
 
+def test_search_with_diversity_dense_band_goes_back_to_the_two_call_path(rlr, oracle):
+    """The fused search -> pool -> MMR enqueue orders the re-scored candidates inside pool_prepare_kernel (no sort_emit
+    launch) when they are at most 1024; a band that holds more -- here 1500 copies of the row closest to the query --
+    reports status 1 and the host takes the two-call path: same answer as the oracle either way."""
+    n, dim = 6000, 768
+    rows = oracle.synth_rows(n, dim, seed=515, n_clusters=4)
+    q = oracle.synth_query(dim, seed=516)
+    best = int(np.argmax(oracle.scan(rows, oracle.normalize(q))))
+    rows[100:1600] = rows[best]                                 # 1500 exact duplicates: one cosine, 1500 candidates in the band
+    eng, _ = build_engine(rlr, rows)
+    stored = eng.index.fetch_rows(np.arange(n))
+    for k, lam in ((10, 0.3), (100, 0.7), (5, 0.0)):
+        got = eng.search_with_diversity(q, k, lam)
+        wr, wc, we, _ = oracle.search_with_diversity(stored, q, k, lam)
+        assert [g.row for g in got] == list(wr), (k, lam)
+        assert np.array_equal(bits([g.score for g in got]), bits(wc)) and np.array_equal(bits([g.embedding_score for g in got]), bits(we))
+    eng.close()
+
+
 def _search_diverse(rlr, ix, qn, pool, k, lam, w_e=0.7, w_l=0.3):
     import ctypes as C
     N = rlr._native
