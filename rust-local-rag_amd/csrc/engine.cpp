@@ -338,17 +338,32 @@ int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *qu
         rlr::HybridTicket *ticket = nullptr;
         int32_t fb = 0;
         bool sampled_gave_up = false;
-        st = rlr::search_hybrid_begin(idx, q.data(), nd, top_k, diversity_factor, diversify ? 1 : 0, w.embedding, w.lexical,
-                                      std::min<uint32_t>(limit, RLR_LEXICAL_MAX_LIMIT), -1.0f, &ticket, &fb);
-        if (st != RLR_OK)
-            return st;
-        if (!fb) {
+        struct BesideScan { // the BM25 chain goes onto its stream as soon as the scan is queued (search_hybrid_begin calls back)
+            rlr_lexical *lex;
+            const char *tokens;
+            size_t len;
+            uint32_t limit;
             rlr::LexPending lp;
-            st = rlr::lexical_enqueue(lex, query_tokens, tokens_len, limit, &lp, /*need_sorted=*/false, /*exact_passes=*/false);
-            if (st != RLR_OK) {
-                rlr::search_hybrid_abort(ticket);
-                return st;
-            }
+            bool queued = false;
+        } beside{lex, query_tokens, tokens_len, limit, {}, false};
+        st = rlr::search_hybrid_begin(
+            idx, q.data(), nd, top_k, diversity_factor, diversify ? 1 : 0, w.embedding, w.lexical,
+            std::min<uint32_t>(limit, RLR_LEXICAL_MAX_LIMIT), -1.0f, &ticket, &fb,
+            [](void *a) -> int32_t {
+                BesideScan *b = static_cast<BesideScan *>(a);
+                const int32_t e = rlr::lexical_enqueue(b->lex, b->tokens, b->len, b->limit, &b->lp, /*need_sorted=*/false,
+                                                       /*exact_passes=*/false);
+                b->queued = e == RLR_OK;
+                return e;
+            },
+            &beside);
+        if (st != RLR_OK) {
+            if (beside.queued) // the index side failed behind it (begin drained its own stream): hand the workspace back
+                rlr::lexical_finish(&beside.lp, false);
+            return st;
+        }
+        if (!fb) {
+            rlr::LexPending &lp = beside.lp;
             const uint32_t n_res = diversify ? static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(top_k, 1u), nd)) : nd;
             std::vector<uint64_t> rows(n_res);
             std::vector<float> cosv(n_res), sc(n_res), lx(n_res);

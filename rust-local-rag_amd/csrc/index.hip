@@ -1220,14 +1220,14 @@ int32_t check_hist_assert(Ctx *c)
 //   folded in) -> LDS-staged reference-order re-score (clears the histograms for the next query)
 //   -> sort + emit (+ candidate count into *d_meta_q).
 // The context's histograms are zero on entry (cleared at creation and by every re-score).
-hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint64_t *d_out_q, uint64_t *d_meta_q,
-                         bool timed, bool emit = true)
+// (in two halves, so that a caller with work for ANOTHER stream -- the BM25 kernels of a text search -- can launch it right
+// behind the scan instead of behind all five launches: enqueue_query_scan, then enqueue_query_rest)
+hipError_t enqueue_query_scan(rlr_index *ix, Ctx *c, uint32_t qi, bool timed)
 {
     hipStream_t s = c->stream;
     hipError_t e;
     const uint32_t n = static_cast<uint32_t>(ix->n_rows);
-    uint32_t *hist1 = c->d_hist, *hist2 = c->d_hist + kHistBins;
-    SelectState *st = c->d_state + qi;
+    uint32_t *hist1 = c->d_hist;
     const float *dq = c->d_query + static_cast<size_t>(qi) * ix->q_pitch;
 
     if (c->h_assert) {
@@ -1256,6 +1256,20 @@ hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p
         e = launch_scan(sa, s);
     if (e != hipSuccess) return e;
     if (timed && (e = hipEventRecord(c->ev[1], s)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+hipError_t enqueue_query_rest(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint64_t *d_out_q, uint64_t *d_meta_q,
+                              bool timed, bool emit = true)
+{
+    hipStream_t s = c->stream;
+    hipError_t e;
+    const uint32_t n = static_cast<uint32_t>(ix->n_rows);
+    uint32_t *hist1 = c->d_hist, *hist2 = c->d_hist + kHistBins;
+    SelectState *st = c->d_state + qi;
+    const float *dq = c->d_query + static_cast<size_t>(qi) * ix->q_pitch;
+    const bool q8 = scan_over_q8(ix);
+    const bool img = !q8 && scan_over_image(ix);
     if ((e = launch_hist2_find1(c->d_scores, n, hist1, hist2, st, p.k, p.cap, ix->n_cu, s)) != hipSuccess) return e;
     const float band = q8 ? q8_two_eps(ix, qi < c->q_norm.size() ? c->q_norm[qi] : 1.0f, p.two_eps * 0.5f)
                           : (img ? p.two_eps_img : p.two_eps);
@@ -1278,6 +1292,13 @@ hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p
     }
     if (timed && (e = hipEventRecord(c->ev[3], s)) != hipSuccess) return e;
     return hipSuccess;
+}
+
+hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint64_t *d_out_q, uint64_t *d_meta_q,
+                         bool timed, bool emit = true)
+{
+    const hipError_t e = enqueue_query_scan(ix, c, qi, timed);
+    return e != hipSuccess ? e : enqueue_query_rest(ix, c, qi, p, d_out_q, d_meta_q, timed, emit);
 }
 
 // Large-candidate path for one query whose band overflowed the LDS sort (massive ties /
@@ -2536,7 +2557,7 @@ struct HybridTicket {
 
 static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t need_in, uint32_t k, float lambda, int32_t diversify,
                                  float w_embedding, float w_lexical, uint32_t n_lex_bound, float guard_eps, HybridTicket **out,
-                                 int32_t *fallback)
+                                 int32_t *fallback, int32_t (*behind_scan)(void *) = nullptr, void *behind_scan_arg = nullptr)
 {
     *out = nullptr;
     *fallback = 0;
@@ -2609,7 +2630,13 @@ static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t nee
     } drain{s};
     RLR_HIP(hipMemcpyAsync(c->d_query, h_q, t->q_bytes, hipMemcpyHostToDevice, s));
     uint64_t *d_meta = c->d_out + fetch;
-    RLR_HIP(enqueue_query(ix, c, 0, p, c->d_out, d_meta, t->timed));
+    // the scan first; then whatever the caller runs beside it (the BM25 chain on its own stream: about as long as scan +
+    // select + re-score + sort, so it must not wait for the host to have launched those -- it used to start 39 us behind the
+    // scan and was the critical path by as much); then the four launches that wait for the scan anyway
+    RLR_HIP(enqueue_query_scan(ix, c, 0, t->timed));
+    if (behind_scan)
+        RLR_TRY(behind_scan(behind_scan_arg));
+    RLR_HIP(enqueue_query_rest(ix, c, 0, p, c->d_out, d_meta, t->timed));
     if (t->timed) RLR_HIP(hipEventRecord(c->bev[0], s));
     drain.armed = false;
     *out = t.release();
@@ -2734,10 +2761,10 @@ static int32_t hybrid_finish_impl(HybridTicket *ticket, const HybridLexSrc &src,
 
 int32_t search_hybrid_begin(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
                             float w_embedding, float w_lexical, uint32_t n_lex_bound, float guard_eps, HybridTicket **ticket,
-                            int32_t *fallback)
+                            int32_t *fallback, int32_t (*behind_scan)(void *), void *behind_scan_arg)
 {
     return hybrid_begin_impl(ix, query, need, k, lambda, diversify, w_embedding, w_lexical, n_lex_bound, guard_eps, ticket,
-                             fallback);
+                             fallback, behind_scan, behind_scan_arg);
 }
 
 int32_t search_hybrid_finish(HybridTicket *ticket, const LexPending *lex, uint64_t *rows_out, float *cos_out, float *score_out,

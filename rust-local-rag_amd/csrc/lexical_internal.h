@@ -47,9 +47,11 @@ void lexical_finish(LexPending *p, bool ok);
 // covered by the fused kernels, no ticket); finish joins `lex` (null or limit 0: no lexical pair) by event, enqueues
 // blend .. results, synchronises and consumes the ticket; abort drains and frees a ticket that will not be finished.
 struct HybridTicket;
+// behind_scan (may be null): called once the scan is queued and before the select .. sort launches are -- the place to launch
+// work for another stream that should run beside the scan; not called when *fallback != 0; its error is begin's error.
 int32_t search_hybrid_begin(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
                             float w_embedding, float w_lexical, uint32_t n_lex_bound, float guard_eps, HybridTicket **ticket,
-                            int32_t *fallback);
+                            int32_t *fallback, int32_t (*behind_scan)(void *) = nullptr, void *behind_scan_arg = nullptr);
 int32_t search_hybrid_finish(HybridTicket *ticket, const LexPending *lex, uint64_t *rows_out, float *cos_out, float *score_out,
                              float *lex_out, uint32_t *n_out, int32_t *fallback);
 void search_hybrid_abort(HybridTicket *ticket);

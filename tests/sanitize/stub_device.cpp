@@ -183,7 +183,7 @@ int32_t lexical_score_exact(rlr_lexical *lx, const char *t, size_t len, uint32_t
     return rlr_lexical_score(lx, t, len, limit, rows, scores, n_out);
 }
 int32_t search_hybrid_begin(rlr_index *, const float *, uint32_t, uint32_t, float, int32_t, float, float, uint32_t, float,
-                            HybridTicket **ticket, int32_t *fallback)
+                            HybridTicket **ticket, int32_t *fallback, int32_t (*)(void *), void *)
 {
     *ticket = nullptr;
     *fallback = 1;
