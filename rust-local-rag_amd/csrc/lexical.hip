@@ -478,6 +478,12 @@ __global__ __launch_bounds__(1024) void lex_final_kernel(const uint64_t *__restr
         *out_n = want;
 }
 
+__global__ __launch_bounds__(1024) void lex_zero_words_kernel(uint32_t *__restrict__ p, uint32_t n)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += 1024)
+        p[i] = 0u;
+}
+
 __global__ __launch_bounds__(256) void lex_clear_kernel(float *__restrict__ scores, const uint32_t *__restrict__ touched,
                                                         const LexControl *__restrict__ ctl)
 {
@@ -1324,7 +1330,12 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     ws->dirty = true; // cleared by lexical_finish(ok) once the whole pipeline has run
     // the control block (counters, histograms) is zeroed in front of a call, not behind it: its counts stay readable
     // for a consumer on another stream until the workspace is handed back
-    LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), s));
+    // (one small kernel: hipMemsetAsync turns the 8328-byte block into two fill kernels of ~5 us each, at the head of a chain
+    // that is as long as the scan .. sort chain it runs beside)
+    static_assert(sizeof(LexControl) % 4 == 0, "cleared as 32-bit words");
+    hipLaunchKernelGGL(lex_zero_words_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<uint32_t *>(ws->d_ctl),
+                       static_cast<uint32_t>(sizeof(LexControl) / 4));
+    LEX_HIP(hipGetLastError());
     const uint32_t max_blocks = static_cast<uint32_t>(lx->n_cu) * 8;
     static const bool per_term = getenv("RLR_LEX_PER_TERM") != nullptr; // (A/B switch: one launch per term and segment)
     // workgroups of the row-partitioned kernel: one per CU while each still owns a few hundred rows
