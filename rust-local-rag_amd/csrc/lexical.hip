@@ -1470,9 +1470,11 @@ void lexical_finish(LexPending *p, bool ok)
     rlr_lexical *lx = p->lx;
     if (p->ws) {
         LexWorkspace *ws = static_cast<LexWorkspace *>(p->ws);
-        if (ok) // the clean-up kernels behind `ready` restore the all-zero accumulators; wait for them before reuse
-            ok = hipStreamSynchronize(ws->stream) == hipSuccess;
-        if (ok)
+        // the clean-up kernels behind `ready` restore the all-zero accumulators: wait for them before reuse.  After a failure
+        // too: the kernels still in flight read the postings, and the shared lock that keeps a writer away from them is
+        // dropped below.
+        const bool drained = hipStreamSynchronize(ws->stream) == hipSuccess;
+        if (ok && drained)
             ws->dirty = false;
         {
             std::lock_guard<std::mutex> lk(lx->ws_mu);
