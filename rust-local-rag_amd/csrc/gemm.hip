@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(1024) void batch_band_kernel(uint64_t *__restrict__
 {
     __shared__ uint64_t s_c[kFinCap];
     __shared__ uint32_t s_hist[2048];
-    __shared__ uint32_t s_sel[2];
+    __shared__ uint32_t s_sel[3];
     __shared__ uint32_t s_band;
     const uint32_t q = blockIdx.x;
     const uint32_t n_raw = st[q].n_cand;

@@ -989,7 +989,7 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
     __shared__ uint32_t s_hidx[kHybridHash];
     __shared__ uint32_t s_flag[kHybridLexMax]; // lexical pair j was reached by the fetch
     __shared__ uint32_t s_hist[2048];
-    __shared__ uint32_t s_pick[2];
+    __shared__ uint32_t s_pick[3];
     __shared__ uint32_t s_got, s_cand, s_nsel, s_emin;
     __shared__ float s_cneed;
     const uint32_t t = threadIdx.x;

@@ -6,6 +6,41 @@
 
 namespace rlr {
 
+// The bin holding the rank-th key counted from the top of a histogram of up to 2048 bins in LDS (entries [nb, 2048) zero), by
+// all 1024 threads of the workgroup: thread t owns bins 2t and 2t + 1 (one conflict-free read), a wavefront suffix
+// scan, the 16 wave totals through LDS.  sel[0] = bin, sel[1] = rank inside the bin (1-based), sel[2] = the bin's count;
+// valid after the call's last barrier.  (It was one wavefront walking 32 bins per lane at a 32-word stride -- every read a
+// 32-way bank conflict -- twice: ~1.5 us of each radix pass.)
+__device__ inline void lds_find_rank_bin_1024(const uint32_t *s_hist, uint32_t rank, uint32_t *s_sel)
+{
+    __shared__ uint32_t s_wave_tot[16];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t lo = s_hist[2 * t], hi = s_hist[2 * t + 1], sum = lo + hi; // (one ds_read2_b32)
+    uint32_t suf = sum; // sum over this wave's lanes >= lane
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_down(suf, off);
+        if (lane + off < 64)
+            suf += v;
+    }
+    if (lane == 0)
+        s_wave_tot[wave] = suf;
+    __syncthreads();
+    uint32_t above = suf - sum; // keys in bins above this thread's two
+    for (uint32_t w = wave + 1; w < 16; ++w)
+        above += s_wave_tot[w];
+    if (above < rank && rank <= above + hi) {
+        s_sel[0] = 2 * t + 1;
+        s_sel[1] = rank - above;
+        s_sel[2] = hi;
+    } else if (above + hi < rank && rank <= above + hi + lo) {
+        s_sel[0] = 2 * t;
+        s_sel[1] = rank - above - hi;
+        s_sel[2] = lo;
+    }
+    __syncthreads();
+}
+
 // k-th largest 32-bit key among the packed candidates s_c[0, n) (key = high word), by three radix passes over LDS
 // (11 + 11 + 10 bits; histogram by LDS atomics, the bin search by one wavefront).  All threads must call it; the result
 // is returned to every thread.  Replaces a full bitonic sort of the list (91 barrier-separated stages at 8192 entries:
@@ -18,7 +53,7 @@ __device__ inline uint32_t lds_kth_key(const uint64_t *s_c, uint32_t n, uint32_t
     for (int pass = 0; pass < 3; ++pass) {
         const uint32_t shift = pass == 0 ? 21u : pass == 1 ? 10u : 0u;
         const uint32_t nb = pass == 2 ? 1024u : 2048u;
-        for (uint32_t i = threadIdx.x; i < nb; i += nthreads)
+        for (uint32_t i = threadIdx.x; i < (nthreads == 1024 ? 2048u : nb); i += nthreads)
             s_hist[i] = 0;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += nthreads) {
@@ -27,7 +62,9 @@ __device__ inline uint32_t lds_kth_key(const uint64_t *s_c, uint32_t n, uint32_t
                 atomicAdd(&s_hist[(key >> shift) & (nb - 1)], 1u);
         }
         __syncthreads();
-        if (threadIdx.x < 64) {
+        if (nthreads == 1024) {
+            lds_find_rank_bin_1024(s_hist, rank, s_sel);
+        } else if (threadIdx.x < 64) {
             // lane l owns bins [l * W, (l + 1) * W); suffix sums over the lanes from the top, then inside the lane
             const uint32_t W = nb / 64, lane = threadIdx.x;
             uint32_t mine = 0;
@@ -54,7 +91,8 @@ __device__ inline uint32_t lds_kth_key(const uint64_t *s_c, uint32_t n, uint32_t
                 }
             }
         }
-        __syncthreads();
+        if (nthreads != 1024)
+            __syncthreads();
         prefix |= s_sel[0] << shift;
         mask |= (nb - 1) << shift;
         rank = s_sel[1];
@@ -94,7 +132,7 @@ __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32
             bits = next_hi < 11 ? next_hi : 11u;
         }
         const uint32_t shift = next_hi - bits, nb = 1u << bits;
-        for (uint32_t i = threadIdx.x; i < nb; i += nthreads)
+        for (uint32_t i = threadIdx.x; i < (nthreads == 1024 ? 2048u : nb); i += nthreads)
             s_hist[i] = 0;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += nthreads) {
@@ -103,7 +141,9 @@ __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32
                 atomicAdd(&s_hist[static_cast<uint32_t>(key >> shift) & (nb - 1)], 1u);
         }
         __syncthreads();
-        if (threadIdx.x < 64) {
+        if (nthreads == 1024) {
+            lds_find_rank_bin_1024(s_hist, rank, s_sel);
+        } else if (threadIdx.x < 64) {
             // lane l owns bins [l * W, (l + 1) * W) (W >= 1: digits narrower than 6 bits leave the upper lanes without bins)
             const uint32_t W = nb >= 64 ? nb / 64 : 1u, lane = threadIdx.x;
             const bool owns = lane * W < nb;
@@ -133,7 +173,8 @@ __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32
                 }
             }
         }
-        __syncthreads();
+        if (nthreads != 1024)
+            __syncthreads();
         prefix |= static_cast<uint64_t>(s_sel[0]) << shift;
         mask |= static_cast<uint64_t>(nb - 1) << shift;
         rank = s_sel[1];
