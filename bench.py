@@ -11,9 +11,11 @@ every input resident in HBM.  With N > 1 (launched by torch.distributed.run, one
 per GPU) the same 10M rows are sharded N ways and every step adds the RCCL all-gather of
 the per-shard partial top-k and the merge -- total work is fixed => "scaling": "strong".
 
-Rank 0 prints ONE JSON line: metric/value/unit/... + "roofline" + "cpu_baseline" + (N = 1 only,
-measured outside the headline's timed region) "configs": BASELINE configs C2 / C3 / C5-share,
-each with its own roofline object.
+Rank 0 prints ONE JSON line: metric/value/unit/... + "roofline" (with the measured read / copy peaks of the box beside
+the spec peak) + "cpu_baseline" + (N = 1 only, measured outside the headline's timed region) "configs": one GPU's share of
+the headline at 8 GPUs through the sharded code path (headline_shard_1of8, with implied_speedup_8), BASELINE configs C2 /
+C3 (with and without the nomination image) / C4-share / C5-share, and the headline on hostile score distributions
+(tight clusters, exact duplicates), each with its own roofline object.
 """
 from __future__ import annotations
 
@@ -254,31 +256,49 @@ def ensure_built():
 # BASELINE configs measured beside the headline (N = 1, outside its timed region)
 # ------------------------------------------------------------------------------------------------------
 def config_c3(rlr, ix, args, torch):
-    """C3: 10 M x 768 f32, 256 batched queries, top-100, over the nomination image (same index as the headline)."""
+    """C3: 10 M x 768 f32, 256 batched queries, top-100 (same index as the headline), both ways a caller can run it:
+    `without_image` -- rlr_search_topk on the f32 index as it is (gemm_nominate_kernel streams the f32 rows and rounds
+    them to binary16 on the way into the matrix cores) -- and over the opt-in nomination image (+dim*2 B/row of HBM,
+    gemm8_kernel streams half the bytes).  Identical results; the top-level value is the image's."""
     nq, steps = 256, 12
     pool = queries_without_oracle(rlr, args.dim, nq + steps + 3, args.seed + 3)
-    ix.enable_batch_image(True)
-    try:
-        for i in range(3):
-            ix.search_topk(pool[i:i + nq], args.k)
-        ix.profile_read(reset=True)
-        ix.profile_enable(True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            ix.search_topk(pool[3 + i:3 + i + nq], args.k)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        ix.profile_enable(False)
-        p = ix.profile_read()
-    finally:
-        ix.enable_batch_image(False)
-    return {"workload": f"C3: {len(ix)} chunks x {args.dim}-d f32, {nq} batched queries/step, top_k={args.k}, "
-                        f"nomination image (+dim*2 B/row)",
-            "value": steps * nq / el, "unit": "queries/s", "ms_per_batch": el / steps * 1e3,
-            "stages_ms": {"gemm_all_launches": p.batch_gemm_ms / max(p.n_batches, 1),
-                          "select_and_finish": p.batch_other_ms / max(p.n_batches, 1)},
-            "fallback_queries": p.n_batch_fallbacks, "roofline": batched_roofline(p, args.dim, nq, True)}
+
+    def leg(image):
+        ix.enable_batch_image(image)
+        try:
+            for i in range(3):
+                ix.search_topk(pool[i:i + nq], args.k)
+            ix.profile_read(reset=True)
+            ix.profile_enable(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                last = ix.search_topk(pool[3 + i:3 + i + nq], args.k)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            ix.profile_enable(False)
+            p = ix.profile_read()
+        finally:
+            ix.enable_batch_image(False)
+        nb = max(p.n_batches, 1)
+        return {"value": steps * nq / el, "unit": "queries/s", "ms_per_batch": el / steps * 1e3,
+                "stages_ms": {"gemm_all_launches": p.batch_gemm_ms / nb, "select_and_finish": p.batch_other_ms / nb},
+                "fallback_queries": p.n_batch_fallbacks,
+                "extra_hbm_bytes": len(ix) * args.dim * 2 if image else 0,
+                "roofline": batched_roofline(p, args.dim, nq, image, "batch256_image" if image else "batch256")}, last
+
+    plain, r0 = leg(False)
+    img, r1 = leg(True)
+    same = bool(np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1].view(np.uint32), r1[1].view(np.uint32)))
+    out = {"workload": f"C3: {len(ix)} chunks x {args.dim}-d f32, {nq} batched queries/step, top_k={args.k}, "
+                       f"nomination image (+dim*2 B/row)"}
+    out.update(img)
+    out["without_image"] = plain
+    out["without_image"]["what"] = ("the default path of an f32 index: rlr_search_topk with 256 queries, no opt-in "
+                                    "(gemm_nominate_kernel over the f32 rows)")
+    out["image_speedup"] = img["value"] / plain["value"] if plain["value"] else None
+    out["same_results_both_ways_on_the_last_batch"] = same
+    return out
 
 
 def c2_hybrid_leg(rlr, torch, ix, qs, n, dim, k, lam, steps):
@@ -425,6 +445,91 @@ def config_c5_share(rlr, torch):
             "timed_passes": reps, "fallback_queries": p.n_batch_fallbacks, "roofline": batched_roofline(p, dim, nq, True, "c5_share")}
 
 
+def config_shard_1of8(rlr, torch, sharded, args, headline_ms):
+    """One GPU's share of the headline at 8 GPUs -- 1.25 M x 768 f32, single query, top-100 -- through the SHARDED code
+    path at world 1: rlr_search_topk_device_begin (pipelines enqueued on torch's stream) -> [the all-gather sits here at
+    world > 1] -> merge kernel (results into pinned host memory) -> _end.  What it leaves out of an 8-GPU step is the
+    8-rank RCCL all-gather of 8 x 100 x 8 B (latency-bound, tens of us).  implied_speedup_8 = headline ms / this ms."""
+    n, steps = args.rows // 8, 400
+    qs = queries_without_oracle(rlr, args.dim, steps + 40, args.seed + 8)
+    sh = sharded.ShardedIndex(args.dim, n, args.dtype, device=0, rank=0, world=1)
+    try:
+        sh.fill_synthetic(args.seed)
+        ix = sh.index
+        for i in range(40):
+            sh.search_topk(qs[i], args.k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            sh.search_topk(qs[40 + i], args.k)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ix.search_topk(qs[40 + i], args.k)                      # the unsharded call on the same shard, for reference
+        plain = (time.perf_counter() - t0) / steps
+        ix.profile_read(reset=True)
+        ix.profile_enable(True)                                      # second pass: per-stage HIP events
+        sh.time_exchange(True)
+        for i in range(100):
+            sh.search_topk(qs[40 + i], args.k)
+        ix.profile_enable(False)
+        p = ix.profile_read()
+        merge_ms = sh.exchange_ms_per_step()
+        sh.time_exchange(False)
+    finally:
+        sh.index.close()
+    ns = max(p.n_scan_launches, 1)
+    scan_ms = p.scan_ms / ns
+    elem = 2 if args.dtype == "f16" else 4
+    b = n * args.dim * elem
+    gbps = b / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    return {"workload": f"headline shard 1 of 8: {n} chunks x {args.dim}-d {args.dtype}, 1 query/step, top_k={args.k}; "
+                        f"ShardedIndex.search_topk at world 1 (begin -> merge kernel -> end)",
+            "value": 1.0 / el, "unit": "queries/s", "ms_per_step": el * 1e3,
+            "stages_ms": {"scan": scan_ms, "select": p.select_ms / ns, "rescore_sort": p.rescore_ms / ns, "merge": merge_ms},
+            "stage_note": "HIP events of a second pass: select = tail stage 1 (bin search + collect + re-score, or the digit-2 "
+                          "histogram), rescore_sort = tail stage 2 (sort + emit), merge = all-gather slot + merge kernel",
+            "fixed_cost_us": (el * 1e3 - scan_ms) * 1e3,
+            "plain_search_topk_ms": plain * 1e3,
+            "implied_speedup_8": headline_ms / (el * 1e3),
+            "implied_note": "headline ms_per_step / this; an 8-rank all-gather of 6.4 KB is not in it",
+            "candidates_per_query": p.n_candidates / max(p.n_searches, 1), "band_retries": p.n_retries,
+            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel": "scan_fixed_kernel", "kernel_ms": scan_ms, "bytes_per_launch": b}}
+
+
+def config_single(rlr, torch, args, n, seed, n_clusters, what, steps=30):
+    """single-query top-k over a fresh index of n rows (C4's per-GPU share, the hostile score distributions)"""
+    qs = queries_without_oracle(rlr, args.dim, steps + 10, seed + 1)
+    ix = rlr.GpuIndex(args.dim, args.dtype)
+    try:
+        ix.fill_synthetic(n, seed=seed, n_clusters=n_clusters)
+        for i in range(10):
+            ix.search_topk(qs[i], args.k)
+        ix.profile_read(reset=True)
+        ix.profile_enable(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ix.search_topk(qs[10 + i], args.k)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+        ix.profile_enable(False)
+        p = ix.profile_read()
+    finally:
+        ix.close()
+    ns = max(p.n_scan_launches, 1)
+    scan_ms = p.scan_ms / ns
+    b = n * args.dim * (2 if args.dtype == "f16" else 4)
+    gbps = b / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    return {"workload": what, "value": 1.0 / el, "unit": "queries/s", "ms_per_step": el * 1e3,
+            "stages_ms": {"scan": scan_ms, "select": p.select_ms / ns, "rescore_sort": p.rescore_ms / ns},
+            "candidates_per_query": p.n_candidates / max(p.n_searches, 1), "band_retries": p.n_retries,
+            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel": "scan_fixed_kernel", "kernel_ms": scan_ms, "bytes_per_launch": b}}
+
+
 def in_process(args):
     """headline workload, rows sharded over args.gpus devices of THIS process (rlr_multi, RCCL exchange)"""
     import gc
@@ -541,6 +646,17 @@ def main():
     if args.image or args.image_scan or args.q8_scan:
         ix.enable_batch_image(args.image or args.image_scan, single_query=args.image_scan, q8=args.q8_scan)
 
+    # Measured-peak denominators ("re-measure on the box"), once, before anything is timed: a read-only
+    # stream and a device-to-device copy over this rank's own rows (rlr_index_probe_bandwidth).
+    measured = None
+    if rank == 0 and not args.no_profile:
+        try:
+            rd, rd_ms = ix.probe_bandwidth(0, 5)
+            cp, cp_ms = ix.probe_bandwidth(1, 5)
+            measured = {"read": rd, "read_ms": rd_ms, "copy": cp, "copy_ms": cp_ms}
+        except Exception as e:  # the probe must never take the headline down
+            measured = {"error": str(e)}
+
     force_sharded = os.environ.get("RLR_BENCH_FORCE_SHARDED") == "1" or force_dist  # rehearse the N>1 code path on one GPU
     use_sharded = world > 1 or force_sharded
 
@@ -647,6 +763,15 @@ def main():
         "fill_s": round(fill_s, 2),
         "build_source_sha16": source_sha16(),
     }
+    if measured and "error" not in measured:
+        out["roofline"]["peak_measured_read_GBps"] = measured["read"]
+        out["roofline"]["peak_measured_copy_GBps"] = measured["copy"]
+        out["roofline"]["frac_of_measured"] = achieved / measured["read"] if measured["read"] > 0 else None
+        out["roofline"]["measured_note"] = ("rlr_index_probe_bandwidth over this index's rows before the timed region: read = the "
+                                            "scan's stream without arithmetic (best of three launch shapes), copy = hipMemcpyAsync "
+                                            "device-to-device, bytes read + written; `frac` stays achieved / the 8 TB/s spec peak")
+    elif measured:
+        out["roofline"]["measured_error"] = measured["error"]
     if use_sharded:
         # the exchange step of SURVEY 8(e): all-gather of world x k packed results + merge kernel, per step
         out["stages_ms"]["allgather_merge"] = exchange_ms
@@ -710,12 +835,30 @@ def main():
     # BASELINE's other single-GPU configurations, each with its own roofline, outside the timed region too
     if extras and args.dtype == "f32" and args.dim == 768 and args.rows == 10_000_000:
         out["configs"] = {}
-        for name, fn in (("C3_256_batched_queries", lambda: config_c3(rlr, ix, args, torch)),
-                         ("C2_100k_mmr", lambda: config_c2(rlr, torch))):
+        headline_ms = elapsed / args.steps * 1e3
+        tight = 0x80000000
+        for name, fn in (("headline_shard_1of8", lambda: config_shard_1of8(rlr, torch, sharded, args, headline_ms)),
+                         ("C3_256_batched_queries", lambda: config_c3(rlr, ix, args, torch)),
+                         ("C2_100k_mmr", lambda: config_c2(rlr, torch)),
+                         ("C4_per_gpu_share", lambda: config_single(
+                             rlr, torch, args, 12_500_000, args.seed + 4, 0,
+                             "C4 per-GPU share: 12500000 chunks x 768-d f32 (100 M / 8), 1 query/step, top_k=100")),
+                         ("headline_clustered", lambda: config_single(
+                             rlr, torch, args, args.rows, args.seed + 6, 64 | tight,
+                             f"{args.rows} chunks x 768-d f32 in 64 TIGHT clusters (rows of a cluster are near-copies, cosine "
+                             f"~0.999: the top of every ranking is one dense cluster), 1 query/step, top_k=100")),
+                         ("headline_duplicates", lambda: config_single(
+                             rlr, torch, args, args.rows, args.seed, 0x40000000,
+                             f"{args.rows} chunks x 768-d f32, the last 1 % of the rows exact duplicates of the first 1 % "
+                             f"(re-ingested documents, rag_engine.rs:347-384), 1 query/step, top_k=100"))):
             try:
                 out["configs"][name] = fn()
             except Exception as e:
                 out["configs"][name] = {"error": str(e)}
+        for name in ("headline_clustered", "headline_duplicates"):
+            c = out["configs"].get(name, {})
+            if "value" in c:
+                c["vs_iid_headline"] = c["value"] / out["value"]
     if world == 1 and not args.no_cpu and O is not None:
         base, sample_rows, want = cpu_baseline(args, rlr)
         out["cpu_baseline"] = base

@@ -88,7 +88,11 @@ int32_t rlr_index_delete_rows(rlr_index *idx, const uint64_t *rows, uint64_t n);
 /* Fill the index with the deterministic synthetic corpus of SURVEY.md 8(d) without
  * crossing PCIe: rows [row0, row0+n_rows) of stream `seed` (integer-only generator,
  * bit-identical to oracle/rlr_oracle.c:rlr_o_synth_rows), reference-normalised, then
- * rounded to the index dtype.  Benchmark / test support. */
+ * rounded to the index dtype.  Benchmark / test support.
+ * n_clusters: low 30 bits = number of cluster centres (0: iid rows); bit 31: "tight" clusters (the rows of a
+ * cluster are near-copies of each other, cosine ~0.999: a dense top of the ranking); bit 30: the last
+ * n_rows / 100 rows repeat the first n_rows / 100 (exact duplicate chunks, as re-ingesting a document
+ * without deleting it first leaves them, rag_engine.rs:347-384). */
 int32_t rlr_index_fill_synthetic(rlr_index *idx, uint64_t n_rows, uint64_t row0, uint64_t seed,
                                  uint32_t n_clusters);
 
@@ -361,6 +365,14 @@ typedef struct rlr_profile {
  * (adds one event pair per stage).  Disabled by default. */
 int32_t rlr_profile_enable(rlr_index *idx, int32_t enable);
 int32_t rlr_profile_read(rlr_index *idx, rlr_profile *out, int32_t reset);
+/* Measured-peak denominators for the roofline ("re-measure on the box"), over the index's own rows
+ * so that nothing else has to fit in HBM:
+ *   mode 0  read-only stream: the scan's row stream with the arithmetic removed (non-temporal 16-byte loads summed
+ *           up, one store per wave), the best of three launch shapes, mean of `reps` launches after one warm-up;
+ *   mode 1  device-to-device copy (hipMemcpyAsync) of the first min(half of the rows, 4 GiB) into a scratch
+ *           allocation; *gbps_out counts bytes read + bytes written, as copy bandwidths are usually quoted.
+ * HIP events on the probe's own stream.  Benchmark support: no search may run on the index meanwhile. */
+int32_t rlr_index_probe_bandwidth(rlr_index *idx, int32_t mode, uint32_t reps, double *gbps_out, double *ms_out);
 
 #ifdef __cplusplus
 }

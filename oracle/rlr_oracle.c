@@ -521,7 +521,11 @@ RLR_O_API size_t rlr_o_search_with_diversity(const float *rows, size_t n, size_t
 /* Integer-only so that host and device produce bit-identical rows:           */
 /*   h   = splitmix64 finaliser of a per-element counter                      */
 /*   raw = (sum of the four 16-bit fields of h) - 131070     (Irwin-Hall n=4) */
-/*   optional cluster centre added (2x weight) to create near-duplicates      */
+/*   optional cluster centre added (2x weight) to create near-duplicates;     */
+/*   bit 31 of n_clusters ("tight"): the per-row part is divided by 16 first  */
+/*   (arithmetic shift), so the rows of a cluster are near-copies of each     */
+/*   other (cosine ~0.999): a dense top-of-the-ranking, as boilerplate chunks */
+/*   produce it                                                               */
 /*   row = reference normalize() of the raw row.                              */
 /* The HIP twin is rust-local-rag_amd/csrc/synth.hip; tests compare the two.  */
 /* ------------------------------------------------------------------------ */
@@ -543,10 +547,14 @@ RLR_O_API float rlr_o_synth_raw(uint64_t seed, uint64_t row, uint32_t col, uint3
     uint64_t s = mix64(seed ^ 0x5EED5EED5EED5EEDULL);
     uint64_t idx = row * (uint64_t)d + col;
     int32_t t = ih4(mix64(s + (idx + 1) * 0x9E3779B97F4A7C15ULL));
+    const int tight = (n_clusters & 0x80000000u) != 0;
+    n_clusters &= 0x7FFFFFFFu;
     if (n_clusters) {
         uint64_t cl = mix64(s ^ (row + 0x632BE59BD9B4E019ULL)) % n_clusters;
         uint64_t cidx = cl * (uint64_t)d + col;
         int32_t c = ih4(mix64((s ^ 0xC1A57E55C1A57E55ULL) + (cidx + 1) * 0x9E3779B97F4A7C15ULL));
+        if (tight)
+            t = t / 16; /* toward zero, as the device twin */
         t += 2 * c;
     }
     return (float)t * (1.0f / 65536.0f); /* |t| < 2^24: exact */

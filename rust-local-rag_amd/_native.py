@@ -132,6 +132,7 @@ PROTOTYPES = [
                                           C.c_float, u32p, f32p, u32p]),
     ("rlr_profile_enable", C.c_int32, [_H, C.c_int32]),
     ("rlr_profile_read", C.c_int32, [_H, C.POINTER(ProfileC), C.c_int32]),
+    ("rlr_index_probe_bandwidth", C.c_int32, [_H, C.c_int32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     # rlr_engine.h
     ("rlr_resolve_weight", C.c_float, [C.c_int32, C.c_float, C.c_float]),
     ("rlr_resolve_weights", None, [C.POINTER(QueryWeightsC), C.POINTER(ResolvedWeightsC)]),

@@ -7,6 +7,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "lds_select.h"
+#include "sort_emit.h"
 #include "lexical_internal.h"
 
 #include <algorithm>
@@ -139,6 +140,8 @@ struct rlr_index {
     void *d_rows = nullptr;
     int n_cu = 256;
     int scan_variant = 0;
+    bool fused_tail = true;      // select -> re-score -> sort behind the scan in two launches (tail.hip); RLR_TAIL=0: the five-launch form
+    uint32_t tail_direct_max = 1024; // RLR_TAIL_DIRECT_MAX: most scores in/above the k-th score's digit-1 bin for the one-pass mode (0: always refine)
     uint32_t batch_min = 0;   // smallest batch that takes the matrix-core path; 0 = decide by the cost model,
                               // RLR_BATCH_MIN=n forces a threshold (a huge n disables the path)
     float max_row_sumsq = 1.0f; // largest sum of squares of a row stored with normalize_on_device = 0 (>= 1): the guard
@@ -286,7 +289,9 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
                 if (c->hist_dirty) { // a previous call failed half way: restore the zero-histogram invariant
                     (void)hipStreamSynchronize(c->stream);
                     // (on the context's own stream: the null stream does not order against a non-blocking one)
-                    if (hipMemsetAsync(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), c->stream) == hipSuccess)
+                    if (hipMemsetAsync(c->d_hist, 0, 2 * kHistBins * sizeof(uint32_t), c->stream) == hipSuccess &&
+                        (!c->d_state || hipMemsetAsync(c->d_state, 0, static_cast<size_t>(c->q_cap) * sizeof(SelectState), c->stream) ==
+                                            hipSuccess))
                         c->hist_dirty = false;
                 }
                 *out = c;
@@ -544,6 +549,8 @@ int32_t ctx_prepare(rlr_index *ix, Ctx *c, uint32_t nq, const SearchPlan &p)
         c->q_cap = 0;
         RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_query), static_cast<size_t>(nq) * ix->q_pitch * sizeof(float)));
         RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_state), static_cast<size_t>(nq) * sizeof(SelectState)));
+        // the fused tail's counters (n_work, done, flags) are zero between two queries; on the context's stream, like the histograms
+        RLR_HIP(hipMemsetAsync(c->d_state, 0, static_cast<size_t>(nq) * sizeof(SelectState), c->stream));
         c->q_cap = nq;
     }
     RLR_TRY(grow(&c->d_scores, &c->score_cap, std::max<uint64_t>(ix->n_rows, 4)));
@@ -579,87 +586,14 @@ __global__ __launch_bounds__(256) void hist_assert_zero_kernel(const uint32_t *_
         atomicAdd(flag, bad);
 }
 
-// device-side: sort the re-scored candidates (<= kLdsSortCap) and emit the best k.
-// unordered: more than 1024 candidates are not sorted (a 2048-entry bitonic network: 22 us) -- the k best are found by a
-// radix select of the k-th key and written in any order (valid entries first, zeros behind, as in the sorted form).
+// device-side: sort the re-scored candidates (<= kLdsSortCap) and emit the best k (sort_emit.h).
 __global__ __launch_bounds__(1024) void sort_emit_kernel(uint64_t *__restrict__ packed, const SelectState *__restrict__ st,
                                                          uint64_t *__restrict__ out, uint32_t k,
                                                          uint64_t *__restrict__ meta, bool unordered)
 {
     __shared__ uint64_t s[4096];
-    const uint32_t n_raw = st->n_cand;
-    if (threadIdx.x == 0 && meta)
-        *meta = n_raw; // travels to the host with the results: one D2H per call
-    if (n_raw > st->cap || n_raw > 4096) {
-        // band overflow: the host re-runs this query on the large-candidate path.  The all-ones word marks
-        // the slot invalid for consumers that read it before the host has looked (the sharded merge).
-        if (threadIdx.x == 0)
-            out[0] = ~0ull;
-        return;
-    }
-    if (n_raw <= 1024) {
-        // rank sort: keys are unique (the row number is part of the key), so the number of larger
-        // keys is the output position -- one pass, two barriers, instead of a log^2 network.
-        if (threadIdx.x < n_raw)
-            s[threadIdx.x] = packed[threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x < n_raw) {
-            const uint64_t mine = s[threadIdx.x];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n_raw; ++j)
-                rank += s[j] > mine;
-            if (rank < k)
-                out[rank] = mine;
-        }
-        for (uint32_t i = n_raw + threadIdx.x; i < k; i += 1024)
-            out[i] = 0ull;
-        return;
-    }
-    if (unordered) {
-        __shared__ uint32_t s_hist[2048];
-        __shared__ uint32_t s_pick[3];
-        __shared__ uint32_t s_n;
-        for (uint32_t i = threadIdx.x; i < n_raw; i += 1024)
-            s[i] = packed[i];
-        if (threadIdx.x == 0)
-            s_n = 0;
-        __syncthreads();
-        uint64_t kth = 0;
-        if (n_raw > k)
-            kth = lds_kth_key64(s, n_raw, k, s_hist, s_pick, 1024); // unique keys: exactly k of them are >= kth
-        for (uint32_t i = threadIdx.x; i < n_raw; i += 1024) {
-            const uint64_t v = s[i];
-            if (v >= kth)
-                out[atomicAdd(&s_n, 1u)] = v;
-        }
-        for (uint32_t i = min(n_raw, k) + threadIdx.x; i < k; i += 1024)
-            out[i] = 0ull;
-        return;
-    }
-    uint32_t n_pad = 1;
-    while (n_pad < n_raw)
-        n_pad <<= 1;
-    for (uint32_t i = threadIdx.x; i < n_pad; i += 1024)
-        s[i] = i < n_raw ? packed[i] : 0ull;
-    __syncthreads();
-    for (uint32_t kk = 2; kk <= n_pad; kk <<= 1) {
-        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < n_pad; i += 1024) {
-                const uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    const uint64_t a = s[i], b = s[ixj];
-                    const bool desc = (i & kk) == 0;
-                    if (desc ? (a < b) : (a > b)) {
-                        s[i] = b;
-                        s[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < k; i += 1024)
-        out[i] = i < n_raw ? s[i] : 0ull;
+    __shared__ uint32_t s_hist[2048];
+    sort_emit_body(packed, st->n_cand, st->cap, out, k, meta, unordered, s, s_hist);
 }
 
 // Exchange-step merge: one workgroup per query orders the world x k packed partial
@@ -1270,9 +1204,36 @@ hipError_t enqueue_query_rest(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPl
     const float *dq = c->d_query + static_cast<size_t>(qi) * ix->q_pitch;
     const bool q8 = scan_over_q8(ix);
     const bool img = !q8 && scan_over_image(ix);
-    if ((e = launch_hist2_find1(c->d_scores, n, hist1, hist2, st, p.k, p.cap, ix->n_cu, s)) != hipSuccess) return e;
     const float band = q8 ? q8_two_eps(ix, qi < c->q_norm.size() ? c->q_norm[qi] : 1.0f, p.two_eps * 0.5f)
                           : (img ? p.two_eps_img : p.two_eps);
+    if (ix->fused_tail && p.cap <= kLdsSortCap && tail_fits(ix->pitch16, ix->dim, ix->dtype)) {
+        // two launches (tail.hip): bin search + collect + re-score (or the digit-2 histogram of a crowded bin), then sort + emit
+        TailArgs ta;
+        ta.scores = c->d_scores;
+        ta.n = n;
+        ta.hist = c->d_hist;
+        ta.st = st;
+        ta.k = p.k;
+        ta.cap = p.cap;
+        ta.two_eps = band;
+        ta.rows = ix->d_rows;
+        ta.pitch16 = ix->pitch16;
+        ta.dim = ix->dim;
+        ta.dtype = ix->dtype;
+        ta.query = dq;
+        ta.packed = c->d_packed;
+        ta.out = emit ? d_out_q : nullptr;
+        ta.meta = d_meta_q;
+        ta.unordered = p.unordered;
+        ta.direct_max = ix->tail_direct_max;
+        ta.n_cu = ix->n_cu;
+        if ((e = launch_tail_stage1(ta, s)) != hipSuccess) return e;
+        if (timed && (e = hipEventRecord(c->ev[2], s)) != hipSuccess) return e;
+        if ((e = launch_tail_stage2(ta, s)) != hipSuccess) return e;
+        if (timed && (e = hipEventRecord(c->ev[3], s)) != hipSuccess) return e;
+        return hipSuccess;
+    }
+    if ((e = launch_hist2_find1(c->d_scores, n, hist1, hist2, st, p.k, p.cap, ix->n_cu, s)) != hipSuccess) return e;
     if ((e = launch_collect_find2(c->d_scores, n, hist2, st, band, c->d_cand, ix->n_cu, s)) != hipSuccess)
         return e;
     if (timed && (e = hipEventRecord(c->ev[2], s)) != hipSuccess) return e;
@@ -1842,6 +1803,10 @@ int32_t rlr_index_create(uint32_t dim, int32_t dtype, int32_t device_id, rlr_ind
     ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *v = getenv("RLR_SCAN_VARIANT"))
         ix->scan_variant = static_cast<int>(strtol(v, nullptr, 0));
+    if (const char *v = getenv("RLR_TAIL"))
+        ix->fused_tail = v[0] != '0';
+    if (const char *v = getenv("RLR_TAIL_DIRECT_MAX"))
+        ix->tail_direct_max = static_cast<uint32_t>(std::min<unsigned long>(strtoul(v, nullptr, 0), 4096));
     if (const char *v = getenv("RLR_BATCH_MIN"))
         ix->batch_min = static_cast<uint32_t>(strtoul(v, nullptr, 0));
     if (const char *v = getenv("RLR_MAX_CONTEXTS"))
@@ -2028,14 +1993,22 @@ int32_t rlr_index_fill_synthetic(rlr_index *ix, uint64_t n_rows, uint64_t row0, 
     float *d_norm = nullptr;
     RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&d_norm), std::min(chunk, std::max<uint64_t>(n_rows, 1)) * sizeof(float)));
     int32_t st = RLR_OK;
-    for (uint64_t r0 = 0; r0 < n_rows && st == RLR_OK; r0 += chunk) {
-        const uint64_t m = std::min(chunk, n_rows - r0);
+    // bit 30: the last n_rows / 100 rows repeat the first n_rows / 100 (exact duplicates)
+    const uint64_t n_dup = (n_clusters & 0x40000000u) ? n_rows / 100 : 0;
+    const uint64_t seam = n_rows - n_dup; // rows [seam, n_rows) are generator rows [row0, row0 + n_dup) again
+    n_clusters &= ~0x40000000u;
+    for (uint64_t r0 = 0; r0 < n_rows && st == RLR_OK;) {
+        uint64_t m = std::min(chunk, n_rows - r0);
+        if (r0 < seam)
+            m = std::min(m, seam - r0); // (a launch never straddles the seam)
+        const uint64_t src = r0 < seam ? row0 + r0 : row0 + (r0 - seam);
         hipError_t e = launch_synth(static_cast<char *>(ix->d_rows) + r0 * row_bytes(ix), ix->pitch16, ix->dim, ix->dtype,
-                                    row0 + r0, static_cast<uint32_t>(m), seed, n_clusters, d_norm, nullptr);
+                                    src, static_cast<uint32_t>(m), seed, n_clusters, d_norm, nullptr);
         if (e == hipSuccess)
             e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess)
             st = fail(RLR_E_HIP, "synthetic fill failed: %s", hipGetErrorString(e));
+        r0 += m;
     }
     (void)hipFree(d_norm);
     if (st == RLR_OK) {
@@ -2308,6 +2281,7 @@ int32_t rlr_score_rows(rlr_index *ix, const float *query, const uint64_t *rows, 
     if (c->q_cap < 1) {
         RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_query), static_cast<size_t>(ix->q_pitch) * sizeof(float)));
         RLR_HIP(rlr::dev_malloc(reinterpret_cast<void **>(&c->d_state), sizeof(SelectState)));
+        RLR_HIP(hipMemsetAsync(c->d_state, 0, sizeof(SelectState), c->stream)); // (the fused tail's counters, as in ctx_prepare)
         c->q_cap = 1;
     }
     RLR_HIP(hipMemcpyAsync(c->d_query, query, ix->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -2990,6 +2964,64 @@ int32_t rlr_fetch_rows_device(rlr_index *ix, const uint64_t *rows, uint32_t n, v
     RLR_TRY(upload_list(ix, c, rows, n));
     RLR_HIP(launch_gather_f32(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, n, static_cast<float *>(d_out), c->stream));
     RLR_HIP(hipStreamSynchronize(c->stream));
+    return RLR_OK;
+}
+
+int32_t rlr_index_probe_bandwidth(rlr_index *ix, int32_t mode, uint32_t reps, double *gbps_out, double *ms_out)
+{
+    RLR_TRY(check_handle(ix));
+    if (!gbps_out || (mode != 0 && mode != 1))
+        return fail(RLR_E_INVALID, "mode must be 0 (read) or 1 (copy), gbps_out non-null");
+    *gbps_out = 0.0;
+    if (ms_out)
+        *ms_out = 0.0;
+    RLR_TRY(use_device(ix));
+    const size_t bytes = static_cast<size_t>(ix->n_rows) * row_bytes(ix);
+    if (bytes < (1u << 20))
+        return fail(RLR_E_INVALID, "the probe needs at least 1 MiB of rows");
+    reps = std::max(reps, 1u);
+    CtxLease lease(ix);
+    RLR_TRY(ctx_acquire(ix, &lease.c));
+    Ctx *c = lease.c;
+    hipStream_t s = c->stream;
+    void *scratch = nullptr;
+    int32_t st = RLR_OK;
+    double best_ms = 0.0;
+    size_t moved = 0;
+    auto timed = [&](auto &&launch) -> int32_t { // one warm-up, then `reps` launches between two events
+        RLR_HIP(launch());
+        RLR_HIP(hipEventRecord(c->ev[0], s));
+        for (uint32_t i = 0; i < reps; ++i)
+            RLR_HIP(launch());
+        RLR_HIP(hipEventRecord(c->ev[1], s));
+        RLR_HIP(hipStreamSynchronize(s));
+        float ms = 0;
+        RLR_HIP(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        const double per = static_cast<double>(ms) / reps;
+        if (best_ms == 0.0 || per < best_ms)
+            best_ms = per;
+        return RLR_OK;
+    };
+    if (mode == 0) {
+        RLR_HIP(rlr::dev_malloc(&scratch, static_cast<size_t>(ix->n_cu) * 8 * 256 * sizeof(float)));
+        moved = bytes / 1024 * 1024;
+        for (int shape = 0; shape < 3 && st == RLR_OK; ++shape)
+            st = timed([&] { return launch_probe_read(ix->d_rows, bytes, static_cast<float *>(scratch), ix->n_cu, shape, s); });
+    } else {
+        const size_t half = std::min<size_t>(bytes / 2, 4ull << 30) & ~static_cast<size_t>(255);
+        hipError_t e = rlr::dev_malloc(&scratch, half);
+        if (e != hipSuccess)
+            return fail(RLR_E_OOM, "scratch allocation of %zu bytes for the copy probe failed", half);
+        moved = 2 * half;
+        st = timed([&] { return hipMemcpyAsync(scratch, ix->d_rows, half, hipMemcpyDeviceToDevice, s); });
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    if (st != RLR_OK)
+        return st;
+    *gbps_out = static_cast<double>(moved) / (best_ms * 1e-3) / 1e9;
+    if (ms_out)
+        *ms_out = best_ms;
     return RLR_OK;
 }
 

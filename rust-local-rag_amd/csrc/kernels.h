@@ -36,6 +36,9 @@ hipError_t launch_scan(const ScanArgs &a, hipStream_t stream);
 bool launch_scan_multi(const ScanArgs &a, uint32_t q_pitch, uint32_t n_queries, size_t score_stride, hipStream_t s,
                        hipError_t *err);
 
+// read-only streaming probe over `bytes` of device memory (sink: blocks * 256 floats, blocks <= n_cu * 8); shape 0..2
+hipError_t launch_probe_read(const void *p, size_t bytes, float *sink, int n_cu, int shape, hipStream_t s);
+
 // ---- select.hip : radix select / collect / sort -------------------------
 // Selection state kept on the device between the stages of one query.
 struct SelectState {
@@ -47,6 +50,11 @@ struct SelectState {
     uint32_t n_cand;     // collect counter (may exceed cap)
     uint32_t cap;        // in : candidate buffer capacity
     uint32_t pad;
+    // fused tail (tail.hip); all four are zero between two queries of a context
+    uint32_t n_work;     // candidate slots handed out so far (becomes n_cand when the tail finishes)
+    uint32_t done;       // workgroups of the refine-mode stage 2 that have finished their slice
+    uint32_t flags;      // bit 0: a workgroup found more candidates in its slice than its local list holds
+    uint32_t mode;       // written by stage 1: 1 = direct (candidates collected and re-scored there), 2 = refine
 };
 hipError_t launch_collect(const float *scores, uint32_t n, SelectState *st, uint32_t *cand,
                           int n_cu, hipStream_t s);
@@ -61,6 +69,37 @@ hipError_t launch_sort_desc(uint64_t *packed, uint32_t n_pad, hipStream_t s);
 hipError_t launch_batch_select(const float *scores, uint32_t n, size_t score_stride, uint32_t q_count,
                                uint32_t *hist, SelectState *st, float two_eps, float *tau_out, uint64_t *cand,
                                uint32_t cand_stride, int n_cu, hipStream_t s);
+
+// ---- tail.hip : everything behind the scan of a single-query search in two launches ----------------
+// stage 1: bin search over hist1 (folded in), then either DIRECT -- at most `direct_max` scores sit in or above the
+//          k-th score's digit-1 bin: every workgroup appends the rows of its slice at or above (bin floor - band) and
+//          re-scores them in reference order on the spot (packed[slot] = (exact score, row)) -- or REFINE: the digit-2
+//          histogram of that bin (what launch_hist2_find1 does);
+// stage 2: DIRECT: workgroup 0 sorts and emits; REFINE: digit-2 bin search, collect + re-score per workgroup, the
+//          workgroup that finishes last sorts and emits.  Both clear the two histograms for the next query.
+// out == nullptr: no sort / emit (the caller orders packed[0, st->n_cand) itself); *meta receives the candidate count.
+// false: the row shape does not fit the staged re-score (the caller takes the split five-launch pipeline).
+struct TailArgs {
+    const float *scores;
+    uint32_t n;
+    uint32_t *hist; // 2 * kHistBins (digit 1, digit 2), zero on entry, zero again when stage 2 has run
+    SelectState *st;
+    uint32_t k, cap;
+    float two_eps;
+    const void *rows;
+    uint32_t pitch16, dim;
+    int dtype;
+    const float *query;
+    uint64_t *packed; // cap entries
+    uint64_t *out;
+    uint64_t *meta;
+    bool unordered;
+    uint32_t direct_max;
+    int n_cu;
+};
+bool tail_fits(uint32_t pitch16, uint32_t dim, int dtype);
+hipError_t launch_tail_stage1(const TailArgs &a, hipStream_t s);
+hipError_t launch_tail_stage2(const TailArgs &a, hipStream_t s);
 
 // ---- gemm.hip : batched queries, MFMA nomination + per-query exact finish ----------------
 float nomination_eps(uint32_t dim, int dtype);

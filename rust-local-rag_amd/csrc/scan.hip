@@ -630,6 +630,47 @@ hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Read-only streaming probe (the measured-peak denominator of bench.py's roofline, SURVEY.md 8(d) "re-measure on the
+// box"): the scan's row stream with the arithmetic removed -- every wave reads bursts of U consecutive KiB with
+// non-temporal 16-byte loads, adds the words up and keeps the sum (one store per wave, so the loads cannot be dropped).
+// ---------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256) void probe_read_kernel(const float4 *__restrict__ p, size_t n_kib, float *__restrict__ sink)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave = static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const size_t n_waves = static_cast<size_t>(gridDim.x) * 4;
+    float acc = 0.0f;
+    for (size_t b = wave * U; b < n_kib; b += n_waves * U) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            x[u] = ld16<true>(p + min(b + u, n_kib - 1) * 64 + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc += (x[u].x + x[u].y) + (x[u].z + x[u].w);
+    }
+    sink[wave * 64 + lane] = acc;
+}
+
+// bytes / 1024 KiB are read; sink holds blocks * 256 floats.  shape: 0 = one workgroup per CU, 12 KiB bursts (the
+// headline scan's shape), 1 = four per CU, 8 KiB bursts, 2 = eight per CU, 4 KiB bursts.
+hipError_t launch_probe_read(const void *p, size_t bytes, float *sink, int n_cu, int shape, hipStream_t s)
+{
+    const size_t n_kib = bytes / 1024;
+    if (n_kib == 0)
+        return hipSuccess;
+    const float4 *p4 = static_cast<const float4 *>(p);
+    if (shape == 0)
+        hipLaunchKernelGGL(probe_read_kernel<12>, dim3(n_cu), dim3(256), 0, s, p4, n_kib, sink);
+    else if (shape == 1)
+        hipLaunchKernelGGL(probe_read_kernel<8>, dim3(n_cu * 4), dim3(256), 0, s, p4, n_kib, sink);
+    else
+        hipLaunchKernelGGL(probe_read_kernel<4>, dim3(n_cu * 8), dim3(256), 0, s, p4, n_kib, sink);
+    return hipGetLastError();
+}
+
 // 2..8 queries over f32 rows whose pitch is a multiple of 1 KiB (256/512/768/1024-d); false otherwise
 bool launch_scan_multi(const ScanArgs &a, uint32_t q_pitch, uint32_t n_queries, size_t score_stride, hipStream_t s,
                        hipError_t *err)

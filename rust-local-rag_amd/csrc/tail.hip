@@ -1,0 +1,323 @@
+// tail.hip -- everything a single-query search does behind the scan, in two launches.
+//
+// The reference sorts every scored chunk and takes the first `initial_k` (/root/reference/src/rag_engine.rs:543-548).
+// Here the scan (scan.hip) leaves the nominated scores (4 B per row) and the digit-1 radix histogram; what is left is
+// integer work on those 4 bytes per row plus the reference-order re-score (`dot_product`, :1777-1779) of the
+// handful of rows that survive.  Rounds 1-3 ran it as four dependent launches (digit-2 histogram, collect, re-score,
+// sort: ~31 us of kernels and three launch boundaries, each of the first two a pass over the score array).  Now:
+//
+//   stage 1 (256-thread workgroups over the score array): every workgroup repeats the digit-1 bin search from the
+//     8 KB histogram.  DIRECT mode -- at most `direct_max` scores sit in or above the bin of the k-th score, the
+//     usual case up to a few million rows: the rows of its slice at or above (bin floor - guard band) are
+//     appended to the candidate list (one slot reservation per workgroup) and re-scored on the spot by the workgroup
+//     that found them -- coalesced row loads, products in parallel, one strict left-to-right chain per candidate
+//     (staged_dot.h).  REFINE mode -- a crowded bin: the digit-2 histogram of that bin, as before.
+//   stage 2 (1024-thread workgroups): DIRECT: workgroup 0 sorts the candidates in LDS and emits the best k; the others
+//     only help clearing the histogram.  REFINE: digit-2 bin search, then collect + re-score exactly as above, and the
+//     workgroup that finishes LAST (a counter in SelectState, agent-scope fences around it) sorts and emits.
+//
+// No workgroup ever waits for another one (no grid barrier): kernels of several searches may share the device.
+// HBM/L2 traffic: the 4 n bytes of scores once (DIRECT) or twice (REFINE) + dim x elem bytes per candidate.
+#include "common.h"
+#include "kernels.h"
+#include "lds_select.h"
+#include "select_dev.h"
+#include "sort_emit.h"
+#include "staged_dot.h"
+#include "../../include/rlr_gpu.h"
+
+#include <algorithm>
+
+namespace rlr {
+
+namespace {
+
+constexpr uint32_t kLocalCap = 1024;    // candidates one workgroup keeps for its own re-score
+constexpr uint32_t kSortBytes = 4096 * 8 + 2048 * 4; // sort_emit_body's LDS: 4096 keys + a 2048-bin histogram
+
+struct TailDev {
+    const float *scores;
+    uint32_t n;
+    uint32_t *hist;
+    SelectState *st;
+    uint32_t k, cap;
+    float two_eps;
+    const float4 *rows;
+    uint32_t pitch16, dim;
+    const float *query;
+    uint64_t *packed;
+    uint64_t *out;
+    uint64_t *meta;
+    uint32_t unordered;
+    uint32_t direct_max;
+    uint32_t cpb;
+};
+
+// The rows of this workgroup's slice whose nominated score key is >= key_lo: reserve their slots in the global candidate
+// list, re-score them in reference order, store (exact score, row).  Called by all NT threads; s_mem = query + products.
+template <bool F16, int NT>
+__device__ __forceinline__ void collect_rescore(const TailDev &a, uint32_t key_lo, float *s_mem)
+{
+    __shared__ uint32_t s_row[kLocalCap];
+    __shared__ uint32_t s_cnt, s_base;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0)
+        s_cnt = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * NT;
+    const uint32_t n4 = a.n / 4;
+    const float4 *s4 = reinterpret_cast<const float4 *>(a.scores);
+    for (uint32_t i = blockIdx.x * NT + tid; i < n4; i += stride) {
+        const float4 v = s4[i];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (score_key(e[j]) >= key_lo) {
+                const uint32_t l = atomicAdd(&s_cnt, 1u);
+                if (l < kLocalCap)
+                    s_row[l] = i * 4 + j;
+            }
+        }
+    }
+    for (uint32_t i = n4 * 4 + blockIdx.x * NT + tid; i < a.n; i += stride) {
+        if (score_key(a.scores[i]) >= key_lo) {
+            const uint32_t l = atomicAdd(&s_cnt, 1u);
+            if (l < kLocalCap)
+                s_row[l] = i;
+        }
+    }
+    __syncthreads();
+    const uint32_t found = s_cnt;
+    if (found == 0)
+        return; // (uniform)
+    if (tid == 0) {
+        s_base = atomicAdd(&a.st->n_work, found);
+        if (found > kLocalCap) // the surplus is lost here: the finish reports an overflow and the host takes the large-candidate path
+            atomicOr(&a.st->flags, 1u);
+    }
+    const uint32_t q_floats = (a.dim + 7) & ~7u;
+    float *s_q = s_mem;
+    float *s_p = s_mem + q_floats;
+    for (uint32_t i = tid; i < q_floats; i += NT)
+        s_q[i] = i < a.dim ? a.query[i] : 0.0f;
+    __syncthreads();
+    const uint32_t base = s_base;
+    const uint32_t cnt = min(found, kLocalCap);
+    for (uint32_t g0 = 0; g0 < cnt; g0 += a.cpb) {
+        const uint32_t c = min(a.cpb, cnt - g0);
+        if (g0)
+            __syncthreads(); // the chains of the previous group have left s_p
+        const float sc = staged_reference_dot<F16, NT>(a.rows, a.pitch16, a.dim, s_q, s_p, s_row + g0, c, tid);
+        const uint32_t slot = base + g0 + tid;
+        if (tid < c && slot < a.cap)
+            a.packed[slot] = pack_result(sc, s_row[g0 + tid]);
+    }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(kSelThreads) void tail_stage1_kernel(TailDev a)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    uint32_t bin1, k2, in_bin;
+    find_rank_bin(a.hist, a.k, &bin1, &k2, &in_bin);
+    const uint32_t n_ge = a.k - k2 + in_bin; // scores in or above the digit-1 bin of the k-th
+    const bool direct = n_ge <= a.direct_max;
+    const uint32_t key_lo = band_floor_key(bin1, 0, a.two_eps);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        SelectState *st = a.st;
+        st->k = a.k;
+        st->bin1 = bin1;
+        st->k2 = k2;
+        st->cap = a.cap;
+        st->mode = direct ? 1u : 2u;
+        if (direct) {
+            st->bin2 = 0;
+            st->key_lo = key_lo;
+        }
+    }
+    if (direct) {
+        collect_rescore<F16, kSelThreads>(a, key_lo, s_mem);
+        return;
+    }
+    // REFINE: digit 2 (key bits 20..10) of the scores whose digit 1 equals bin1
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_mem);
+    for (int i = threadIdx.x; i < kHistBins; i += kSelThreads)
+        s_hist[i] = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kSelThreads;
+    const uint32_t n4 = a.n / 4;
+    const float4 *s4 = reinterpret_cast<const float4 *>(a.scores);
+    for (uint32_t i = blockIdx.x * kSelThreads + threadIdx.x; i < n4; i += stride) {
+        const float4 v = s4[i];
+        const uint32_t k0 = score_key(v.x), k1 = score_key(v.y), k2_ = score_key(v.z), k3 = score_key(v.w);
+        if ((k0 >> 21) == bin1) atomicAdd(&s_hist[(k0 >> 10) & (kHistBins - 1)], 1u);
+        if ((k1 >> 21) == bin1) atomicAdd(&s_hist[(k1 >> 10) & (kHistBins - 1)], 1u);
+        if ((k2_ >> 21) == bin1) atomicAdd(&s_hist[(k2_ >> 10) & (kHistBins - 1)], 1u);
+        if ((k3 >> 21) == bin1) atomicAdd(&s_hist[(k3 >> 10) & (kHistBins - 1)], 1u);
+    }
+    for (uint32_t i = n4 * 4 + blockIdx.x * kSelThreads + threadIdx.x; i < a.n; i += stride) {
+        const uint32_t k0 = score_key(a.scores[i]);
+        if ((k0 >> 21) == bin1) atomicAdd(&s_hist[(k0 >> 10) & (kHistBins - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t *g_hist2 = a.hist + kHistBins;
+    for (int i = threadIdx.x; i < kHistBins; i += kSelThreads) {
+        const uint32_t c = s_hist[i];
+        if (c)
+            atomicAdd(&g_hist2[i], c);
+    }
+}
+
+// One workgroup, all candidates in place: publish the count, reset the tail's counters for the next query of this
+// context, order and emit.
+__device__ __forceinline__ void tail_finish(const TailDev &a, float *s_mem)
+{
+    __shared__ uint32_t s_n;
+    SelectState *st = a.st;
+    if (threadIdx.x == 0) {
+        const uint32_t n = __hip_atomic_load(&st->n_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t fl = __hip_atomic_load(&st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t n_eff = (fl & 1u) ? max(n, a.cap + 1u) : n; // a local list overflowed: report a band overflow
+        st->n_cand = n_eff;
+        st->n_work = 0;
+        st->done = 0;
+        st->flags = 0;
+        s_n = n_eff;
+    }
+    __syncthreads();
+    const uint32_t n_eff = s_n;
+    if (a.out) {
+        uint64_t *s = reinterpret_cast<uint64_t *>(s_mem);
+        uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_mem) + 4096 * 2;
+        sort_emit_body(a.packed, n_eff, a.cap, a.out, a.k, a.meta, a.unordered != 0, s, s_hist);
+    } else if (threadIdx.x == 0 && a.meta) {
+        *a.meta = n_eff;
+    }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(1024) void tail_stage2_kernel(TailDev a)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    __shared__ uint32_t s_sel[3];
+    __shared__ uint32_t s_last;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gid = blockIdx.x * 1024 + tid;
+    SelectState *st = a.st;
+    const uint32_t mode = st->mode;
+    if (gid < kHistBins)
+        a.hist[gid] = 0; // digit 1: stage 1 was its last reader
+    if (mode == 1u) {
+        if (blockIdx.x == 0)
+            tail_finish(a, s_mem);
+        return;
+    }
+    if (mode != 2u)
+        return;
+    lds_find_rank_bin_1024(a.hist + kHistBins, st->k2, s_sel);
+    const uint32_t bin2 = s_sel[0];
+    const uint32_t key_lo = band_floor_key(st->bin1, bin2, a.two_eps);
+    collect_rescore<F16, 1024>(a, key_lo, s_mem);
+    // the workgroup that arrives last sees every other workgroup's candidates
+    __threadfence();
+    __syncthreads();
+    if (tid == 0)
+        s_last = atomicAdd(&st->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last)
+        return;
+    __threadfence();
+    for (uint32_t i = tid; i < kHistBins; i += 1024)
+        a.hist[kHistBins + i] = 0; // digit 2: every workgroup has read it
+    if (tid == 0) {
+        st->bin2 = bin2;
+        st->key_lo = key_lo;
+    }
+    tail_finish(a, s_mem);
+}
+
+bool tail_shape(uint32_t pitch16, uint32_t dim, int dtype, uint32_t *cpb_out, size_t *staging_out)
+{
+    const size_t q_bytes = static_cast<size_t>((dim + 7) & ~7u) * sizeof(float);
+    const size_t row_bytes = q_bytes + 16; // f32 products of one candidate row (+16 B pad)
+    if (pitch16 * (dtype == RLR_F16 ? 8u : 4u) < ((dim + 7) & ~7u))
+        return false; // row pitch narrower than the 8-float rounding of dim (f32 rows, dim % 8 in 1..4)
+    constexpr size_t budget = 56 * 1024; // + 4 KB of local candidate list + a few words: under the 64 KB a kernel gets by default
+    uint32_t cpb = 8;
+    while (cpb > 1 && q_bytes + cpb * row_bytes > budget)
+        cpb >>= 1;
+    if (q_bytes + cpb * row_bytes > budget)
+        return false;
+    *cpb_out = cpb;
+    *staging_out = q_bytes + cpb * row_bytes;
+    return true;
+}
+
+TailDev to_dev(const TailArgs &a, uint32_t cpb)
+{
+    TailDev d;
+    d.scores = a.scores;
+    d.n = a.n;
+    d.hist = a.hist;
+    d.st = a.st;
+    d.k = a.k;
+    d.cap = a.cap;
+    d.two_eps = a.two_eps;
+    d.rows = static_cast<const float4 *>(a.rows);
+    d.pitch16 = a.pitch16;
+    d.dim = a.dim;
+    d.query = a.query;
+    d.packed = a.packed;
+    d.out = a.out;
+    d.meta = a.meta;
+    d.unordered = a.unordered ? 1u : 0u;
+    d.direct_max = a.direct_max;
+    d.cpb = cpb;
+    return d;
+}
+
+} // namespace
+
+bool tail_fits(uint32_t pitch16, uint32_t dim, int dtype)
+{
+    uint32_t cpb;
+    size_t staging;
+    return tail_shape(pitch16, dim, dtype, &cpb, &staging);
+}
+
+hipError_t launch_tail_stage1(const TailArgs &a, hipStream_t s)
+{
+    uint32_t cpb;
+    size_t staging;
+    if (!tail_shape(a.pitch16, a.dim, a.dtype, &cpb, &staging))
+        return hipErrorInvalidValue;
+    const TailDev d = to_dev(a, cpb);
+    const size_t lds = std::max<size_t>(staging, kHistBins * sizeof(uint32_t));
+    uint32_t blocks = (a.n / 4 + kSelThreads - 1) / kSelThreads;
+    blocks = std::max<uint32_t>(1, std::min<uint32_t>(blocks, static_cast<uint32_t>(a.n_cu) * 8));
+    if (a.dtype == RLR_F16)
+        hipLaunchKernelGGL(tail_stage1_kernel<true>, dim3(blocks), dim3(kSelThreads), lds, s, d);
+    else
+        hipLaunchKernelGGL(tail_stage1_kernel<false>, dim3(blocks), dim3(kSelThreads), lds, s, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_tail_stage2(const TailArgs &a, hipStream_t s)
+{
+    uint32_t cpb;
+    size_t staging;
+    if (!tail_shape(a.pitch16, a.dim, a.dtype, &cpb, &staging))
+        return hipErrorInvalidValue;
+    const TailDev d = to_dev(a, cpb);
+    const size_t lds = std::max<size_t>(staging, kSortBytes);
+    // at least two workgroups (2048 threads clear the digit-1 histogram); REFINE mode wants a pass over the scores
+    uint32_t blocks = (a.n / 4 + 1023) / 1024;
+    blocks = std::max<uint32_t>(2, std::min<uint32_t>(blocks, static_cast<uint32_t>(a.n_cu) * 2));
+    if (a.dtype == RLR_F16)
+        hipLaunchKernelGGL(tail_stage2_kernel<true>, dim3(blocks), dim3(1024), lds, s, d);
+    else
+        hipLaunchKernelGGL(tail_stage2_kernel<false>, dim3(blocks), dim3(1024), lds, s, d);
+    return hipGetLastError();
+}
+
+} // namespace rlr

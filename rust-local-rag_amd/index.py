@@ -218,6 +218,13 @@ class GpuIndex:
         N.check(self._L.rlr_profile_read(self._h, C.byref(p), int(reset)))
         return Profile(*(getattr(p, f) for f, _ in N.ProfileC._fields_))
 
+    def probe_bandwidth(self, mode: int, reps: int = 5):
+        """measured-peak denominators over the index's own rows: mode 0 read-only stream, 1 device-to-device copy
+        -> (GB/s, ms per launch)"""
+        g, ms = C.c_double(), C.c_double()
+        N.check(self._L.rlr_index_probe_bandwidth(self._h, mode, reps, C.byref(g), C.byref(ms)))
+        return g.value, ms.value
+
 
 class MultiGpuIndex:
     """One process, several GPUs (rlr_multi_*): contiguous row shards, host-side merge."""

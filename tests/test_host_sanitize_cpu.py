@@ -44,7 +44,7 @@ def test_pools_locks_and_leases_under_thread_sanitizer(tmp_path):
     with a simulated device latency so that callers really queue on the condition variables, and a mutation between
     rounds.  Pass = no ThreadSanitizer report, no deadlock (timeout), every call returned RLR_OK."""
     csrc = os.path.join(ROOT, "rust-local-rag_amd", "csrc")
-    units = ["scan.hip", "select.hip", "exact.hip", "gemm.hip", "index.hip", "engine.cpp", "multi.cpp", "lexical.hip",
+    units = ["scan.hip", "select.hip", "tail.hip", "exact.hip", "gemm.hip", "index.hip", "engine.cpp", "multi.cpp", "lexical.hip",
              "q8.hip", "jsonio.cpp"]
     san = ["-fsanitize=thread", "-g", "-O1"]
     procs, objs = [], []
