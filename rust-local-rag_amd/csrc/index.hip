@@ -11,6 +11,8 @@
 #include "lexical_internal.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
@@ -20,6 +22,8 @@
 #include <memory>
 #include <new>
 #include <vector>
+
+#include <time.h>
 
 using namespace rlr;
 
@@ -78,6 +82,12 @@ uint32_t next_pow2(uint32_t v)
     return p;
 }
 
+// how long the recent waits of one kind took (the hybrid wait sleeps through most of that before it polls)
+struct WaitEma {
+    double us = 0.0;
+    uint32_t key = 0; // what "one kind" means to the caller (number of queries, ...): a change resets the average
+};
+
 // -------- per-call context ---------------------------------------------------------
 struct Ctx {
     hipStream_t stream = nullptr;
@@ -118,6 +128,7 @@ struct Ctx {
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
     std::vector<float> q_norm; // ||q||_2 of the staged queries (band of the 8-bit nomination scan)
+    WaitEma wait_ema;          // how long the last waits for a call's completion words took (wait_flags)
     bool hist_dirty = false; // a pipeline was enqueued and did not complete: d_hist may hold counts
     uint32_t *h_assert = nullptr; // RLR_POISON_ALLOC=1 only: pinned word the zero-histogram assertion kernel counts into
     // rlr_search_topk_device_begin / _end
@@ -140,7 +151,8 @@ struct rlr_index {
     void *d_rows = nullptr;
     int n_cu = 256;
     int scan_variant = 0;
-    bool fused_tail = true;      // select -> re-score -> sort behind the scan in two launches (tail.hip); RLR_TAIL=0: the five-launch form
+    int fused_tail = -1;         // select -> re-score -> sort behind the scan in two launches (tail.hip): RLR_TAIL=1 always, 0 never
+                                 // (the five-launch form), unset: while the corpus is small enough for the one-pass mode to be the rule
     uint32_t tail_direct_max = 1024; // RLR_TAIL_DIRECT_MAX: most scores in/above the k-th score's digit-1 bin for the one-pass mode (0: always refine)
     uint32_t batch_min = 0;   // smallest batch that takes the matrix-core path; 0 = decide by the cost model,
                               // RLR_BATCH_MIN=n forces a threshold (a huge n disables the path)
@@ -497,6 +509,137 @@ int32_t ingest(rlr_index *ix, const float *rows, uint64_t n, uint64_t first, int
     return st;
 }
 
+// ---- waiting for a query without the stream's completion signal ------------------------------------------------
+// The last kernel of a pipeline writes the query's candidate count into pinned host memory behind a system-scope fence
+// (sort_emit.h), so "the count has left kMetaPending" means "the k results are in host memory".  hipStreamSynchronize
+// learns the same thing from the queue's completion signal, which the ROCm runtime waits for in the kernel driver
+// (interrupt + wake-up: ~15-20 us between the end of the last kernel and the return, measured as device idle time
+// between two searches of a C loop); polling the word takes ~1 us.  RLR_WAIT: "hybrid" (default) polls, but sleeps
+// through the first two thirds of a wait that took more than 1.5 ms last time -- a 4.4 ms scan does not burn a core --,
+// "spin" always polls from the start, "block" is hipStreamSynchronize.
+enum WaitMode { kWaitHybrid = 0, kWaitSpin = 1, kWaitBlock = 2 };
+
+WaitMode wait_mode()
+{
+    static const WaitMode m = [] {
+        const char *v = getenv("RLR_WAIT");
+        if (v && v[0] == 's')
+            return kWaitSpin;
+        if (v && v[0] == 'b')
+            return kWaitBlock;
+        return kWaitHybrid;
+    }();
+    return m;
+}
+
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
+
+// Wait until `complete()` holds -- it reads pinned host words the device writes last (and may check them against the
+// data they cover).  The stream is queried every ~1000 polls: an error, or a drained stream with the words still
+// incomplete (a kernel that never ran), ends the wait.
+template <typename Complete>
+int32_t wait_polling(Complete &&complete, hipStream_t s, WaitEma *c, uint32_t key)
+{
+    using clk = std::chrono::steady_clock;
+    const WaitMode mode = wait_mode();
+    if (mode == kWaitBlock) {
+        RLR_HIP(hipStreamSynchronize(s));
+        return RLR_OK;
+    }
+    const auto t0 = clk::now();
+    bool slept = false;
+    if (c && c->key != key) {
+        c->key = key;
+        c->us = 0.0;
+    }
+    // (only waits of milliseconds: a timed sleep comes back 50-150 us late often enough that at 0.5 ms per query the
+    // hybrid form measured 589 us per call where polling from the start took 565 and hipStreamSynchronize 570)
+    if (mode == kWaitHybrid && c && c->us > 1500.0) {
+        const double sleep_us = 0.7 * c->us - 150.0;
+        if (sleep_us > 20.0) {
+            timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            const long add = static_cast<long>(sleep_us * 1000.0);
+            ts.tv_sec += (ts.tv_nsec + add) / 1000000000L;
+            ts.tv_nsec = (ts.tv_nsec + add) % 1000000000L;
+            (void)clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &ts, nullptr);
+            slept = true;
+        }
+    }
+    uint32_t polls = 0;
+    for (;;) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (complete())
+            break;
+        if ((++polls & 0x3FFu) == 0) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) {
+                // drained: everything the kernels stored is on its way; give it a moment, then it is an error
+                bool ok = false;
+                for (int spin = 0; spin < 100000 && !ok; ++spin) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    ok = complete();
+                    cpu_relax();
+                }
+                if (ok)
+                    break;
+                return fail(RLR_E_INTERNAL, "the stream drained but a completion word was never written");
+            }
+            if (e != hipErrorNotReady)
+                return fail(RLR_E_HIP, "stream failed while a search was in flight: %s", hipGetErrorString(e));
+        }
+        cpu_relax();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (c) {
+        const double us = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+        if (slept && polls == 0) // the words were there when the sleep ended: it was too long (a smaller corpus than last time)
+            c->us *= 0.5;
+        else
+            c->us = c->us == 0.0 ? us : 0.75 * c->us + 0.25 * us;
+    }
+    return RLR_OK;
+}
+
+// The completion words of nq single-query pipelines (sort_emit.h: count | checksum << 32, written last).  res != null:
+// the k result words of each query are in host memory too and must match the checksum -- the word alone can overtake
+// the results on their way through PCIe.
+int32_t wait_results(const volatile uint64_t *meta, const volatile uint64_t *res, uint32_t nq, uint32_t k, uint32_t limit,
+                     hipStream_t s, WaitEma *c)
+{
+    uint32_t verified = nq; // queries [verified, nq) are complete (the last one finishes last)
+    return wait_polling(
+        [&]() {
+            while (verified > 0) {
+                const uint32_t q = verified - 1;
+                const uint64_t m = meta[q];
+                if (m == kMetaPending)
+                    return false;
+                if (res && static_cast<uint32_t>(m) <= limit) { // (an overflowed query emits only its marker: nothing to verify)
+                    uint32_t chk = 0;
+                    const volatile uint64_t *r = res + static_cast<size_t>(q) * k;
+                    for (uint32_t i = 0; i < k; ++i) {
+                        const uint64_t w = r[i];
+                        if (w)
+                            chk += result_chk_term(w, i);
+                    }
+                    if (chk != static_cast<uint32_t>(m >> 32))
+                        return false;
+                }
+                verified--;
+            }
+            return true;
+        },
+        s, c, nq);
+}
+
 // ---- the search pipeline ------------------------------------------------------------
 struct SearchPlan {
     uint32_t k;        // per query, already clamped to n_rows
@@ -603,14 +746,16 @@ struct MergeBases {
     uint64_t base[16];
 };
 
+
 __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restrict__ gathered, uint32_t world,
                                                          uint32_t n_queries, uint32_t k, MergeBases bases,
                                                          uint64_t *__restrict__ rows_out, float *__restrict__ cos_out,
-                                                         uint32_t *__restrict__ n_out)
+                                                         uint32_t *__restrict__ n_out, uint64_t *__restrict__ flag_out)
 {
     __shared__ uint64_t s[8192];
     __shared__ uint32_t s_valid;
     __shared__ uint32_t s_valid_overflow;
+    __shared__ uint32_t s_chk;
     const uint32_t q = blockIdx.x;
     const uint32_t n = world * k;
     uint32_t n_pad = 1;
@@ -619,6 +764,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
     if (threadIdx.x == 0) {
         s_valid = 0;
         s_valid_overflow = 0;
+        s_chk = 0;
     }
     __syncthreads();
     uint32_t valid = 0;
@@ -676,11 +822,22 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
     const uint32_t m = min(s_valid, k);
     for (uint32_t i = threadIdx.x; i < k; i += 256) {
         const uint64_t v = i < m ? s[i] : 0ull;
-        rows_out[static_cast<size_t>(q) * k + i] = i < m ? 0xFFFFFFFFull - (v & 0xFFFFFFFFull) : ~0ull;
-        cos_out[static_cast<size_t>(q) * k + i] = key_score(static_cast<uint32_t>(v >> 32));
+        const uint64_t row = i < m ? 0xFFFFFFFFull - (v & 0xFFFFFFFFull) : ~0ull;
+        const float cs = key_score(static_cast<uint32_t>(v >> 32));
+        rows_out[static_cast<size_t>(q) * k + i] = row;
+        cos_out[static_cast<size_t>(q) * k + i] = cs;
+        atomicAdd(&s_chk, result_chk_term(row, i) + result_chk_term(__builtin_bit_cast(uint32_t, cs), i + k));
     }
-    if (threadIdx.x == 0)
-        n_out[q] = s_valid_overflow ? 0xFFFFFFFFu : m;
+    // count | checksum << 32 last, behind a system-scope fence: a host that pre-set the word to kMetaPending polls it and
+    // verifies the checksum over the rows and scores it finds in its memory (sort_emit.h: the word can overtake them)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t cnt = s_valid_overflow ? 0xFFFFFFFFu : m;
+        n_out[q] = cnt;
+        if (flag_out)
+            flag_out[q] = (static_cast<uint64_t>(s_chk) << 32) | cnt;
+    }
 }
 
 // The large-candidate path's finish (a guard band that outgrew the 4096-entry LDS sort: dense score distributions under
@@ -1206,7 +1363,12 @@ hipError_t enqueue_query_rest(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPl
     const bool img = !q8 && scan_over_image(ix);
     const float band = q8 ? q8_two_eps(ix, qi < c->q_norm.size() ? c->q_norm[qi] : 1.0f, p.two_eps * 0.5f)
                           : (img ? p.two_eps_img : p.two_eps);
-    if (ix->fused_tail && p.cap <= kLdsSortCap && tail_fits(ix->pitch16, ix->dim, ix->dtype)) {
+    // Up to a few million rows the k-th score's digit-1 bin holds a few hundred scores and the tail's one-pass (DIRECT)
+    // mode applies: 15 + 8 us at 1.25 M rows where the four launches took 30 + three launch boundaries.  At 10 M rows the
+    // bin holds thousands, both forms make two passes over the 40 MB of scores, and the four specialised kernels win
+    // (31 us against 15 + 27: their histogram / collect passes run at a third of the registers and LDS).
+    const bool fused = ix->fused_tail < 0 ? ix->n_rows <= 4000000ull : ix->fused_tail != 0;
+    if (fused && p.cap <= kLdsSortCap && tail_fits(ix->pitch16, ix->dim, ix->dtype)) {
         // two launches (tail.hip): bin search + collect + re-score (or the digit-2 histogram of a crowded bin), then sort + emit
         TailArgs ta;
         ta.scores = c->d_scores;
@@ -1647,6 +1809,9 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     const bool host_direct = !d_out_user;
     uint64_t *q_out = host_direct ? h_res : d_out;
     uint64_t *q_meta = h_meta; // the candidate count always goes straight to the host (the overflow check needs it)
+    if (wait_mode() != kWaitBlock)
+        for (uint32_t q = 0; q < nq; ++q)
+            h_meta[q] = kMetaPending; // each pipeline's last store replaces it (sort_emit.h): what the wait below polls
     if (!timed || nq == 1) {
         // (with profiling on, a single query's four events are read after the one final sync)
         for (uint32_t q = 0; q < nq; ++q)
@@ -1666,7 +1831,11 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
             total_ms += a + b + d;
         }
     }
-    RLR_HIP(hipStreamSynchronize(s));
+    if (timed)
+        RLR_HIP(hipStreamSynchronize(s)); // (the events are read below)
+    else
+        RLR_TRY(wait_results(h_meta, host_direct ? h_res : nullptr, nq, p.k, std::min<uint32_t>(p.cap, kLdsSortCap), s,
+                             &c->wait_ema));
     RLR_TRY(check_hist_assert(c));
     if (timed && nq == 1) {
         float a = 0, b = 0, d = 0;
@@ -1804,7 +1973,7 @@ int32_t rlr_index_create(uint32_t dim, int32_t dtype, int32_t device_id, rlr_ind
     if (const char *v = getenv("RLR_SCAN_VARIANT"))
         ix->scan_variant = static_cast<int>(strtol(v, nullptr, 0));
     if (const char *v = getenv("RLR_TAIL"))
-        ix->fused_tail = v[0] != '0';
+        ix->fused_tail = v[0] != '0' ? 1 : 0;
     if (const char *v = getenv("RLR_TAIL_DIRECT_MAX"))
         ix->tail_direct_max = static_cast<uint32_t>(std::min<unsigned long>(strtoul(v, nullptr, 0), 4096));
     if (const char *v = getenv("RLR_BATCH_MIN"))
@@ -2140,6 +2309,9 @@ int32_t rlr_search_topk_device_begin(rlr_index *ix, const float *queries, uint32
     c->stream = static_cast<hipStream_t>(stream);
     hipStream_t s = c->stream;
     c->hist_dirty = true;
+    if (wait_mode() != kWaitBlock)
+        for (uint32_t q = 0; q < n_queries; ++q)
+            h_meta[q] = kMetaPending; // (what _end polls instead of the stream's completion signal)
     hipError_t e = hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s);
     uint64_t *out = static_cast<uint64_t *>(d_packed_out);
     for (uint32_t q = 0; q < n_queries && e == hipSuccess; ++q)
@@ -2172,7 +2344,10 @@ int32_t rlr_search_topk_device_end(rlr_index *ix, void *ticket, uint32_t *n_over
     CtxLease lease(ix);
     lease.c = c;
     RLR_TRY(use_device(ix));
-    RLR_HIP(hipStreamSynchronize(c->pending_stream));
+    if (c->pending_timed)
+        RLR_HIP(hipStreamSynchronize(c->pending_stream)); // (the events are read below)
+    else // usually already there: whatever the caller queued behind the pipelines and waited for ran after them
+        RLR_TRY(wait_results(c->pending_meta, nullptr, c->pending_q, c->pending_k, kLdsSortCap, c->pending_stream, nullptr));
     RLR_TRY(check_hist_assert(c));
     uint32_t over = 0;
     uint64_t n_cand = 0;
@@ -2226,7 +2401,7 @@ int32_t rlr_merge_topk(int32_t device_id, const void *d_gathered, uint32_t world
     thread_local void *h_buf = nullptr;
     thread_local size_t h_cap = 0;
     const size_t nk = static_cast<size_t>(n_queries) * k;
-    const size_t need = nk * (sizeof(uint64_t) + sizeof(float)) + n_queries * sizeof(uint32_t) + 64;
+    const size_t need = nk * (sizeof(uint64_t) + sizeof(float)) + n_queries * (sizeof(uint32_t) + sizeof(uint64_t)) + 64;
     if (h_cap < need) {
         if (h_buf)
             (void)hipHostFree(h_buf);
@@ -2236,16 +2411,42 @@ int32_t rlr_merge_topk(int32_t device_id, const void *d_gathered, uint32_t world
         h_cap = std::max<size_t>(need, 1 << 16);
     }
     uint64_t *h_rows = static_cast<uint64_t *>(h_buf);
-    float *h_cos = reinterpret_cast<float *>(h_rows + nk);
+    uint64_t *h_flag = h_rows + nk;
+    float *h_cos = reinterpret_cast<float *>(h_flag + n_queries);
     uint32_t *h_n = reinterpret_cast<uint32_t *>(h_cos + nk);
     rlr::MergeBases mb;
     for (uint32_t r = 0; r < 16; ++r)
         mb.base[r] = r < world ? bases[r] : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    for (uint32_t q = 0; q < n_queries; ++q)
+        h_flag[q] = kMetaPending;
     hipLaunchKernelGGL(rlr::merge_topk_kernel, dim3(n_queries), dim3(256), 0, s, static_cast<const uint64_t *>(d_gathered),
-                       world, n_queries, k, mb, h_rows, h_cos, h_n);
+                       world, n_queries, k, mb, h_rows, h_cos, h_n, h_flag);
     RLR_HIP(hipGetLastError());
-    RLR_HIP(hipStreamSynchronize(s));
+    // (this wait usually spans the scans queued in front of the merge on the same stream)
+    thread_local WaitEma merge_wait;
+    const volatile uint64_t *vf = h_flag;
+    const volatile uint64_t *vr = h_rows;
+    const volatile uint32_t *vc = reinterpret_cast<const volatile uint32_t *>(h_cos);
+    uint32_t verified = n_queries;
+    RLR_TRY(wait_polling(
+        [&]() {
+            while (verified > 0) {
+                const uint32_t q = verified - 1;
+                const uint64_t m = vf[q];
+                if (m == kMetaPending)
+                    return false;
+                uint32_t chk = 0;
+                for (uint32_t i = 0; i < k; ++i)
+                    chk += result_chk_term(vr[static_cast<size_t>(q) * k + i], i) +
+                           result_chk_term(vc[static_cast<size_t>(q) * k + i], i + k);
+                if (chk != static_cast<uint32_t>(m >> 32))
+                    return false;
+                verified--;
+            }
+            return true;
+        },
+        s, &merge_wait, world * 65536u + n_queries));
     std::memcpy(rows_out, h_rows, nk * sizeof(uint64_t));
     std::memcpy(cos_out, h_cos, nk * sizeof(float));
     std::memcpy(n_out, h_n, n_queries * sizeof(uint32_t));

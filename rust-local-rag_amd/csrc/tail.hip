@@ -55,8 +55,9 @@ struct TailDev {
 
 // The rows of this workgroup's slice whose nominated score key is >= key_lo: reserve their slots in the global candidate
 // list, re-score them in reference order, store (exact score, row).  Called by all NT threads; s_mem = query + products.
+// Returns the number of candidates found in the slice (uniform over the workgroup).
 template <bool F16, int NT>
-__device__ __forceinline__ void collect_rescore(const TailDev &a, uint32_t key_lo, float *s_mem)
+__device__ __forceinline__ uint32_t collect_rescore(const TailDev &a, uint32_t key_lo, float *s_mem)
 {
     __shared__ uint32_t s_row[kLocalCap];
     __shared__ uint32_t s_cnt, s_base;
@@ -67,15 +68,28 @@ __device__ __forceinline__ void collect_rescore(const TailDev &a, uint32_t key_l
     const uint32_t stride = gridDim.x * NT;
     const uint32_t n4 = a.n / 4;
     const float4 *s4 = reinterpret_cast<const float4 *>(a.scores);
-    for (uint32_t i = blockIdx.x * NT + tid; i < n4; i += stride) {
-        const float4 v = s4[i];
-        const float e[4] = {v.x, v.y, v.z, v.w};
+    // four independent 16-byte loads in flight per thread (a 10 M-row pass is ~10 loads per thread: issued one at a time
+    // behind the compare-and-append it was latency-bound)
+    for (uint32_t i0 = blockIdx.x * NT + tid; i0 < n4; i0 += 4 * stride) {
+        float4 v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (score_key(e[j]) >= key_lo) {
-                const uint32_t l = atomicAdd(&s_cnt, 1u);
-                if (l < kLocalCap)
-                    s_row[l] = i * 4 + j;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * stride;
+            v[u] = s4[i < n4 ? i : i0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * stride;
+            if (i >= n4)
+                break;
+            const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (score_key(e[j]) >= key_lo) {
+                    const uint32_t l = atomicAdd(&s_cnt, 1u);
+                    if (l < kLocalCap)
+                        s_row[l] = i * 4 + j;
+                }
             }
         }
     }
@@ -89,7 +103,7 @@ __device__ __forceinline__ void collect_rescore(const TailDev &a, uint32_t key_l
     __syncthreads();
     const uint32_t found = s_cnt;
     if (found == 0)
-        return; // (uniform)
+        return 0; // (uniform)
     if (tid == 0) {
         s_base = atomicAdd(&a.st->n_work, found);
         if (found > kLocalCap) // the surplus is lost here: the finish reports an overflow and the host takes the large-candidate path
@@ -109,9 +123,10 @@ __device__ __forceinline__ void collect_rescore(const TailDev &a, uint32_t key_l
             __syncthreads(); // the chains of the previous group have left s_p
         const float sc = staged_reference_dot<F16, NT>(a.rows, a.pitch16, a.dim, s_q, s_p, s_row + g0, c, tid);
         const uint32_t slot = base + g0 + tid;
-        if (tid < c && slot < a.cap)
-            a.packed[slot] = pack_result(sc, s_row[g0 + tid]);
+        if (tid < c && slot < a.cap) // agent-scope store: written through to where the other XCDs' workgroups read it (stage 2, REFINE)
+            __hip_atomic_store(&a.packed[slot], pack_result(sc, s_row[g0 + tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    return found;
 }
 
 template <bool F16>
@@ -189,7 +204,7 @@ __device__ __forceinline__ void tail_finish(const TailDev &a, float *s_mem)
     if (a.out) {
         uint64_t *s = reinterpret_cast<uint64_t *>(s_mem);
         uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_mem) + 4096 * 2;
-        sort_emit_body(a.packed, n_eff, a.cap, a.out, a.k, a.meta, a.unordered != 0, s, s_hist);
+        sort_emit_body<true>(a.packed, n_eff, a.cap, a.out, a.k, a.meta, a.unordered != 0, s, s_hist);
     } else if (threadIdx.x == 0 && a.meta) {
         *a.meta = n_eff;
     }
@@ -218,15 +233,18 @@ __global__ __launch_bounds__(1024) void tail_stage2_kernel(TailDev a)
     const uint32_t bin2 = s_sel[0];
     const uint32_t key_lo = band_floor_key(st->bin1, bin2, a.two_eps);
     collect_rescore<F16, 1024>(a, key_lo, s_mem);
-    // the workgroup that arrives last sees every other workgroup's candidates
-    __threadfence();
+    // The workgroup that arrives last orders and emits every workgroup's candidates.  The candidates were stored with
+    // agent-scope (write-through) stores and are read back below with agent-scope loads, so no workgroup needs an
+    // agent-scope FENCE -- which writes back and invalidates its XCD's whole L2 while the other workgroups still stream
+    // scores through it: with one fence per wave the stage took 150 us at 10 M rows, with one per workgroup that had
+    // candidates 36 us.  The barrier below waits for this workgroup's stores (vmcnt 0) before thread 0 counts it done.
     __syncthreads();
     if (tid == 0)
         s_last = atomicAdd(&st->done, 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (!s_last)
         return;
-    __threadfence();
+    __threadfence(); // (one workgroup, once per query: acquire for everything it reads from here on)
     for (uint32_t i = tid; i < kHistBins; i += 1024)
         a.hist[kHistBins + i] = 0; // digit 2: every workgroup has read it
     if (tid == 0) {
@@ -310,9 +328,11 @@ hipError_t launch_tail_stage2(const TailArgs &a, hipStream_t s)
         return hipErrorInvalidValue;
     const TailDev d = to_dev(a, cpb);
     const size_t lds = std::max<size_t>(staging, kSortBytes);
-    // at least two workgroups (2048 threads clear the digit-1 histogram); REFINE mode wants a pass over the scores
+    // at least two workgroups (2048 threads clear the digit-1 histogram); REFINE mode wants a pass over the scores.  One
+    // 1024-thread workgroup per CU is what is resident at this kernel's register count: a second round of workgroups would
+    // only start when the first has finished its bin search, pass and re-score.
     uint32_t blocks = (a.n / 4 + 1023) / 1024;
-    blocks = std::max<uint32_t>(2, std::min<uint32_t>(blocks, static_cast<uint32_t>(a.n_cu) * 2));
+    blocks = std::max<uint32_t>(2, std::min<uint32_t>(blocks, static_cast<uint32_t>(a.n_cu)));
     if (a.dtype == RLR_F16)
         hipLaunchKernelGGL(tail_stage2_kernel<true>, dim3(blocks), dim3(1024), lds, s, d);
     else

@@ -106,6 +106,8 @@ class ShardedIndex:
         self._bases_h = np.array([shard_range(n_total, r, self.world)[0] for r in range(self.world)], dtype=np.uint64)
         self._local = None
         self._gath = None
+        self._stream0 = None
+        self._merge_args = None
         self._time_exchange = False
         self._exchange_ms = 0.0
         self._exchange_n = 0
@@ -140,7 +142,11 @@ class ShardedIndex:
             self._rows_h = np.zeros((nq, k), dtype=np.uint64)
             self._cos_h = np.zeros((nq, k), dtype=np.float32)
             self._n_h = np.zeros(nq, dtype=np.uint32)
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        # torch's current stream carries the collective; without one (world 1) the library's calls only need A stream
+        if self.world > 1 or self.dist is not None or self._stream0 is None:
+            stream = self._stream0 = torch.cuda.current_stream(self.dev).cuda_stream
+        else:
+            stream = self._stream0
         if _redo:
             self.index.search_topk_device(q, k, self._local.data_ptr(), stream)   # synchronous, handles overflow
             ticket = None
@@ -158,9 +164,12 @@ class ShardedIndex:
             else:
                 gathered = self._local
             # merge on the GPU in one launch (rlr_merge_topk), results land in pinned host memory
-            N.check(N.lib().rlr_merge_topk(self.dev.index, C.c_void_p(gathered.data_ptr()), self.world, nq, k,
-                                           self._bases_h.ctypes.data_as(N.u64p), rows_h.ctypes.data_as(N.u64p),
-                                           cos_h.ctypes.data_as(N.f32p), n_h.ctypes.data_as(N.u32p), C.c_void_p(stream)))
+            ma = self._merge_args
+            if ma is None or ma[0] is not rows_h:   # (ctypes views of the persistent buffers: ~1 us each to build)
+                ma = self._merge_args = (rows_h, self._bases_h.ctypes.data_as(N.u64p), rows_h.ctypes.data_as(N.u64p),
+                                         cos_h.ctypes.data_as(N.f32p), n_h.ctypes.data_as(N.u32p), N.lib().rlr_merge_topk)
+            N.check(ma[5](self.dev.index, C.c_void_p(gathered.data_ptr()), self.world, nq, k, ma[1], ma[2], ma[3], ma[4],
+                          C.c_void_p(stream)))
             if self._time_exchange:
                 self._ev[1].record()
         finally:

@@ -196,6 +196,11 @@ hipError_t hipStreamSynchronize(hipStream_t s)
         std::this_thread::sleep_for(std::chrono::microseconds(us));
     return hipSuccess;
 }
+hipError_t hipStreamQuery(hipStream_t s)
+{
+    touch(s);
+    return hipSuccess;
+}
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int)
 {
     touch(s);

@@ -108,7 +108,9 @@ def test_tail_local_list_overflow_takes_the_large_candidate_path(rlr, oracle, mo
     try:
         ix.profile_read(reset=True)
         check(ix, oracle, rows, qn, k)
-        assert ix.profile_read().n_retries == 1
+        # stage 1 hands every workgroup ONE 1024-row chunk up to 2 M rows: its local list cannot overflow here; stage 2's
+        # workgroups take 4096-row chunks and this one does
+        assert ix.profile_read().n_retries == (1 if mode == "refine" else 0)
         check(ix, oracle, rows, oracle.normalize(oracle.synth_query(dim, seed=43)), k)  # the counters were reset: next query fine
     finally:
         ix.close()

@@ -67,7 +67,7 @@ def test_pools_locks_and_leases_under_thread_sanitizer(tmp_path):
     # (host-only objects name their missing device image as an undefined symbol; the stub runtime never reads it)
     subprocess.run([CLANGXX, *san, *objs, "-o", exe, "-lpthread", "-ldl", "-Wl,--unresolved-symbols=ignore-all"], check=True)
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1 exitcode=66", STUB_SYNC_US="300",
-               RLR_MAX_CONTEXTS="4")
+               RLR_MAX_CONTEXTS="4", RLR_WAIT="block")  # (the stub's kernels never write a completion word to poll)
     env.pop("LD_PRELOAD", None)
     out = subprocess.run([exe, "3", "120"], capture_output=True, text=True, env=env, timeout=900)
     assert "ThreadSanitizer" not in out.stderr, out.stderr[-8000:]
