@@ -371,6 +371,8 @@ int32_t rlr_profile_read(rlr_index *idx, rlr_profile *out, int32_t reset);
  *           up, one store per wave), the best of three launch shapes, mean of `reps` launches after one warm-up;
  *   mode 1  device-to-device copy (hipMemcpyAsync) of the first min(half of the rows, 4 GiB) into a scratch
  *           allocation; *gbps_out counts bytes read + bytes written, as copy bandwidths are usually quoted.
+ *   mode 2 / 3  diagnostics: the scan kernel itself (zero query, scores into a scratch array) without / with the
+ *           radix histogram it flushes with global atomics; *gbps_out = row bytes / time.
  * HIP events on the probe's own stream.  Benchmark support: no search may run on the index meanwhile. */
 int32_t rlr_index_probe_bandwidth(rlr_index *idx, int32_t mode, uint32_t reps, double *gbps_out, double *ms_out);
 

@@ -21,6 +21,7 @@
 #include <mutex>
 #include <memory>
 #include <new>
+#include <string>
 #include <vector>
 
 #include <time.h>
@@ -81,6 +82,15 @@ uint32_t next_pow2(uint32_t v)
         p <<= 1;
     return p;
 }
+
+// The allocation behind an index's row matrix.  Where the rows land in physical memory moves the streaming rate of the scan by
+// up to 1.5 %, so the policy is explicit: see rows_alloc.
+struct RowBlock {
+    void *raw = nullptr;     // what hipFree / hipMemAddressFree takes
+    size_t raw_bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles; // virtual-memory form: one physical allocation per slab
+    size_t slab = 0;
+};
 
 // how long the recent waits of one kind took (the hybrid wait sleeps through most of that before it polls)
 struct WaitEma {
@@ -149,6 +159,7 @@ struct rlr_index {
     uint64_t n_rows = 0;
     uint64_t cap_rows = 0;
     void *d_rows = nullptr;
+    RowBlock rows_block;      // how d_rows was obtained (rows_alloc / rows_free)
     int n_cu = 256;
     int scan_variant = 0;
     int fused_tail = -1;         // select -> re-score -> sort behind the scan in two launches (tail.hip): RLR_TAIL=1 always, 0 never
@@ -295,8 +306,12 @@ int32_t ctx_acquire(rlr_index *ix, Ctx **out)
         std::unique_lock<std::mutex> lk(ix->mu);
         for (;;) {
             if (!ix->free_ctx.empty()) {
-                Ctx *c = ix->free_ctx.back();
-                ix->free_ctx.pop_back();
+                static const bool rotate = getenv("RLR_CTX_ROTATE") != nullptr; // (experiment: cycle through the contexts)
+                Ctx *c = rotate ? ix->free_ctx.front() : ix->free_ctx.back();
+                if (rotate)
+                    ix->free_ctx.erase(ix->free_ctx.begin());
+                else
+                    ix->free_ctx.pop_back();
                 lk.unlock();
                 if (c->hist_dirty) { // a previous call failed half way: restore the zero-histogram invariant
                     (void)hipStreamSynchronize(c->stream);
@@ -384,6 +399,294 @@ int32_t check_handle(const rlr_index *ix)
     return RLR_OK;
 }
 
+// RLR_ROWS_ALLOC (experiment switch; the default is chosen in DESIGN.md section 5):
+//   "plain"          hipMalloc(bytes)
+//   "align:<MiB>"    hipMalloc(bytes + A), base rounded up to A
+//   "round:<MiB>"    hipMalloc(bytes rounded up to a multiple of A)
+//   "vmm:<MiB>"      one virtual range (hipMemAddressReserve, aligned to the slab size) backed by separate physical
+//                    allocations of <MiB> each (hipMemCreate + hipMemMap)
+void rows_free(RowBlock *b)
+{
+    if (!b->handles.empty()) {
+        (void)hipMemUnmap(b->raw, b->raw_bytes);
+        for (auto h : b->handles)
+            (void)hipMemRelease(h);
+        (void)hipMemAddressFree(b->raw, b->raw_bytes);
+    } else if (b->raw) {
+        (void)hipFree(b->raw);
+    }
+    *b = RowBlock();
+}
+
+// Time of the scan kernel this index's searches launch over the rows at `base` (a slab of a fresh allocation: the
+// content is irrelevant), best of `reps` launches after one warm-up, in ms; < 0 on error.
+float slab_scan_ms(const rlr_index *ix, const void *base, size_t bytes, float *d_scratch, hipEvent_t ev0, hipEvent_t ev1, int reps)
+{
+    ScanArgs sa;
+    sa.rows = base;
+    sa.n_rows = static_cast<uint32_t>(bytes / row_bytes(ix));
+    sa.scores = d_scratch;
+    sa.query = d_scratch + sa.n_rows; // zeros
+    sa.hist = nullptr;
+    sa.dim = ix->dim;
+    sa.pitch16 = ix->pitch16;
+    sa.dtype = ix->dtype;
+    sa.n_cu = ix->n_cu;
+    sa.variant = ix->scan_variant;
+    float best = -1.0f;
+    for (int i = 0; i <= reps; ++i) {
+        if (hipEventRecord(ev0, nullptr) != hipSuccess || launch_scan(sa, nullptr) != hipSuccess ||
+            hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess)
+            return -1.0f;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess)
+            return -1.0f;
+        if (i > 0 && (best < 0 || ms < best))
+            best = ms;
+    }
+    return best;
+}
+
+// "select" (an experiment that did NOT become the default): the row matrix on 1 GiB physical slabs behind one virtual range,
+// the slabs chosen by measurement.  In the steady state the scan kernel streams a 1 GiB slab at 0.897-0.902 of the HBM peak or
+// at 0.883-0.890, the same slabs every time, in runs of consecutive allocations (scratch/slab_scan.py, slab_content.py) -- so:
+// map the slabs, time the scan kernel over each, swap every slab more than 0.7 % slower than the best for a fresh allocation
+// (holding on to the rejects so the driver cannot hand the same memory back).  What it buys: nothing reliable.  During the
+// first seconds after the mapping a slab's rate moves between the two grades from one measurement to the next, so the
+// selection sorts noise; and a whole 10 M-row scan runs ~2 % below the mean of its slabs whatever they are (0.867 over slabs
+// that average 0.892).  Six selected indexes in one process: 0.872 .. 0.883; six from hipMalloc: 0.869 .. 0.887
+// (scratch/alloc_spread.py).  Kept behind RLR_ROWS_ALLOC=select for whoever wants to look again; DESIGN.md section 5.
+hipError_t rows_alloc_select(const rlr_index *ix, size_t bytes, RowBlock *b, void **base)
+{
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ix->device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (e != hipSuccess || gran == 0)
+        return e == hipSuccess ? hipErrorNotSupported : e;
+    const size_t slab = ((1ull << 30) + gran - 1) / gran * gran;
+    const size_t n_slabs = (bytes + slab - 1) / slab;
+    const size_t total = n_slabs * slab;
+    *b = RowBlock();
+    e = hipMemAddressReserve(&b->raw, total, slab, nullptr, 0);
+    if (e != hipSuccess)
+        return e;
+    b->raw_bytes = total;
+    b->slab = slab;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    auto place = [&](size_t pos, hipMemGenericAllocationHandle_t h) -> hipError_t {
+        char *at = static_cast<char *>(b->raw) + pos * slab;
+        hipError_t pe = hipMemMap(at, slab, 0, h, 0);
+        if (pe == hipSuccess)
+            pe = hipMemSetAccess(at, slab, &acc, 1);
+        return pe;
+    };
+    size_t mapped = 0;
+    for (; mapped < n_slabs && e == hipSuccess; ++mapped) {
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, slab, &prop, 0);
+        if (e != hipSuccess)
+            break;
+        b->handles.push_back(h);
+        e = place(mapped, h);
+    }
+    if (e != hipSuccess) {
+        for (size_t i = 0; i < b->handles.size(); ++i) {
+            if (i < mapped)
+                (void)hipMemUnmap(static_cast<char *>(b->raw) + i * slab, slab);
+            (void)hipMemRelease(b->handles[i]);
+        }
+        (void)hipMemAddressFree(b->raw, total);
+        *b = RowBlock();
+        (void)hipGetLastError();
+        return e;
+    }
+    *base = b->raw;
+    // ---- selection (best effort: any failure from here on keeps the slabs as they are) ----
+    static const bool no_select = getenv("RLR_ROWS_NO_SELECT") != nullptr;
+    const size_t slab_rows = slab / row_bytes(ix);
+    float *d_scratch = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipMemGenericAllocationHandle_t> rejects;
+    if (!no_select && n_slabs >= 2 && slab_rows >= 4096 &&
+        rlr::dev_malloc(reinterpret_cast<void **>(&d_scratch), (slab_rows + ix->q_pitch + 64) * sizeof(float)) == hipSuccess &&
+        hipMemset(d_scratch, 0, (slab_rows + ix->q_pitch + 64) * sizeof(float)) == hipSuccess && hipEventCreate(&ev0) == hipSuccess &&
+        hipEventCreate(&ev1) == hipSuccess) {
+        std::vector<float> ms(n_slabs, -1.0f);
+        float best = -1.0f;
+        bool ok = true;
+        for (size_t i = 0; i < n_slabs && ok; ++i) {
+            ms[i] = slab_scan_ms(ix, static_cast<char *>(b->raw) + i * slab, slab, d_scratch, ev0, ev1, 3);
+            ok = ms[i] > 0;
+            if (ok && (best < 0 || ms[i] < best))
+                best = ms[i];
+        }
+        size_t budget = std::min<size_t>(2 * n_slabs, 96); // fresh slabs to try in all
+        uint32_t swapped = 0, tried = 0;
+        for (size_t i = 0; i < n_slabs && ok && budget > 0; ++i) {
+            for (int attempt = 0; attempt < 4 && ms[i] > best * 1.007f && budget > 0; ++attempt) {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 3 * slab)
+                    budget = 1; // (this is the last try)
+                hipMemGenericAllocationHandle_t h;
+                if (hipMemCreate(&h, slab, &prop, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    budget = 0;
+                    break;
+                }
+                budget--;
+                tried++;
+                char *at = static_cast<char *>(b->raw) + i * slab;
+                if (hipMemUnmap(at, slab) != hipSuccess || place(i, h) != hipSuccess) {
+                    // (cannot happen on a healthy runtime; the position must not stay unmapped)
+                    (void)hipGetLastError();
+                    (void)hipMemRelease(h);
+                    ok = place(i, b->handles[i]) == hipSuccess;
+                    budget = 0;
+                    break;
+                }
+                const float t = slab_scan_ms(ix, at, slab, d_scratch, ev0, ev1, 3);
+                if (t > 0 && t < ms[i]) { // better than what was here: keep it, hold the old one until the end
+                    rejects.push_back(b->handles[i]);
+                    b->handles[i] = h;
+                    ms[i] = t;
+                    swapped++;
+                    if (t < best)
+                        best = t;
+                } else { // no better: put the old one back, hold the new one until the end
+                    (void)hipMemUnmap(at, slab);
+                    ok = place(i, b->handles[i]) == hipSuccess;
+                    rejects.push_back(h);
+                }
+            }
+        }
+        if (getenv("RLR_ROWS_ALLOC_LOG")) {
+            float worst = 0;
+            for (float t : ms)
+                worst = std::max(worst, t);
+            fprintf(stderr, "rlr rows: %zu slabs of %zu MiB, %u fresh slabs tried, %u swapped in; slab scan best %.4f ms worst %.4f ms\n",
+                    n_slabs, slab >> 20, tried, swapped, best, worst);
+        }
+        if (!ok) { // a position could not be re-mapped: give up on this block altogether
+            for (auto h : rejects)
+                (void)hipMemRelease(h);
+            if (ev0) (void)hipEventDestroy(ev0);
+            if (ev1) (void)hipEventDestroy(ev1);
+            (void)hipFree(d_scratch);
+            rows_free(b);
+            return hipErrorUnknown;
+        }
+    }
+    for (auto h : rejects)
+        (void)hipMemRelease(h);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (d_scratch) (void)hipFree(d_scratch);
+    (void)hipGetLastError();
+    if (rlr::poison_mode()) {
+        (void)hipMemset(b->raw, 0xFF, total);
+        (void)hipDeviceSynchronize();
+    }
+    return hipSuccess;
+}
+
+hipError_t rows_alloc(const rlr_index *ix, size_t bytes, RowBlock *b, void **base)
+{
+    const int device = ix->device;
+    static const std::string policy = [] {
+        const char *v = getenv("RLR_ROWS_ALLOC");
+        return std::string(v ? v : "plain");
+    }();
+    const char *v = getenv("RLR_ROWS_ALLOC_NOW"); // (re-read per call: the placement experiment creates several indexes in one process)
+    const std::string pol = v ? std::string(v) : policy;
+    const size_t colon = pol.find(':');
+    const std::string kind = pol.substr(0, colon);
+    const size_t mib = colon == std::string::npos ? 0 : static_cast<size_t>(strtoull(pol.c_str() + colon + 1, nullptr, 10));
+    const size_t A = std::max<size_t>(mib, 2) << 20;
+    *b = RowBlock();
+    hipError_t e = hipSuccess;
+    // ("auto" = "select" from 2 GiB: NOT the default -- see the note above rows_alloc_select)
+    if (kind == "select" || (kind == "auto" && bytes >= (2ull << 30))) {
+        e = rows_alloc_select(ix, bytes, b, base);
+        if (e == hipSuccess)
+            return e;
+        (void)hipGetLastError();
+        *b = RowBlock(); // (no virtual-memory API, or out of memory for the slab rounding: the plain allocation below)
+    }
+    if (kind == "align") {
+        e = rlr::dev_malloc(&b->raw, bytes + A);
+        if (e != hipSuccess)
+            return e;
+        b->raw_bytes = bytes + A;
+        *base = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(b->raw) + A - 1) / A * A);
+        return hipSuccess;
+    }
+    if (kind == "round") {
+        const size_t r = (bytes + A - 1) / A * A;
+        e = rlr::dev_malloc(&b->raw, r);
+        b->raw_bytes = r;
+        *base = b->raw;
+        return e;
+    }
+    if (kind == "vmm") {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        size_t gran = 0;
+        e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+        if (e != hipSuccess)
+            return e;
+        const size_t slab = (A + gran - 1) / gran * gran;
+        const size_t total = (bytes + slab - 1) / slab * slab;
+        e = hipMemAddressReserve(&b->raw, total, slab, nullptr, 0);
+        if (e != hipSuccess)
+            return e;
+        b->raw_bytes = total;
+        b->slab = slab;
+        for (size_t off = 0; off < total && e == hipSuccess; off += slab) {
+            hipMemGenericAllocationHandle_t h;
+            e = hipMemCreate(&h, slab, &prop, 0);
+            if (e != hipSuccess)
+                break;
+            b->handles.push_back(h);
+            e = hipMemMap(static_cast<char *>(b->raw) + off, slab, 0, h, 0);
+        }
+        if (e == hipSuccess) {
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            e = hipMemSetAccess(b->raw, total, &acc, 1);
+        }
+        if (e != hipSuccess) {
+            // (partial mappings: unmap what was mapped, release, free the range)
+            for (size_t i = 0; i < b->handles.size(); ++i) {
+                (void)hipMemUnmap(static_cast<char *>(b->raw) + i * slab, slab);
+                (void)hipMemRelease(b->handles[i]);
+            }
+            b->handles.clear();
+            (void)hipMemAddressFree(b->raw, total);
+            *b = RowBlock();
+            (void)hipGetLastError();
+            return e;
+        }
+        if (rlr::poison_mode()) {
+            (void)hipMemset(b->raw, 0xFF, total);
+            (void)hipDeviceSynchronize();
+        }
+        *base = b->raw;
+        return hipSuccess;
+    }
+    e = rlr::dev_malloc(&b->raw, bytes);
+    b->raw_bytes = bytes;
+    *base = b->raw;
+    return e;
+}
+
 int32_t ensure_rows(rlr_index *ix, uint64_t want_rows)
 {
     if (want_rows <= ix->cap_rows)
@@ -393,22 +696,31 @@ int32_t ensure_rows(rlr_index *ix, uint64_t want_rows)
     uint64_t cap = std::max<uint64_t>(want_rows, ix->cap_rows + ix->cap_rows / 2);
     cap = std::max<uint64_t>(cap, 1024);
     void *n = nullptr;
-    hipError_t e = rlr::dev_malloc(&n, cap * row_bytes(ix));
+    RowBlock nb;
+    hipError_t e = rows_alloc(ix, cap * row_bytes(ix), &nb, &n);
     if (e != hipSuccess && cap > want_rows) {
         cap = want_rows;
-        e = rlr::dev_malloc(&n, cap * row_bytes(ix));
+        e = rows_alloc(ix, cap * row_bytes(ix), &nb, &n);
     }
     if (e != hipSuccess)
-        return fail(RLR_E_OOM, "hipMalloc of %llu rows x %zu B failed: %s",
+        return fail(RLR_E_OOM, "allocation of %llu rows x %zu B failed: %s",
                     static_cast<unsigned long long>(cap), row_bytes(ix), hipGetErrorString(e));
     if (ix->d_rows && ix->n_rows) {
-        RLR_HIP(hipMemcpy(n, ix->d_rows, ix->n_rows * row_bytes(ix), hipMemcpyDeviceToDevice));
-        RLR_HIP(hipStreamSynchronize(nullptr)); // a device-to-device copy may return before it has run
+        hipError_t ce = hipMemcpy(n, ix->d_rows, ix->n_rows * row_bytes(ix), hipMemcpyDeviceToDevice);
+        if (ce == hipSuccess)
+            ce = hipStreamSynchronize(nullptr); // a device-to-device copy may return before it has run
+        if (ce != hipSuccess) {
+            rows_free(&nb);
+            return fail(RLR_E_HIP, "moving the rows into the larger allocation failed: %s", hipGetErrorString(ce));
+        }
     }
-    if (ix->d_rows)
-        (void)hipFree(ix->d_rows);
+    rows_free(&ix->rows_block);
+    ix->rows_block = std::move(nb);
     ix->d_rows = n;
     ix->cap_rows = cap;
+    if (getenv("RLR_ROWS_ALLOC_LOG"))
+        fprintf(stderr, "rlr rows: base %p bytes %zu (raw %p, %zu slabs of %zu)\n", n, static_cast<size_t>(cap * row_bytes(ix)),
+                ix->rows_block.raw, ix->rows_block.handles.size(), ix->rows_block.slab);
     return RLR_OK;
 }
 
@@ -1337,6 +1649,10 @@ hipError_t enqueue_query_scan(rlr_index *ix, Ctx *c, uint32_t qi, bool timed)
     sa.dtype = ix->dtype;
     sa.n_cu = ix->n_cu;
     sa.variant = ix->scan_variant;
+    static const bool variant_dyn = getenv("RLR_SCAN_VARIANT_DYN") != nullptr; // (experiments: the variant re-read per launch)
+    if (variant_dyn)
+        if (const char *v = getenv("RLR_SCAN_VARIANT"))
+            sa.variant = static_cast<int>(strtol(v, nullptr, 0));
     const bool q8 = scan_over_q8(ix);
     const bool img = !q8 && scan_over_image(ix);
     if (q8)
@@ -1992,8 +2308,8 @@ int32_t rlr_index_destroy(rlr_index *ix)
     (void)hipDeviceSynchronize();
     for (Ctx *c : ix->free_ctx)
         ctx_free(c);
-    if (ix->d_rows)
-        (void)hipFree(ix->d_rows);
+    rows_free(&ix->rows_block);
+    ix->d_rows = nullptr;
     if (ix->d_q8) (void)hipFree(ix->d_q8);
     if (ix->d_q8_scale) (void)hipFree(ix->d_q8_scale);
     if (ix->d_q8_stats) (void)hipFree(ix->d_q8_stats);
@@ -3171,8 +3487,8 @@ int32_t rlr_fetch_rows_device(rlr_index *ix, const uint64_t *rows, uint32_t n, v
 int32_t rlr_index_probe_bandwidth(rlr_index *ix, int32_t mode, uint32_t reps, double *gbps_out, double *ms_out)
 {
     RLR_TRY(check_handle(ix));
-    if (!gbps_out || (mode != 0 && mode != 1))
-        return fail(RLR_E_INVALID, "mode must be 0 (read) or 1 (copy), gbps_out non-null");
+    if (!gbps_out || mode < 0 || mode > 3)
+        return fail(RLR_E_INVALID, "mode must be 0 (read), 1 (copy), 2 / 3 (the scan kernel without / with its histogram), gbps_out non-null");
     *gbps_out = 0.0;
     if (ms_out)
         *ms_out = 0.0;
@@ -3205,9 +3521,39 @@ int32_t rlr_index_probe_bandwidth(rlr_index *ix, int32_t mode, uint32_t reps, do
     };
     if (mode == 0) {
         RLR_HIP(rlr::dev_malloc(&scratch, static_cast<size_t>(ix->n_cu) * 8 * 256 * sizeof(float)));
-        moved = bytes / 1024 * 1024;
-        for (int shape = 0; shape < 3 && st == RLR_OK; ++shape)
-            st = timed([&] { return launch_probe_read(ix->d_rows, bytes, static_cast<float *>(scratch), ix->n_cu, shape, s); });
+        // (experiments: RLR_PROBE_SHAPE pins the launch shape, RLR_PROBE_OFF_MIB / RLR_PROBE_LEN_MIB a sub-range of the rows)
+        const char *es = getenv("RLR_PROBE_SHAPE"), *eo = getenv("RLR_PROBE_OFF_MIB"), *el = getenv("RLR_PROBE_LEN_MIB");
+        size_t off = eo ? static_cast<size_t>(strtoull(eo, nullptr, 10)) << 20 : 0;
+        size_t len = el ? static_cast<size_t>(strtoull(el, nullptr, 10)) << 20 : bytes;
+        off = std::min(off, bytes - (1u << 20));
+        len = std::min(len, bytes - off);
+        moved = len / 1024 * 1024;
+        const char *base = static_cast<const char *>(ix->d_rows) + off;
+        for (int shape = es ? atoi(es) : 0; shape < (es ? atoi(es) + 1 : 3) && st == RLR_OK; ++shape)
+            st = timed([&] { return launch_probe_read(base, len, static_cast<float *>(scratch), ix->n_cu, shape, s); });
+    } else if (mode >= 2) {
+        // diagnostic: the scan kernel itself over the rows with a zero query, scores into a scratch array, without (2) or
+        // with (3) the digit-1 histogram it accumulates in LDS and flushes with global atomics
+        const size_t sc_bytes = (static_cast<size_t>(ix->n_rows) + 2 * kHistBins + ix->q_pitch) * sizeof(float);
+        RLR_HIP(rlr::dev_malloc(&scratch, sc_bytes));
+        RLR_HIP(hipMemsetAsync(scratch, 0, sc_bytes, s));
+        const char *eo = getenv("RLR_PROBE_OFF_MIB"), *el = getenv("RLR_PROBE_LEN_MIB"); // (experiments: a sub-range of the rows)
+        const uint64_t row_lo = eo ? std::min<uint64_t>((strtoull(eo, nullptr, 10) << 20) / row_bytes(ix), ix->n_rows - 1) : 0;
+        const uint64_t row_n = el ? std::min<uint64_t>((strtoull(el, nullptr, 10) << 20) / row_bytes(ix), ix->n_rows - row_lo)
+                                  : ix->n_rows - row_lo;
+        ScanArgs sa;
+        sa.rows = static_cast<const char *>(ix->d_rows) + row_lo * row_bytes(ix);
+        sa.scores = static_cast<float *>(scratch);
+        sa.hist = mode == 3 ? reinterpret_cast<uint32_t *>(sa.scores + ix->n_rows) : nullptr;
+        sa.query = sa.scores + ix->n_rows + 2 * kHistBins;
+        sa.n_rows = static_cast<uint32_t>(row_n);
+        sa.dim = ix->dim;
+        sa.pitch16 = ix->pitch16;
+        sa.dtype = ix->dtype;
+        sa.n_cu = ix->n_cu;
+        sa.variant = ix->scan_variant;
+        moved = static_cast<size_t>(row_n) * ix->dim * (ix->dtype == RLR_F16 ? 2 : 4);
+        st = timed([&] { return launch_scan(sa, s); });
     } else {
         const size_t half = std::min<size_t>(bytes / 2, 4ull << 30) & ~static_cast<size_t>(255);
         hipError_t e = rlr::dev_malloc(&scratch, half);
