@@ -97,7 +97,8 @@ def pmc_traffic(bytes_per_launch, kernel):
     this same command (profiles/rNN_pmc.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
     separate passes).  PMC counters cannot be read from inside the process, so the figure is
     quoted from the newest summary of the SAME kernel whose byte count matches this run's shape
-    (within 5 %); any other shape -- a shard of an N > 1 run, other dims -- reports null."""
+    (within 5 %); any other shape -- a shard of an N > 1 run, other dims -- reports null.
+    -> (bytes, file, collected on this very build?)"""
     import glob
 
     best = None
@@ -109,7 +110,7 @@ def pmc_traffic(bytes_per_launch, kernel):
         except Exception:
             continue
         if kernel in name and abs(t - bytes_per_launch) <= 0.05 * bytes_per_launch:
-            best = (t, os.path.basename(f))
+            best = (t, os.path.basename(f), d.get("build_source_sha16") == source_sha16())
     return best
 
 
@@ -117,13 +118,15 @@ def batched_traffic(bytes_per_launch, kernel, tag):
     """HBM bytes of the batch's main GEMM pass from the committed rocprofv3 counter passes of the same workload
     (profiles/rNN_<tag>_kernels.json, `counters_by_ordinal`: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE per launch of the
     LAST ordinal inside a batch = the filtered main pass); the newest round's summary.  PMC counters cannot be read from
-    inside the process; a figure outside [0.9, 4] x the operand bytes would mean another shape and is not quoted."""
+    inside the process; a figure outside [0.9, 4] x the operand bytes would mean another shape and is not quoted.
+    -> (bytes, description, collected on this very build?)"""
     import glob
 
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_kernels.json"))):
         try:
-            cbo = json.load(open(f)).get("counters_by_ordinal", {})
+            doc = json.load(open(f))
+            cbo = doc.get("counters_by_ordinal", {})
         except Exception:
             continue
         for name, by_ord in cbo.items():
@@ -135,8 +138,24 @@ def batched_traffic(bytes_per_launch, kernel, tag):
             if fetch is None or not (0.9 * bytes_per_launch <= fetch <= 4.0 * bytes_per_launch):
                 continue
             write = c.get("WRITE_SIZE", {}).get("bytes", 0.0)
-            best = (fetch + write, os.path.basename(f) + f" ({name}, launch {o} of a batch)")
+            best = (fetch + write, os.path.basename(f) + f" ({name}, launch {o} of a batch)",
+                    doc.get("build_source_sha16") == source_sha16())
     return best
+
+
+def quote_traffic(roof, t, what):
+    """Counter traffic into a roofline object: `traffic` only when the committed summary was collected on THIS build of the
+    library (csrc/ + include/ hash equal); a summary of another build goes under `profiled_traffic` with a note, and
+    `traffic` stays null -- a fresh kernel time is never paired with an older kernel's bytes."""
+    roof["traffic"], roof["traffic_source"] = None, None
+    if not t:
+        return
+    src = f"profiles/{t[1]}: {what}"
+    if t[2]:
+        roof["traffic"], roof["traffic_source"] = t[0], src
+    else:
+        roof["profiled_traffic"] = {"value": t[0], "source": src,
+                                    "stale_profile": "collected on another build of csrc/ + include/ than the one running"}
 
 
 def batched_roofline(prof, dim, nq, image, tag="batch256_image"):
@@ -153,10 +172,9 @@ def batched_roofline(prof, dim, nq, image, tag="batch256_image"):
     mfma = {"achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F16_PEAK_TFLOPS}
     main = dict(mfma if t_mfma >= t_hbm else hbm)
     traffic = batched_traffic(b, batch_kernel_name(dim, nq, image), tag)
-    main.update({"bound": "mfma" if t_mfma >= t_hbm else "hbm", "traffic": traffic[0] if traffic else None,
-                 "traffic_source": ("profiles/" + traffic[1] + ": FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of "
-                                    "this shape") if traffic else None,
-                 "kernel": batch_kernel_name(dim, nq, image) + " (the filtered main pass of a batch)",
+    main["bound"] = "mfma" if t_mfma >= t_hbm else "hbm"
+    quote_traffic(main, traffic, "FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this shape")
+    main.update({"kernel": batch_kernel_name(dim, nq, image) + " (the filtered main pass of a batch)",
                  "kernel_ms": ms, "bytes_per_launch": b, "flops_per_launch": fl,
                  "hbm": hbm, "mfma": mfma,
                  "all_gemm_launches_ms": prof.batch_gemm_ms / n,
@@ -682,7 +700,9 @@ def main():
     if dist:
         # every step holds a collective: all ranks must run the SAME number of settle steps, so the count cannot
         # depend on a local clock
-        for _ in range(256 if args.settle_ms > 0 else 0):
+        # (from the shape, identical on every rank: ~6.5 TB/s over the shard + 0.1 ms of fixed cost per step)
+        est_ms = (args.rows / world) * args.dim * (2 if args.dtype == "f16" else 4) / 6.5e9 + 0.1
+        for _ in range(max(256, int(args.settle_ms / est_ms)) if args.settle_ms > 0 else 0):
             step(0)
     else:
         while args.settle_ms > 0 and (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
@@ -792,9 +812,8 @@ def main():
         out["roofline"]["kernel"] = "scan_image_kernel"
         out["dtype"] = "f32 rows, binary16 nomination scan over the image + f32 reference-order re-score"
         out["config"]["workload"] += "; single-query nomination over the binary16 image (opt-in, +dim*2 B/row of HBM)"
-    t = pmc_traffic(bytes_per_launch, out["roofline"]["kernel"]) if not batched else None
-    if t:
-        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t[0], f"profiles/{t[1]} (rocprofv3 --pmc)"
+    if not batched:
+        quote_traffic(out["roofline"], pmc_traffic(bytes_per_launch, out["roofline"]["kernel"]), "rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE")
     extras = world == 1 and not batched and not args.image_scan and not args.q8_scan and not args.no_extras
     # Informational, outside the timed region above: the same workload with the opt-in nomination copies (identical
     # results, the scan streams a half / a quarter of the bytes).  Never the headline `value`.

@@ -329,6 +329,7 @@ typedef struct rlr_multi_stats_t {
     double topk_rccl_ms;
     uint64_t n_mmr_exchanges, mmr_exchange_bytes;
     double mmr_exchange_ms;
+    uint64_t n_mmr_host_bounces; /* winner-row pieces that went through host memory because the peer copy failed */
 } rlr_multi_stats_t;
 int32_t rlr_multi_stats(rlr_multi *m, rlr_multi_stats_t *out, int32_t reset);
 

@@ -32,6 +32,22 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def source_sha16():
+    """sha256 over the sources librlr_gpu.so is built from (csrc/ + include/), first 16 hex digits -- bench.py computes the same
+    and quotes a summary's counter traffic only for the build it was collected on"""
+    import hashlib
+
+    root = os.path.dirname(HERE)
+    h = hashlib.sha256()
+    for d in (os.path.join(root, "rust-local-rag_amd", "csrc"), os.path.join(root, "include")):
+        for f in sorted(os.listdir(d)):
+            p = os.path.join(d, f)
+            if os.path.isfile(p):
+                h.update(f.encode())
+                h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def counter_means(d, kernel_substr):
     """{counter: (mean per dispatch, dispatches)} of the kernel (by substring) with the most dispatches in `d`"""
     fs = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
@@ -98,6 +114,7 @@ def headline():
     write_kib, n_w, _ = w["WRITE_SIZE"]
     out = {
         "command": command,
+        "build_source_sha16": source_sha16(),
         "kernel": name,
         "kernel_trace": {"calls": int(dom["Calls"]), "avg_ns": float(dom["AverageNs"]),
                          "min_ns": float(dom["MinNs"]), "max_ns": float(dom["MaxNs"]),
@@ -118,7 +135,7 @@ def kernels():
     pmc_dirs = sys.argv[7:] if len(sys.argv) > 6 and sys.argv[6] == "--pmc" else []
     stats, rows = stats_rows(d_kt)
     shutil.copy(stats, os.path.join(HERE, f"{tag}_kernel_stats.csv"))
-    out = {"command": command, "kernels": {}}
+    out = {"command": command, "build_source_sha16": source_sha16(), "kernels": {}}
     for sub in subs.split(","):
         hit = [r for r in rows if sub in r["Name"]]
         for r in hit:

@@ -68,7 +68,7 @@ class ProfileC(C.Structure):
 class MultiStatsC(C.Structure):
     _fields_ = [("n_topk_rccl", C.c_uint64), ("n_topk_host_merge", C.c_uint64), ("n_topk_rccl_fell_back", C.c_uint64),
                 ("topk_rccl_ms", C.c_double), ("n_mmr_exchanges", C.c_uint64), ("mmr_exchange_bytes", C.c_uint64),
-                ("mmr_exchange_ms", C.c_double)]
+                ("mmr_exchange_ms", C.c_double), ("n_mmr_host_bounces", C.c_uint64)]
 
 
 # every symbol include/*.h declares: (name, restype, argtypes)

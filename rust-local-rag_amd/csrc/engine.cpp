@@ -362,6 +362,12 @@ int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *qu
                 rlr::lexical_finish(&beside.lp, false);
             return st;
         }
+        if (fb && beside.queued) {
+            // begin handed the query back AFTER the BM25 chain was queued behind the scan (today it only does so before):
+            // the workspace and the readers' lock it holds must go back whichever way begin ends
+            rlr::lexical_finish(&beside.lp, false);
+            beside.queued = false;
+        }
         if (!fb) {
             rlr::LexPending &lp = beside.lp;
             const uint32_t n_res = diversify ? static_cast<uint32_t>(std::min<uint64_t>(std::max<uint32_t>(top_k, 1u), nd)) : nd;

@@ -959,6 +959,10 @@ __global__ __launch_bounds__(256) void mmr_greedy_lazy_kernel(const float *__res
                 wm_raw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), src));
             }
             s_log[n_sel] = make_uint2(last, __builtin_bit_cast(uint32_t, wm_raw)); // (every lane, the same words)
+            // lane 0 reads the log back in the tie path and every lane at the end: ordered for the compiler too, not only
+            // by the wave's lockstep (the same pair as in gram_mfma_f32_kernel)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             n_sel++;
         };
         bool hit[J];
@@ -981,6 +985,10 @@ __global__ __launch_bounds__(256) void mmr_greedy_lazy_kernel(const float *__res
                 s_posof[moved] = static_cast<uint16_t>(p);
             }
         }
+        // lane 0's replay above is read by all 64 lanes below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         replayed = n_sel;
         uint32_t pj[J], bp = 0xFFFFFFFFu;
 #pragma unroll

@@ -1473,7 +1473,15 @@ void lexical_finish(LexPending *p, bool ok)
         // the clean-up kernels behind `ready` restore the all-zero accumulators: wait for them before reuse.  After a failure
         // too: the kernels still in flight read the postings, and the shared lock that keeps a writer away from them is
         // dropped below.
-        const bool drained = hipStreamSynchronize(ws->stream) == hipSuccess;
+        const hipError_t de = hipStreamSynchronize(ws->stream);
+        const bool drained = de == hipSuccess;
+        if (!drained) {
+            // the stream reports an error instead of draining: make sure nothing of this device still runs before the lock
+            // that protects the postings goes, leave the workspace marked dirty (it is re-zeroed before its next use) and
+            // say so in the thread's error message -- the caller is on a failure path already or gets this as its first sign
+            (void)hipDeviceSynchronize();
+            (void)set_error(RLR_E_HIP, "lexical workspace did not drain: %s", hipGetErrorString(de));
+        }
         if (ok && drained)
             ws->dirty = false;
         {

@@ -143,11 +143,14 @@ struct rlr_multi {
     std::vector<Worker *> worker; // shards 1..G-1 (shard 0 runs on the calling thread)
     // RCCL exchange (rlr_multi_set_exchange)
     int32_t exchange = 0;
-    std::mutex xmu; // one collective at a time on the communicators
+    std::mutex xmu; // one collective at a time is ENQUEUED on the communicators (the scans around it are not under it)
     std::vector<ncclComm_t> comm;
-    std::vector<hipStream_t> xstream;
-    std::vector<void *> d_local, d_gath;
-    size_t x_cap = 0; // entries (u64) d_local holds per shard
+    // exchange workspaces (a stream, the local list and the gathered lists per shard), leased per call like XferWs:
+    // concurrent callers scan side by side and only take turns for the group call itself
+    std::mutex emu;
+    std::condition_variable ecv;
+    std::vector<struct ExWs *> e_free;
+    int e_made = 0;
     // cross-shard MMR: a few exchange workspaces (stage + receive buffer and a copy stream per shard), leased per call
     std::mutex wmu;
     std::condition_variable wcv;
@@ -157,7 +160,16 @@ struct rlr_multi {
     // which path the calls took (rlr_multi_stats)
     std::atomic<uint64_t> n_topk_rccl{0}, n_topk_host{0}, n_topk_fellback{0}, n_mmr_exchanges{0}, mmr_exchange_bytes{0};
     std::atomic<uint64_t> topk_exchange_ns{0}, mmr_exchange_ns{0};
+    std::atomic<uint64_t> n_mmr_host_bounces{0}; // winner-row pieces that went through the host because the peer copy failed
 };
+
+struct ExWs {
+    std::vector<hipStream_t> stream;
+    std::vector<void *> d_local, d_gath;
+    size_t cap = 0; // entries (u64) d_local holds per shard
+};
+
+constexpr int kMaxExWs = 4;
 
 struct XferWs {
     std::vector<void *> d_stage, d_recv; // per shard, on its device
@@ -225,22 +237,32 @@ int32_t for_each_shard(const rlr_multi *m, F f)
     return RLR_OK;
 }
 
+void exws_destroy(rlr_multi *m, ExWs *w)
+{
+    if (!w)
+        return;
+    for (size_t g = 0; g < w->stream.size(); ++g) {
+        (void)hipSetDevice(m->device[g]);
+        if (w->stream[g]) {
+            (void)hipStreamSynchronize(w->stream[g]);
+            (void)hipStreamDestroy(w->stream[g]);
+        }
+        if (w->d_local[g]) (void)hipFree(w->d_local[g]);
+        if (w->d_gath[g]) (void)hipFree(w->d_gath[g]);
+    }
+    delete w;
+}
+
 void exchange_teardown(rlr_multi *m)
 {
+    for (ExWs *w : m->e_free)
+        exws_destroy(m, w);
+    m->e_free.clear();
+    m->e_made = 0;
     for (size_t g = 0; g < m->comm.size(); ++g)
         if (m->comm[g])
             (void)rccl().CommDestroy(m->comm[g]);
     m->comm.clear();
-    for (size_t g = 0; g < m->xstream.size(); ++g) {
-        (void)hipSetDevice(m->device[g]);
-        if (m->xstream[g]) (void)hipStreamDestroy(m->xstream[g]);
-        if (g < m->d_local.size() && m->d_local[g]) (void)hipFree(m->d_local[g]);
-        if (g < m->d_gath.size() && m->d_gath[g]) (void)hipFree(m->d_gath[g]);
-    }
-    m->xstream.clear();
-    m->d_local.clear();
-    m->d_gath.clear();
-    m->x_cap = 0;
 }
 
 #define RLR_X_HIP(call)                                                                                        \
@@ -256,8 +278,78 @@ void exchange_teardown(rlr_multi *m)
             return rlr::set_error(RLR_E_HIP, "%s: %s", #call, rccl().GetErrorString(r_));                      \
     } while (0)
 
+int32_t exws_acquire(rlr_multi *m, ExWs **out)
+{
+    {
+        std::unique_lock<std::mutex> lk(m->emu);
+        for (;;) {
+            if (!m->e_free.empty()) {
+                *out = m->e_free.back();
+                m->e_free.pop_back();
+                return RLR_OK;
+            }
+            if (m->e_made < kMaxExWs) {
+                m->e_made++;
+                break;
+            }
+            m->ecv.wait(lk);
+        }
+    }
+    const size_t G = m->shard.size();
+    ExWs *w = new (std::nothrow) ExWs();
+    hipError_t e = w ? hipSuccess : hipErrorOutOfMemory;
+    if (w) {
+        w->stream.assign(G, nullptr);
+        w->d_local.assign(G, nullptr);
+        w->d_gath.assign(G, nullptr);
+        for (size_t g = 0; g < G && e == hipSuccess; ++g) {
+            e = hipSetDevice(m->device[g]);
+            if (e == hipSuccess)
+                e = hipStreamCreateWithFlags(&w->stream[g], hipStreamNonBlocking);
+        }
+    }
+    if (e != hipSuccess) {
+        exws_destroy(m, w);
+        {
+            std::lock_guard<std::mutex> lk(m->emu);
+            m->e_made--;
+        }
+        m->ecv.notify_one();
+        return rlr::set_error(RLR_E_HIP, "exchange workspace: %s", hipGetErrorString(e));
+    }
+    *out = w;
+    return RLR_OK;
+}
+
+void exws_release(rlr_multi *m, ExWs *w)
+{
+    {
+        std::lock_guard<std::mutex> lk(m->emu);
+        m->e_free.push_back(w);
+    }
+    m->ecv.notify_one();
+}
+
+struct ExLease {
+    rlr_multi *m;
+    ExWs *w = nullptr;
+    explicit ExLease(rlr_multi *mm) : m(mm) {}
+    ~ExLease()
+    {
+        if (w)
+            exws_release(m, w);
+    }
+};
+
 // The RCCL form of the exchange step.  *handled = false: a shard's guard band overflowed (or the shape is outside
 // the merge kernel) and the caller falls through to the host merge, which handles everything.
+//
+// No host round trip between the scans and the collective: every shard ENQUEUES its pipelines on the workspace's stream
+// of its device (rlr_search_topk_device_begin), the all-gathers queue up behind them in one group call, the merge
+// kernel behind device 0's; the one wait of the call is the merge's.  The workspace (streams + lists) is leased per
+// call, so concurrent callers overlap their scans and hold `xmu` only while the group call is enqueued -- a
+// communicator takes one collective at a time.  Nothing waits for the other devices' halves of the collective: the
+// next user of the workspace enqueues behind them on the same streams.
 int32_t search_rccl(rlr_multi *m, const float *queries, uint32_t nq, uint32_t k, float guard_eps, uint64_t *rows_out,
                     float *cos_out, uint32_t *n_out, bool *handled)
 {
@@ -265,45 +357,71 @@ int32_t search_rccl(rlr_multi *m, const float *queries, uint32_t nq, uint32_t k,
     const size_t G = m->shard.size();
     if (G > 16 || static_cast<uint64_t>(G) * k > 8192 || nq == 0 || k == 0)
         return RLR_OK;
-    std::lock_guard<std::mutex> xl(m->xmu);
+    ExLease lease(m);
+    {
+        const int32_t as = exws_acquire(m, &lease.w);
+        if (as != RLR_OK)
+            return as;
+    }
+    ExWs *w = lease.w;
     const size_t per = static_cast<size_t>(nq) * k;
-    if (m->x_cap < per) {
-        m->x_cap = 0; // nothing usable until every buffer of the new size exists
+    if (w->cap < per) {
+        w->cap = 0; // nothing usable until every buffer of the new size exists
         for (size_t g = 0; g < G; ++g) {
             RLR_X_HIP(hipSetDevice(m->device[g]));
-            if (m->d_local[g]) (void)hipFree(m->d_local[g]);
-            if (m->d_gath[g]) (void)hipFree(m->d_gath[g]);
-            m->d_local[g] = m->d_gath[g] = nullptr;
-            RLR_X_HIP(rlr::dev_malloc(&m->d_local[g], per * sizeof(uint64_t)));
-            RLR_X_HIP(rlr::dev_malloc(&m->d_gath[g], G * per * sizeof(uint64_t)));
+            RLR_X_HIP(hipStreamSynchronize(w->stream[g])); // (an earlier call's collective may still read the old buffers)
+            if (w->d_local[g]) (void)hipFree(w->d_local[g]);
+            if (w->d_gath[g]) (void)hipFree(w->d_gath[g]);
+            w->d_local[g] = w->d_gath[g] = nullptr;
+            RLR_X_HIP(rlr::dev_malloc(&w->d_local[g], per * sizeof(uint64_t)));
+            RLR_X_HIP(rlr::dev_malloc(&w->d_gath[g], G * per * sizeof(uint64_t)));
         }
-        m->x_cap = per;
+        w->cap = per;
     }
-    // every shard: the whole local pipeline, k packed results per query left in its device memory
+    // every shard: the whole local pipeline enqueued, k packed results per query into its device memory
+    std::vector<void *> ticket(G, nullptr);
+    auto end_all = [&]() { // hand the search contexts back (waits for whatever is still in flight on the shard's stream)
+        uint32_t over = 0;
+        int32_t est = RLR_OK;
+        for (size_t g = 0; g < G; ++g) {
+            uint32_t o = 0;
+            const int32_t s1 = rlr_search_topk_device_end(m->shard[g], ticket[g], &o);
+            ticket[g] = nullptr;
+            over += o;
+            if (s1 != RLR_OK && est == RLR_OK)
+                est = s1;
+        }
+        return std::make_pair(est, over);
+    };
     int32_t st = for_each_shard(m, [&](uint32_t g) {
-        return rlr_search_topk_device(m->shard[g], queries, nq, k, guard_eps, m->d_local[g], m->xstream[g]);
+        return rlr_search_topk_device_begin(m->shard[g], queries, nq, k, guard_eps, w->d_local[g], w->stream[g], &ticket[g]);
     });
-    if (st != RLR_OK)
+    if (st != RLR_OK) {
+        (void)end_all();
         return st;
+    }
     // one all-gather per shard inside a group call: G x nq x k x 8 bytes land on every device, rank-major
-    RLR_X_NCCL(rccl().GroupStart());
-    for (size_t g = 0; g < G; ++g) {
-        const ncclResult_t r = rccl().AllGather(m->d_local[g], m->d_gath[g], per, ncclUint64, m->comm[g], m->xstream[g]);
+    {
+        std::lock_guard<std::mutex> xl(m->xmu);
+        ncclResult_t r = rccl().GroupStart();
+        for (size_t g = 0; g < G && r == ncclSuccess; ++g)
+            r = rccl().AllGather(w->d_local[g], w->d_gath[g], per, ncclUint64, m->comm[g], w->stream[g]);
+        const ncclResult_t r2 = rccl().GroupEnd();
+        if (r == ncclSuccess)
+            r = r2;
         if (r != ncclSuccess) {
-            (void)rccl().GroupEnd();
-            return rlr::set_error(RLR_E_HIP, "ncclAllGather: %s", rccl().GetErrorString(r));
+            (void)end_all();
+            return rlr::set_error(RLR_E_HIP, "ncclAllGather group: %s", rccl().GetErrorString(r));
         }
     }
-    RLR_X_NCCL(rccl().GroupEnd());
     // merge on the first device (a single process needs the answer once); queued behind its all-gather
-    st = rlr_merge_topk(m->device[0], m->d_gath[0], static_cast<uint32_t>(G), nq, k, m->base.data(), rows_out, cos_out,
-                        n_out, m->xstream[0]);
-    for (size_t g = 1; g < G; ++g) { // the other devices' halves of the collective must be done before the buffers are reused
-        RLR_X_HIP(hipSetDevice(m->device[g]));
-        RLR_X_HIP(hipStreamSynchronize(m->xstream[g]));
-    }
+    st = rlr_merge_topk(m->device[0], w->d_gath[0], static_cast<uint32_t>(G), nq, k, m->base.data(), rows_out, cos_out,
+                        n_out, w->stream[0]);
+    const auto ended = end_all();
     if (st != RLR_OK)
         return st;
+    if (ended.first != RLR_OK)
+        return ended.first;
     for (uint32_t q = 0; q < nq; ++q)
         if (n_out[q] == 0xFFFFFFFFu)
             return RLR_OK; // overflow marker: host merge redoes the call
@@ -505,10 +623,20 @@ int32_t multi_mmr(rlr_multi *m, const uint64_t *pool_rows, const float *pool_sco
                     continue;
                 char *dst = static_cast<char *>(w->d_recv[o]) + recv_off[o][g] * rb;
                 const char *src = static_cast<const char *>(w->d_stage[g]) + send_off[g][o] * rb;
-                if (m->device[o] == m->device[g])
+                if (m->device[o] == m->device[g]) {
                     RLR_X_HIP(hipMemcpyAsync(dst, src, cnt * rb, hipMemcpyDeviceToDevice, w->stream[g]));
-                else
-                    RLR_X_HIP(hipMemcpyPeerAsync(dst, m->device[o], src, m->device[g], cnt * rb, w->stream[g]));
+                } else if (hipMemcpyPeerAsync(dst, m->device[o], src, m->device[g], cnt * rb, w->stream[g]) != hipSuccess) {
+                    // no peer path between this pair (or the runtime refused it): bounce the piece through the host
+                    // rather than failing the whole diversified search -- slower, same bytes
+                    (void)hipGetLastError();
+                    std::vector<char> bounce(cnt * rb);
+                    RLR_X_HIP(hipStreamSynchronize(w->stream[g])); // (the gather that produced `src`)
+                    RLR_X_HIP(hipMemcpy(bounce.data(), src, cnt * rb, hipMemcpyDeviceToHost));
+                    RLR_X_HIP(hipSetDevice(m->device[o]));
+                    RLR_X_HIP(hipMemcpy(dst, bounce.data(), cnt * rb, hipMemcpyHostToDevice));
+                    RLR_X_HIP(hipSetDevice(m->device[g]));
+                    m->n_mmr_host_bounces++;
+                }
             }
             return RLR_OK;
         }();
@@ -622,6 +750,8 @@ int32_t rlr_multi_create(uint32_t dim, int32_t dtype, int32_t n_devices, const i
     }
     // the winner-row exchange copies device to device: map the peers where the platform allows it (a refusal only
     // means the runtime stages the copy itself)
+    int caller_device = 0;
+    const bool have_caller_device = hipGetDevice(&caller_device) == hipSuccess;
     for (int32_t a = 0; a < n_devices; ++a)
         for (int32_t b = 0; b < n_devices; ++b) {
             int can = 0;
@@ -630,6 +760,8 @@ int32_t rlr_multi_create(uint32_t dim, int32_t dtype, int32_t n_devices, const i
             if (hipSetDevice(device_ids[a]) == hipSuccess && hipDeviceEnablePeerAccess(device_ids[b], 0) != hipSuccess)
                 (void)hipGetLastError(); // (already enabled counts as an error)
         }
+    if (have_caller_device)
+        (void)hipSetDevice(caller_device); // (the loop above moved the calling thread's current device)
     set_bases(m, 0);
     *out = m;
     return RLR_OK;
@@ -677,18 +809,6 @@ int32_t rlr_multi_set_exchange(rlr_multi *m, int32_t mode)
         if (r != ncclSuccess) {
             m->comm.clear();
             return rlr::set_error(RLR_E_HIP, "ncclCommInitAll: %s", rccl().GetErrorString(r));
-        }
-        m->xstream.assign(G, nullptr);
-        m->d_local.assign(G, nullptr);
-        m->d_gath.assign(G, nullptr);
-        for (size_t g = 0; g < G; ++g) {
-            hipError_t e = hipSetDevice(m->device[g]);
-            if (e == hipSuccess)
-                e = hipStreamCreateWithFlags(&m->xstream[g], hipStreamNonBlocking);
-            if (e != hipSuccess) { // no half-built exchange: a retry starts from scratch
-                exchange_teardown(m);
-                return rlr::set_error(RLR_E_HIP, "exchange stream on device %d: %s", m->device[g], hipGetErrorString(e));
-            }
         }
     }
     m->exchange = 1;
@@ -891,7 +1011,9 @@ int32_t rlr_multi_stats(rlr_multi *m, rlr_multi_stats_t *out, int32_t reset)
     out->n_mmr_exchanges = m->n_mmr_exchanges.load();
     out->mmr_exchange_bytes = m->mmr_exchange_bytes.load();
     out->mmr_exchange_ms = static_cast<double>(m->mmr_exchange_ns.load()) * 1e-6;
+    out->n_mmr_host_bounces = m->n_mmr_host_bounces.load();
     if (reset) {
+        m->n_mmr_host_bounces = 0;
         m->n_topk_rccl = 0;
         m->n_topk_host = 0;
         m->n_topk_fellback = 0;

@@ -173,3 +173,27 @@ def test_multi_engine_concurrent_callers(rlr, oracle):
     [t.join() for t in th]
     assert not bad, bad[:4]
     mi.close()
+
+
+@pytest.mark.parametrize("exchange", ["host", "rccl"])
+def test_multi_engine_on_two_distinct_devices(rlr, oracle, exchange):
+    """The cross-device half that one GPU cannot exercise: shards on devices 0 and 1 -- peer mapping at create time,
+    hipMemcpyPeerAsync in the winner-row exchange, a two-rank ncclAllGather in the RCCL form.  Skipped on a one-GPU box (the
+    driver's multi-GPU node runs it)."""
+    if rlr.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    n, dim = 9001, 768
+    rows = corpus(oracle, n, dim, False, seed=3301)
+    mi = rlr.MultiGpuIndex(dim, [0, 1], "f32")
+    mi.upload(rows)
+    mi.set_exchange(exchange)
+    qs = [oracle.synth_query(dim, seed=3400 + i) for i in range(3)]
+    for qi, q in enumerate(qs):
+        check(mi.engine_search(q, 100), oracle.search(rows, q, 100), ("search", qi))
+        check(mi.engine_search_with_diversity(q, 20, 0.7), oracle.search_with_diversity(rows, q, 20, 0.7), ("mmr", qi))
+    st = mi.stats()
+    assert st["n_mmr_exchanges"] > 0
+    assert st["n_mmr_host_bounces"] == 0, st          # the peer copies worked (a bounce is correct too, but worth knowing)
+    if exchange == "rccl":
+        assert st["n_topk_rccl"] > 0, st
+    mi.close()
