@@ -20,7 +20,7 @@ ROOT = os.path.dirname(HERE)
 
 SOURCES = ["scan.hip", "select.hip", "tail.hip", "exact.hip", "gemm.hip", "index.hip", "engine.cpp", "multi.cpp", "lexical.hip", "q8.hip",
            "jsonio.cpp"]
-HEADERS = ["common.h", "kernels.h", "exact_dot.h", "lds_select.h", "staged_dot.h", "select_dev.h", "sort_emit.h",
+HEADERS = ["common.h", "kernels.h", "exact_dot.h", "lds_select.h", "staged_dot.h", "select_dev.h", "sort_emit.h", "pool_prepare.h",
            "engine_host.h", "lexical_internal.h", os.path.join(ROOT, "include", "rlr_gpu.h"),
            os.path.join(ROOT, "include", "rlr_engine.h"), os.path.join(ROOT, "include", "rlr_lexical.h")]
 

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "exact_dot.h"
 #include "staged_dot.h"
+#include "sort_emit.h"
 #include "kernels.h"
 #include "../../include/rlr_gpu.h"
 
@@ -673,6 +674,52 @@ __global__ __launch_bounds__(64) void mmr_greedy_kernel(const float *__restrict_
         *out_n = n_sel;
 }
 
+// The result block of the fused search -> MMR paths, written by ONE wave (sort_emit.h: [row | cos | combined | lexical] x
+// k_cap, n, status, checksum, done): pick i is pool slot order(i).  The values, then n / status / the checksum of it all, then --
+// behind a system-scope fence -- the completion word a polling host waits for (the word can still overtake the values on
+// their way through PCIe; the checksum settles that on the host).
+template <typename Order>
+__device__ __forceinline__ void emit_result_block(const MmrEmit &emit, uint32_t n_sel, uint32_t lane, Order order)
+{
+    const uint32_t status = emit.info[1];
+    const uint32_t n = status ? 0u : min(n_sel, emit.k_cap);
+    uint32_t chk = 0;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t o = order(i);
+        const uint32_t w0 = emit.list[o], w1 = __builtin_bit_cast(uint32_t, emit.cosv[o]);
+        const uint32_t w2 = __builtin_bit_cast(uint32_t, emit.comb[o]);
+        const uint32_t w3 = emit.lexv ? __builtin_bit_cast(uint32_t, emit.lexv[o]) : 0u;
+        emit.h_out[i] = w0;
+        emit.h_out[emit.k_cap + i] = w1;
+        emit.h_out[2 * emit.k_cap + i] = w2;
+        emit.h_out[3 * emit.k_cap + i] = w3;
+        chk += result_chk_term(w0, i) + result_chk_term(w1, emit.k_cap + i) + result_chk_term(w2, 2 * emit.k_cap + i) +
+               result_chk_term(w3, 3 * emit.k_cap + i);
+    }
+    __threadfence_system();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        chk += static_cast<uint32_t>(__shfl_xor(static_cast<int>(chk), off));
+    if (lane == 0) {
+        emit.h_out[4 * emit.k_cap] = n;
+        emit.h_out[4 * emit.k_cap + 1] = status;
+        emit.h_out[4 * emit.k_cap + 2] = block_chk_tail(chk, n, status, emit.k_cap);
+        __threadfence_system();
+        emit.h_out[4 * emit.k_cap + 3] = kBlockDone;
+    }
+}
+
+// an unusable pool (size 0, its status in info[1]): the same block with no values; one thread
+__device__ __forceinline__ void emit_empty_block(const MmrEmit &emit)
+{
+    const uint32_t status = emit.info[1];
+    emit.h_out[4 * emit.k_cap] = 0;
+    emit.h_out[4 * emit.k_cap + 1] = status;
+    emit.h_out[4 * emit.k_cap + 2] = block_chk_tail(0u, 0u, status, emit.k_cap);
+    __threadfence_system();
+    emit.h_out[4 * emit.k_cap + 3] = kBlockDone;
+}
+
 // Register-resident greedy MMR for pools of <= 64*J candidates: lane l owns candidates l, l+64, ...
 // with their relevance, running max-similarity and current position in the reference's
 // `remaining` vector held in VGPRs.  A step is one batch of independent L2 loads of the last
@@ -702,10 +749,8 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
     if (P == 0) {
         if (threadIdx.x == 0) {
             *out_n = 0;
-            if (emit.h_out) { // (an unusable pool arrives here as size 0 with its status in info[1])
-                emit.h_out[4 * emit.k_cap] = 0;
-                emit.h_out[4 * emit.k_cap + 1] = emit.info[1];
-            }
+            if (emit.h_out) // (an unusable pool arrives here as size 0 with its status in info[1])
+                emit_empty_block(emit);
         }
         return;
     }
@@ -805,19 +850,7 @@ __global__ __launch_bounds__(256) void mmr_greedy_reg_kernel(const float *__rest
         *out_n = n_sel;
     if (emit.h_out) { // the picks straight into the caller's (pinned) result block
         __threadfence(); // lane 0's out_order stores, read back by all lanes
-        const uint32_t status = emit.info[1];
-        const uint32_t n = status ? 0u : min(n_sel, emit.k_cap);
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t o = out_order[i];
-            emit.h_out[i] = emit.list[o];
-            emit.h_out[emit.k_cap + i] = __builtin_bit_cast(uint32_t, emit.cosv[o]);
-            emit.h_out[2 * emit.k_cap + i] = __builtin_bit_cast(uint32_t, emit.comb[o]);
-            emit.h_out[3 * emit.k_cap + i] = emit.lexv ? __builtin_bit_cast(uint32_t, emit.lexv[o]) : 0u;
-        }
-        if (lane == 0) {
-            emit.h_out[4 * emit.k_cap] = n;
-            emit.h_out[4 * emit.k_cap + 1] = status;
-        }
+        emit_result_block(emit, n_sel, lane, [&](uint32_t i) { return out_order[i]; });
     }
 }
 
@@ -876,10 +909,8 @@ __global__ __launch_bounds__(256) void mmr_greedy_lazy_kernel(const float *__res
     if (P == 0) {
         if (threadIdx.x == 0) {
             *out_n = 0;
-            if (emit.h_out) { // (an unusable pool arrives here as size 0 with its status in info[1])
-                emit.h_out[4 * emit.k_cap] = 0;
-                emit.h_out[4 * emit.k_cap + 1] = emit.info[1];
-            }
+            if (emit.h_out) // (an unusable pool arrives here as size 0 with its status in info[1])
+                emit_empty_block(emit);
         }
         return;
     }
@@ -1010,21 +1041,8 @@ __global__ __launch_bounds__(256) void mmr_greedy_lazy_kernel(const float *__res
     }
     if (lane == 0)
         *out_n = n_sel;
-    if (emit.h_out) { // the picks straight into the caller's (pinned) result block
-        const uint32_t status = emit.info[1];
-        const uint32_t n = status ? 0u : min(n_sel, emit.k_cap);
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t o = s_log[i].x;
-            emit.h_out[i] = emit.list[o];
-            emit.h_out[emit.k_cap + i] = __builtin_bit_cast(uint32_t, emit.cosv[o]);
-            emit.h_out[2 * emit.k_cap + i] = __builtin_bit_cast(uint32_t, emit.comb[o]);
-            emit.h_out[3 * emit.k_cap + i] = emit.lexv ? __builtin_bit_cast(uint32_t, emit.lexv[o]) : 0u;
-        }
-        if (lane == 0) {
-            emit.h_out[4 * emit.k_cap] = n;
-            emit.h_out[4 * emit.k_cap + 1] = status;
-        }
-    }
+    if (emit.h_out) // the picks straight into the caller's (pinned) result block
+        emit_result_block(emit, n_sel, lane, [&](uint32_t i) { return s_log[i].x; });
 }
 
 uint32_t ew_blocks(size_t total)

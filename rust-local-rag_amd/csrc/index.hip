@@ -8,6 +8,7 @@
 #include "kernels.h"
 #include "lds_select.h"
 #include "sort_emit.h"
+#include "pool_prepare.h"
 #include "lexical_internal.h"
 
 #include <algorithm>
@@ -920,6 +921,25 @@ int32_t wait_polling(Complete &&complete, hipStream_t s, WaitEma *c, uint32_t ke
     return RLR_OK;
 }
 
+// The result block of a fused search -> MMR call (sort_emit.h: [4 x k_cap values] n status checksum done).
+int32_t wait_block(const volatile uint32_t *h_out, uint32_t k_cap, hipStream_t s, WaitEma *c)
+{
+    return wait_polling(
+        [&]() {
+            if (h_out[4 * k_cap + 3] != kBlockDone)
+                return false;
+            const uint32_t n = h_out[4 * k_cap], status = h_out[4 * k_cap + 1];
+            if (n > k_cap)
+                return false;
+            uint32_t chk = 0;
+            for (uint32_t b = 0; b < 4; ++b)
+                for (uint32_t i = 0; i < n; ++i)
+                    chk += result_chk_term(h_out[b * k_cap + i], b * k_cap + i);
+            return block_chk_tail(chk, n, status, k_cap) == h_out[4 * k_cap + 2];
+        },
+        s, c, 0x40000000u);
+}
+
 // The completion words of nq single-query pipelines (sort_emit.h: count | checksum << 32, written last).  res != null:
 // the k result words of each query are in host memory too and must match the checksum -- the word alone can overtake
 // the results on their way through PCIe.
@@ -950,6 +970,35 @@ int32_t wait_results(const volatile uint64_t *meta, const volatile uint64_t *res
             return true;
         },
         s, c, nq);
+}
+
+// ---- query upload -----------------------------------------------------------------------------------------------
+// The staged queries (pinned host memory, zero padded to the row pitch) -> the context's device buffer.  A few KB: one
+// small kernel on the search's own stream reads them over PCIe itself.  hipMemcpyAsync does the same with the runtime's
+// copy kernel, but the scan behind it then starts 4-5 us after that copy has finished (every other boundary of the
+// pipeline: < 1 us; scratch/step_timeline.py) -- a stream's copies and kernels are ordered through a signal, kernels
+// among themselves by the queue.
+} // namespace
+
+namespace rlr {
+__global__ __launch_bounds__(256) void stage_query_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, uint32_t n16)
+{
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256)
+        dst[i] = src[i];
+}
+} // namespace rlr
+
+namespace {
+
+hipError_t upload_queries(Ctx *c, const float *h_q, size_t q_bytes, hipStream_t s)
+{
+    static const bool by_copy = getenv("RLR_QUERY_MEMCPY") != nullptr; // (A/B)
+    if (by_copy || q_bytes > (64u << 10) || (q_bytes & 15) || (reinterpret_cast<uintptr_t>(h_q) & 15))
+        return hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s);
+    const uint32_t n16 = static_cast<uint32_t>(q_bytes / 16);
+    hipLaunchKernelGGL(rlr::stage_query_kernel, dim3(std::min<uint32_t>((n16 + 255) / 256, 8)), dim3(256), 0, s,
+                       reinterpret_cast<const float4 *>(h_q), reinterpret_cast<float4 *>(c->d_query), n16);
+    return hipGetLastError();
 }
 
 // ---- the search pipeline ------------------------------------------------------------
@@ -1212,112 +1261,13 @@ __global__ void emit_kernel(const uint64_t *__restrict__ packed, uint32_t n, uin
         out[i] = i < n ? packed[i] : 0ull;
 }
 
-// ---- search -> MMR without a host round trip (rlr_search_diverse) -----------------------------------------
-// The device twin of the host code between `search` and `mmr_diversify` for a query without lexical candidates
-// (csrc/engine.cpp: search_impl's candidate list + rlr_engine_search_with_diversity): the `fetch` best rows by
-// cosine (sorted, packed) become candidates with combined = w_e * cos + w_l * 0 (rag_engine.rs:531-532: two
-// rounded products, one add), ordered (combined desc, NaN last, row asc) -- distinct cosines can round to one
-// combined score, so this is NOT always the cosine order -- cut to the first `need` (:544, :734).  If such a
-// rounding tie chain reaches the last fetched row while rows remain unfetched the order cannot be decided from
-// this fetch: info[1] = 2 and the host takes the widening two-call path, exactly as search_impl does.
-//   info[0] = pool size, info[1] = status (0 ok, 1 guard-band overflow upstream, 2 boundary tie)
-constexpr uint32_t kPoolMax = 1024, kPoolFetchMax = kPoolMax + 8;
-
-// FROM_CANDIDATES: `packed` is the re-score's unordered candidate list (st->n_cand entries) instead of sort_emit_kernel's
-// output -- the `fetch` best are ranked here (the same rank sort over the same unique keys), one launch and one trip through
-// memory less per search (6.5 + ~2 us of config 2's 160).  More than 1024 candidates (a dense band) report status 1 and
-// the host takes the two-call path, as for a guard-band overflow.
+// ---- search -> MMR without a host round trip (rlr_search_diverse): pool_prepare.h ---------------------------
 template <bool FROM_CANDIDATES>
 __global__ __launch_bounds__(1024) void pool_prepare_kernel(const uint64_t *__restrict__ packed, const SelectState *__restrict__ st,
-                                                            uint32_t fetch, uint32_t need, uint32_t n_rows, float w_e, float w_l,
-                                                            uint32_t *__restrict__ list, float *__restrict__ comb,
-                                                            float *__restrict__ cosv, uint32_t *__restrict__ info)
+                                                            PoolArgs pa)
 {
-    __shared__ uint64_t s_key[kPoolFetchMax];
-    __shared__ float s_c[kPoolFetchMax], s_e[kPoolFetchMax];
-    __shared__ uint64_t s_raw[FROM_CANDIDATES ? 1024 : 1], s_best[FROM_CANDIDATES ? kPoolFetchMax : 1];
-    __shared__ uint32_t s_got;
-    __shared__ float s_cneed;
-    const uint32_t t = threadIdx.x;
-    if (t == 0) {
-        s_got = 0;
-        s_cneed = 0.0f;
-    }
-    bool overflow;
-    if constexpr (FROM_CANDIDATES) {
-        const uint32_t n_raw = st->n_cand;
-        overflow = n_raw > st->cap || n_raw > 1024;
-        if (!overflow) {
-            if (t < n_raw)
-                s_raw[t] = packed[t];
-            for (uint32_t i = min(n_raw, fetch) + t; i < fetch; i += 1024)
-                s_best[i] = 0ull; // (valid entries are a prefix, zeros behind: what sort_emit_kernel writes)
-            __syncthreads();
-            if (t < n_raw) {
-                const uint64_t mine = s_raw[t];
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < n_raw; ++j)
-                    rank += s_raw[j] > mine;
-                if (rank < fetch)
-                    s_best[rank] = mine;
-            }
-        }
-    } else {
-        overflow = packed[0] == ~0ull;
-    }
-    __syncthreads();
-    for (uint32_t i = t; i < fetch; i += 1024) {
-        const uint64_t p = overflow ? 0ull : (FROM_CANDIDATES ? s_best[i] : packed[i]);
-        uint64_t key = 0;
-        if (p != 0) { // valid entries are a prefix: (score desc, row asc), padding zeros behind
-            const float e = key_score(static_cast<uint32_t>(p >> 32));
-            const float t0 = w_e * e;
-            const float t1 = w_l * 0.0f;
-            const float c = t0 + t1;
-            s_c[i] = c;
-            s_e[i] = e;
-            key = (static_cast<uint64_t>(score_key(c)) << 32) | (p & 0xFFFFFFFFull);
-            atomicAdd(&s_got, 1u);
-        }
-        s_key[i] = key;
-    }
-    __syncthreads();
-    const uint32_t got = s_got;
-    // rank sort: keys are unique (the row is part of the key)
-    for (uint32_t i = t; i < got; i += 1024) {
-        const uint64_t mine = s_key[i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < got; ++j)
-            rank += s_key[j] > mine;
-        if (rank < need) {
-            list[rank] = 0xFFFFFFFFu - static_cast<uint32_t>(mine & 0xFFFFFFFFull);
-            comb[rank] = s_c[i];
-            cosv[rank] = s_e[i];
-            if (rank == need - 1)
-                s_cneed = s_c[i];
-        }
-    }
-    const uint32_t n_pool = min(got, need);
-    for (uint32_t i = n_pool + t; i < need; i += 1024) { // unused slots: a valid row, never read by the greedy kernel
-        list[i] = 0;
-        comb[i] = 0.0f;
-        cosv[i] = 0.0f;
-    }
-    __syncthreads();
-    if (t == 0) {
-        uint32_t status = overflow ? 1u : 0u;
-        if (!overflow && got < n_rows && got > 0) {
-            // bound on every unfetched row: the combined score of the last fetched cosine
-            const float t0 = w_e * s_e[got - 1];
-            const float t1 = w_l * 0.0f;
-            const float c_tail = t0 + t1;
-            const bool ok = got >= need && (c_tail != c_tail || s_cneed > c_tail);
-            if (!ok)
-                status = 2u;
-        }
-        info[0] = status ? 0u : n_pool;
-        info[1] = status;
-    }
+    __shared__ __attribute__((aligned(16))) char s_pool[kPoolLdsBytes];
+    pool_prepare_body<FROM_CANDIDATES, false>(packed, FROM_CANDIDATES ? st->n_cand : 0u, FROM_CANDIDATES ? st->cap : 0u, pa, s_pool);
 }
 
 
@@ -1550,16 +1500,32 @@ __global__ __launch_bounds__(256) void hybrid_emit_kernel(const uint32_t *__rest
                                                           const uint32_t *__restrict__ info, uint32_t k_cap,
                                                           uint32_t *__restrict__ h_out)
 {
+    __shared__ uint32_t s_chk;
+    if (threadIdx.x == 0)
+        s_chk = 0;
+    __syncthreads();
     const uint32_t n = info[1] ? 0u : min(info[0], k_cap);
+    uint32_t chk = 0;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        h_out[i] = list[i];
-        h_out[k_cap + i] = __builtin_bit_cast(uint32_t, cosv[i]);
-        h_out[2 * k_cap + i] = __builtin_bit_cast(uint32_t, comb[i]);
-        h_out[3 * k_cap + i] = __builtin_bit_cast(uint32_t, lexv[i]);
+        const uint32_t w0 = list[i], w1 = __builtin_bit_cast(uint32_t, cosv[i]), w2 = __builtin_bit_cast(uint32_t, comb[i]);
+        const uint32_t w3 = __builtin_bit_cast(uint32_t, lexv[i]);
+        h_out[i] = w0;
+        h_out[k_cap + i] = w1;
+        h_out[2 * k_cap + i] = w2;
+        h_out[3 * k_cap + i] = w3;
+        chk += result_chk_term(w0, i) + result_chk_term(w1, k_cap + i) + result_chk_term(w2, 2 * k_cap + i) +
+               result_chk_term(w3, 3 * k_cap + i);
     }
-    if (threadIdx.x == 0) {
+    if (chk)
+        atomicAdd(&s_chk, chk);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { // (the greedy kernel's emit tail writes the same four words)
         h_out[4 * k_cap] = n;
         h_out[4 * k_cap + 1] = info[1];
+        h_out[4 * k_cap + 2] = block_chk_tail(s_chk, n, info[1], k_cap);
+        __threadfence_system();
+        h_out[4 * k_cap + 3] = kBlockDone;
     }
 }
 } // namespace rlr
@@ -1666,9 +1632,13 @@ hipError_t enqueue_query_scan(rlr_index *ix, Ctx *c, uint32_t qi, bool timed)
     return hipSuccess;
 }
 
+// pool != nullptr (with emit == false): a diversified search -- when the fused tail runs, its finish builds the MMR pool in
+// the same launch and *pool_done = true; otherwise the caller launches pool_prepare_kernel itself.
 hipError_t enqueue_query_rest(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint64_t *d_out_q, uint64_t *d_meta_q,
-                              bool timed, bool emit = true)
+                              bool timed, bool emit = true, const PoolArgs *pool = nullptr, bool *pool_done = nullptr)
 {
+    if (pool_done)
+        *pool_done = false;
     hipStream_t s = c->stream;
     hipError_t e;
     const uint32_t n = static_cast<uint32_t>(ix->n_rows);
@@ -1705,6 +1675,9 @@ hipError_t enqueue_query_rest(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPl
         ta.unordered = p.unordered;
         ta.direct_max = ix->tail_direct_max;
         ta.n_cu = ix->n_cu;
+        ta.pool = emit ? nullptr : pool;
+        if (pool_done)
+            *pool_done = ta.pool != nullptr;
         if ((e = launch_tail_stage1(ta, s)) != hipSuccess) return e;
         if (timed && (e = hipEventRecord(c->ev[2], s)) != hipSuccess) return e;
         if ((e = launch_tail_stage2(ta, s)) != hipSuccess) return e;
@@ -1734,10 +1707,10 @@ hipError_t enqueue_query_rest(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPl
 }
 
 hipError_t enqueue_query(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPlan &p, uint64_t *d_out_q, uint64_t *d_meta_q,
-                         bool timed, bool emit = true)
+                         bool timed, bool emit = true, const PoolArgs *pool = nullptr, bool *pool_done = nullptr)
 {
     const hipError_t e = enqueue_query_scan(ix, c, qi, timed);
-    return e != hipSuccess ? e : enqueue_query_rest(ix, c, qi, p, d_out_q, d_meta_q, timed, emit);
+    return e != hipSuccess ? e : enqueue_query_rest(ix, c, qi, p, d_out_q, d_meta_q, timed, emit, pool, pool_done);
 }
 
 // Large-candidate path for one query whose band overflowed the LDS sort (massive ties /
@@ -2073,7 +2046,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     stage_query_norms(ix, c, queries, nq);
     hipStream_t s = c->stream;
     c->hist_dirty = true; // cleared when every enqueued pipeline has run to its histogram-clearing stage
-    RLR_HIP(hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s));
+    RLR_HIP(upload_queries(c, h_q, q_bytes, s));
 
     const bool timed = ix->profiling;
     double scan_ms = 0, select_ms = 0, rescore_ms = 0, total_ms = 0;
@@ -2628,7 +2601,7 @@ int32_t rlr_search_topk_device_begin(rlr_index *ix, const float *queries, uint32
     if (wait_mode() != kWaitBlock)
         for (uint32_t q = 0; q < n_queries; ++q)
             h_meta[q] = kMetaPending; // (what _end polls instead of the stream's completion signal)
-    hipError_t e = hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s);
+    hipError_t e = upload_queries(c, h_q, q_bytes, s);
     uint64_t *out = static_cast<uint64_t *>(d_packed_out);
     for (uint32_t q = 0; q < n_queries && e == hipSuccess; ++q)
         e = enqueue_query(ix, c, q, p, out + static_cast<size_t>(q) * k, h_meta + q, timed);
@@ -2950,28 +2923,32 @@ int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uin
     uint32_t *d_nsel = reinterpret_cast<uint32_t *>(d_cos + 3ull * P);
     uint32_t *d_info = d_nsel + 1;
     const size_t q_bytes = static_cast<size_t>(ix->q_pitch) * sizeof(float);
-    const size_t out_words = 4ull * k_cap + 2;
+    const size_t out_words = 4ull * k_cap + 4;
     RLR_TRY(pin_reserve(c, q_bytes + out_words * 4 + 64));
     float *h_q = static_cast<float *>(c->h_pin);
     uint32_t *h_out = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + q_bytes);
+    h_out[4 * k_cap + 3] = kBlockPending; // (the greedy kernel's last store replaces it: what the wait below polls)
     std::memset(h_q, 0, q_bytes);
     std::memcpy(h_q, query, ix->dim * sizeof(float));
     stage_query_norms(ix, c, query, 1);
     c->hist_dirty = true;
     const bool timed = ix->profiling;
-    RLR_HIP(hipMemcpyAsync(c->d_query, h_q, q_bytes, hipMemcpyHostToDevice, s));
+    RLR_HIP(upload_queries(c, h_q, q_bytes, s));
     uint64_t *d_meta = c->d_out + fetch;
     static const bool two_launches = getenv("RLR_POOL_AFTER_SORT") != nullptr; // A/B: sort_emit, then the pool from its output
     const bool from_candidates = fetch <= 512 && !two_launches;                // (the band of a larger fetch rarely fits 1024)
-    RLR_HIP(enqueue_query(ix, c, 0, p, c->d_out, d_meta, timed, /*emit=*/!from_candidates));
+    const PoolArgs pa{fetch, need, n, w_embedding, w_lexical, c->d_list, d_comb, d_cos, d_info};
+    bool pool_done = false; // (the fused tail's finish builds the pool itself: one launch and ~13 us of config 2's chain less)
+    RLR_HIP(enqueue_query(ix, c, 0, p, c->d_out, d_meta, timed, /*emit=*/!from_candidates, from_candidates ? &pa : nullptr,
+                          &pool_done));
     if (timed) RLR_HIP(hipEventRecord(c->bev[0], s));
-    if (from_candidates)
-        hipLaunchKernelGGL(rlr::pool_prepare_kernel<true>, dim3(1), dim3(1024), 0, s, c->d_packed, c->d_state, fetch, need, n,
-                           w_embedding, w_lexical, c->d_list, d_comb, d_cos, d_info);
-    else
-        hipLaunchKernelGGL(rlr::pool_prepare_kernel<false>, dim3(1), dim3(1024), 0, s, c->d_out, c->d_state, fetch, need, n,
-                           w_embedding, w_lexical, c->d_list, d_comb, d_cos, d_info);
-    RLR_HIP(hipGetLastError());
+    if (!pool_done) {
+        if (from_candidates)
+            hipLaunchKernelGGL(rlr::pool_prepare_kernel<true>, dim3(1), dim3(1024), 0, s, c->d_packed, c->d_state, pa);
+        else
+            hipLaunchKernelGGL(rlr::pool_prepare_kernel<false>, dim3(1), dim3(1024), 0, s, c->d_out, c->d_state, pa);
+        RLR_HIP(hipGetLastError());
+    }
     RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
     rlr::MmrEmit emit; // the greedy kernel writes the picks into the pinned block itself
     emit.list = c->d_list;
@@ -2982,7 +2959,10 @@ int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uin
     emit.h_out = h_out;
     RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, k, lambda, d_order, d_mmr, d_nsel, d_info, 1, s, &emit));
     if (timed) RLR_HIP(hipEventRecord(c->bev[1], s));
-    RLR_HIP(hipStreamSynchronize(s));
+    if (timed)
+        RLR_HIP(hipStreamSynchronize(s)); // (the events are read below)
+    else
+        RLR_TRY(wait_block(h_out, k_cap, s, &c->wait_ema));
     RLR_TRY(check_hist_assert(c));
     c->hist_dirty = false;
     const uint32_t n_sel = h_out[4 * k_cap], status = h_out[4 * k_cap + 1];
@@ -3103,7 +3083,7 @@ static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t nee
     t->timed = ix->profiling;
     t->q_bytes = static_cast<size_t>(ix->q_pitch) * sizeof(float);
     t->lex_bytes_cap = 8 + static_cast<size_t>(n_lex_bound) * 8; // header | rows | scores, one copy
-    RLR_TRY(pin_reserve(c, t->q_bytes + t->lex_bytes_cap + (4ull * k_cap + 2) * 4 + 64));
+    RLR_TRY(pin_reserve(c, t->q_bytes + t->lex_bytes_cap + (4ull * k_cap + 4) * 4 + 64));
     float *h_q = static_cast<float *>(c->h_pin);
     std::memset(h_q, 0, t->q_bytes);
     std::memcpy(h_q, query, ix->dim * sizeof(float));
@@ -3119,7 +3099,7 @@ static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t nee
                 (void)hipStreamSynchronize(s);
         }
     } drain{s};
-    RLR_HIP(hipMemcpyAsync(c->d_query, h_q, t->q_bytes, hipMemcpyHostToDevice, s));
+    RLR_HIP(upload_queries(c, h_q, t->q_bytes, s));
     uint64_t *d_meta = c->d_out + fetch;
     // the scan first; then whatever the caller runs beside it (the BM25 chain on its own stream: about as long as scan +
     // select + re-score + sort, so it must not wait for the host to have launched those -- it used to start 39 us behind the
@@ -3173,6 +3153,7 @@ static int32_t hybrid_finish_impl(HybridTicket *ticket, const HybridLexSrc &src,
     float *d_cand = d_lcos + t->n_lex_bound;
     uint32_t *h_lex = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + t->q_bytes);
     uint32_t *h_out = reinterpret_cast<uint32_t *>(static_cast<char *>(c->h_pin) + t->q_bytes + t->lex_bytes_cap);
+    h_out[4 * k_cap + 3] = kBlockPending; // (the last kernel's last store replaces it: what the wait below polls)
     if (src.dev) { // the BM25 kernels ran beside the scan on their own stream: join, then unpack their result
         RLR_HIP(hipStreamWaitEvent(s, static_cast<hipEvent_t>(src.dev->ready), 0));
         hipLaunchKernelGGL(lex_unpack_kernel, dim3(1), dim3(1024), 0, s, src.dev->d_packed, src.dev->d_count,
@@ -3212,8 +3193,13 @@ static int32_t hybrid_finish_impl(HybridTicket *ticket, const HybridLexSrc &src,
         RLR_HIP(hipGetLastError());
     }
     if (t->timed) RLR_HIP(hipEventRecord(c->bev[1], s));
-    drain.armed = false;
-    RLR_HIP(hipStreamSynchronize(s));
+    if (t->timed) {
+        drain.armed = false;
+        RLR_HIP(hipStreamSynchronize(s)); // (the events are read below)
+    } else {
+        RLR_TRY(wait_block(h_out, k_cap, s, &c->wait_ema)); // (a failure leaves the drain guard armed)
+        drain.armed = false;
+    }
     RLR_TRY(check_hist_assert(c));
     c->hist_dirty = false;
     const uint32_t n_sel = h_out[4 * k_cap], status = h_out[4 * k_cap + 1];

@@ -79,6 +79,16 @@ hipError_t launch_batch_select(const float *scores, uint32_t n, size_t score_str
 //          workgroup that finishes last sorts and emits.  Both clear the two histograms for the next query.
 // out == nullptr: no sort / emit (the caller orders packed[0, st->n_cand) itself); *meta receives the candidate count.
 // false: the row shape does not fit the staged re-score (the caller takes the split five-launch pipeline).
+// The MMR pool of a diversified search built by the workgroup that finishes the tail (pool_prepare.h) instead of the
+// sort / emit: the `fetch` best candidates -> combined scores, order, cut to `need`.
+struct PoolArgs {
+    uint32_t fetch, need, n_rows;
+    float w_e, w_l;
+    uint32_t *list; // pool slot -> row
+    float *comb;    // combined score per slot
+    float *cosv;    // cosine per slot
+    uint32_t *info; // [0] pool size, [1] status
+};
 struct TailArgs {
     const float *scores;
     uint32_t n;
@@ -96,6 +106,7 @@ struct TailArgs {
     bool unordered;
     uint32_t direct_max;
     int n_cu;
+    const PoolArgs *pool = nullptr; // non-null (with out == nullptr): the finish builds the MMR pool from the candidates
 };
 bool tail_fits(uint32_t pitch16, uint32_t dim, int dtype);
 hipError_t launch_tail_stage1(const TailArgs &a, hipStream_t s);

@@ -149,4 +149,14 @@ __device__ inline void sort_emit_body(const uint64_t *packed, uint32_t n_raw, ui
     }
 }
 
+// The result block of the fused search -> MMR paths in pinned host memory: [row | cos | combined | lexical] x k_cap, then
+// n, status, checksum, done.  `done` (pre-set to kBlockPending by a host that wants to poll) is written last; the
+// checksum covers the 4 x n value words plus n and status, with the same term as above.
+constexpr uint32_t kBlockPending = 0xFFFFFFFFu, kBlockDone = 1u;
+
+__host__ __device__ inline uint32_t block_chk_tail(uint32_t chk_values, uint32_t n, uint32_t status, uint32_t k_cap)
+{
+    return chk_values + result_chk_term(n, 4 * k_cap) + result_chk_term(status, 4 * k_cap + 1);
+}
+
 } // namespace rlr

@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "lds_select.h"
 #include "select_dev.h"
+#include "pool_prepare.h"
 #include "sort_emit.h"
 #include "staged_dot.h"
 #include "../../include/rlr_gpu.h"
@@ -33,7 +34,8 @@ namespace rlr {
 namespace {
 
 constexpr uint32_t kLocalCap = 1024;    // candidates one workgroup keeps for its own re-score
-constexpr uint32_t kSortBytes = 4096 * 8 + 2048 * 4; // sort_emit_body's LDS: 4096 keys + a 2048-bin histogram
+constexpr uint32_t kSortBytes = 4096 * 8 + 2048 * 4; // sort_emit_body's LDS: 4096 keys + a 2048-bin histogram (>= kPoolLdsBytes)
+static_assert(kPoolLdsBytes <= kSortBytes, "the pool preparation runs in the sort's LDS");
 
 struct TailDev {
     const float *scores;
@@ -51,6 +53,8 @@ struct TailDev {
     uint32_t unordered;
     uint32_t direct_max;
     uint32_t cpb;
+    uint32_t has_pool;
+    PoolArgs pool;
 };
 
 // The rows of this workgroup's slice whose nominated score key is >= key_lo: reserve their slots in the global candidate
@@ -65,22 +69,25 @@ __device__ __forceinline__ uint32_t collect_rescore(const TailDev &a, uint32_t k
     if (tid == 0)
         s_cnt = 0;
     __syncthreads();
-    const uint32_t stride = gridDim.x * NT;
     const uint32_t n4 = a.n / 4;
     const float4 *s4 = reinterpret_cast<const float4 *>(a.scores);
-    // four independent 16-byte loads in flight per thread (a 10 M-row pass is ~10 loads per thread: issued one at a time
-    // behind the compare-and-append it was latency-bound)
-    for (uint32_t i0 = blockIdx.x * NT + tid; i0 < n4; i0 += 4 * stride) {
+    // This workgroup's slice: one contiguous run of 16-byte score units (the grid may hold more workgroups than the pass
+    // needs -- launch_tail_stage*: the re-score wants the candidates of a small corpus spread out).  Four independent
+    // loads in flight per thread (a 10 M-row pass is ~10 loads per thread: one at a time behind the compare-and-append
+    // it was latency-bound).
+    const uint32_t chunk = (n4 + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = min(blockIdx.x * chunk, n4), hi = min(lo + chunk, n4);
+    for (uint32_t i0 = lo + tid; i0 < hi; i0 += 4 * NT) {
         float4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t i = i0 + u * stride;
-            v[u] = s4[i < n4 ? i : i0];
+            const uint32_t i = i0 + u * NT;
+            v[u] = s4[i < hi ? i : i0];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t i = i0 + u * stride;
-            if (i >= n4)
+            const uint32_t i = i0 + u * NT;
+            if (i >= hi)
                 break;
             const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
@@ -93,13 +100,13 @@ __device__ __forceinline__ uint32_t collect_rescore(const TailDev &a, uint32_t k
             }
         }
     }
-    for (uint32_t i = n4 * 4 + blockIdx.x * NT + tid; i < a.n; i += stride) {
-        if (score_key(a.scores[i]) >= key_lo) {
-            const uint32_t l = atomicAdd(&s_cnt, 1u);
-            if (l < kLocalCap)
-                s_row[l] = i;
-        }
-    }
+    if (blockIdx.x == 0) // the up to three scores behind the last whole unit
+        for (uint32_t i = n4 * 4 + tid; i < a.n; i += NT)
+            if (score_key(a.scores[i]) >= key_lo) {
+                const uint32_t l = atomicAdd(&s_cnt, 1u);
+                if (l < kLocalCap)
+                    s_row[l] = i;
+            }
     __syncthreads();
     const uint32_t found = s_cnt;
     if (found == 0)
@@ -205,8 +212,11 @@ __device__ __forceinline__ void tail_finish(const TailDev &a, float *s_mem)
         uint64_t *s = reinterpret_cast<uint64_t *>(s_mem);
         uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_mem) + 4096 * 2;
         sort_emit_body<true>(a.packed, n_eff, a.cap, a.out, a.k, a.meta, a.unordered != 0, s, s_hist);
-    } else if (threadIdx.x == 0 && a.meta) {
-        *a.meta = n_eff;
+    } else {
+        if (threadIdx.x == 0 && a.meta)
+            *a.meta = n_eff;
+        if (a.has_pool) // a diversified search: the MMR pool straight from the candidates, in this launch (pool_prepare.h)
+            pool_prepare_body<true, true>(a.packed, n_eff, a.cap, a.pool, reinterpret_cast<char *>(s_mem));
     }
 }
 
@@ -291,6 +301,8 @@ TailDev to_dev(const TailArgs &a, uint32_t cpb)
     d.unordered = a.unordered ? 1u : 0u;
     d.direct_max = a.direct_max;
     d.cpb = cpb;
+    d.has_pool = a.pool && !a.out ? 1u : 0u;
+    d.pool = a.pool ? *a.pool : PoolArgs{};
     return d;
 }
 
@@ -311,7 +323,13 @@ hipError_t launch_tail_stage1(const TailArgs &a, hipStream_t s)
         return hipErrorInvalidValue;
     const TailDev d = to_dev(a, cpb);
     const size_t lds = std::max<size_t>(staging, kHistBins * sizeof(uint32_t));
-    uint32_t blocks = (a.n / 4 + kSelThreads - 1) / kSelThreads;
+    // One 16-byte load per thread covers the pass; but the workgroups also re-score what they find, eight candidates at a
+    // time, one 768-step chain each -- so a small corpus is spread over MORE workgroups than its scores need (partly idle
+    // ones), until a few hundred candidates come out at a handful per workgroup: with 25 workgroups for 100 k rows the
+    // ~1800 candidates of a text search's fetch took 85 us to re-score, ten groups in a row per workgroup.
+    const uint32_t n4 = a.n / 4 + 1;
+    uint32_t blocks = (n4 + kSelThreads - 1) / kSelThreads;
+    blocks = std::max(blocks, std::min<uint32_t>(static_cast<uint32_t>(a.n_cu) * 2, (n4 + 31) / 32));
     blocks = std::max<uint32_t>(1, std::min<uint32_t>(blocks, static_cast<uint32_t>(a.n_cu) * 8));
     if (a.dtype == RLR_F16)
         hipLaunchKernelGGL(tail_stage1_kernel<true>, dim3(blocks), dim3(kSelThreads), lds, s, d);
@@ -331,7 +349,9 @@ hipError_t launch_tail_stage2(const TailArgs &a, hipStream_t s)
     // at least two workgroups (2048 threads clear the digit-1 histogram); REFINE mode wants a pass over the scores.  One
     // 1024-thread workgroup per CU is what is resident at this kernel's register count: a second round of workgroups would
     // only start when the first has finished its bin search, pass and re-score.
-    uint32_t blocks = (a.n / 4 + 1023) / 1024;
+    // (and, as in stage 1, at least one workgroup per 64 score units: the candidates of a small corpus spread out)
+    const uint32_t n4 = a.n / 4 + 1;
+    uint32_t blocks = std::max((n4 + 1023) / 1024, (n4 + 63) / 64);
     blocks = std::max<uint32_t>(2, std::min<uint32_t>(blocks, static_cast<uint32_t>(a.n_cu)));
     if (a.dtype == RLR_F16)
         hipLaunchKernelGGL(tail_stage2_kernel<true>, dim3(blocks), dim3(1024), lds, s, d);

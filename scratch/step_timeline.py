@@ -11,8 +11,9 @@ scan_idx = [i for i, k in enumerate(ks) if k[0].startswith("scan_")]
 steps = []
 for a, b in zip(scan_idx, scan_idx[1:]):
     # a step = [copy in front of the scan] scan ... up to the copy in front of the next scan
-    lo = a - 1 if a > 0 and ks[a - 1][0].startswith("__amd_rocclr_copy") else a
-    hi = b - 1 if ks[b - 1][0].startswith("__amd_rocclr_copy") else b
+    up = ("__amd_rocclr_copy", "stage_query_kernel")  # the query upload in front of a scan
+    lo = a - 1 if a > 0 and ks[a - 1][0].startswith(up) else a
+    hi = b - 1 if ks[b - 1][0].startswith(up) else b
     steps.append(ks[lo:hi] + [("NEXT", ks[hi][1], ks[hi][1])])
 steps = [s for s in steps if len(s) == statistics.mode(len(x) for x in steps)][20:]
 def total(s): return (s[-1][1] - s[0][1]) / 1000

@@ -96,8 +96,9 @@ def test_tail_duplicates_ties_and_nan_rows(rlr, oracle, mode):
 @pytest.mark.parametrize("mode", ["direct", "refine"])
 def test_tail_local_list_overflow_takes_the_large_candidate_path(rlr, oracle, mode):
     """more than 1024 candidates inside one workgroup's slice (3000 adjacent copies of the best row): the local list
-    overflows, the finish reports a band overflow and the host's large-candidate path answers -- same result"""
-    n, dim, k = 40000, 256, 50
+    overflows, the finish reports a band overflow and the host's large-candidate path answers -- same result.  (1.2 M short
+    rows: stage 2's 256 workgroups then own ~4700 rows each; stage 1's never own more than 1024, their lists cannot overflow.)"""
+    n, dim, k = 1_200_000, 64, 50
     rows = oracle.synth_rows(n, dim, seed=41)
     qn = oracle.normalize(oracle.synth_query(dim, seed=42))
     e = oracle.scan(rows, qn)
@@ -108,8 +109,6 @@ def test_tail_local_list_overflow_takes_the_large_candidate_path(rlr, oracle, mo
     try:
         ix.profile_read(reset=True)
         check(ix, oracle, rows, qn, k)
-        # stage 1 hands every workgroup ONE 1024-row chunk up to 2 M rows: its local list cannot overflow here; stage 2's
-        # workgroups take 4096-row chunks and this one does
         assert ix.profile_read().n_retries == (1 if mode == "refine" else 0)
         check(ix, oracle, rows, oracle.normalize(oracle.synth_query(dim, seed=43)), k)  # the counters were reset: next query fine
     finally:
