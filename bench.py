@@ -304,6 +304,7 @@ def config_c3(rlr, ix, args, torch):
         return {"value": steps * nq / el, "unit": "queries/s", "ms_per_batch": el / steps * 1e3,
                 "stages_ms": {"gemm_all_launches": p.batch_gemm_ms / nb, "select_and_finish": p.batch_other_ms / nb},
                 "fallback_queries": p.n_batch_fallbacks,
+                "n_batches_without_image": p.n_batches_without_image,   # rlr_profile's hint that an image would have paid
                 "extra_hbm_bytes": len(ix) * args.dim * 2 if image else 0,
                 "roofline": batched_roofline(p, args.dim, nq, image, "batch256_image" if image else "batch256")}, last
 

@@ -100,7 +100,9 @@ int32_t rlr_index_fill_synthetic(rlr_index *idx, uint64_t n_rows, uint64_t row0,
  * matrix-core path: [tile of 256 rows][K-chunk][wave][MFMA fragment], every fragment load lane-
  * linear and a tile contiguous in HBM.  Costs dim * 2 bytes per row; kept in sync by upload /
  * append / delete / fill.  Results are unchanged (the image only nominates; nominated rows are
- * re-scored from the row-major master copy); batched throughput roughly doubles.  dim % 64 == 0.
+ * re-scored from the row-major master copy); batched throughput roughly doubles (rlr_profile's
+ * n_batches_without_image counts the batches that would have gained).  It is never switched on
+ * behind the caller's back: + 50 % of an f32 index's HBM is the caller's decision.  dim % 64 == 0.
  * enable = 3 (bit 1) additionally lets SINGLE queries over f32 rows nominate from the image: the
  * HBM-bound scan then streams 2 bytes per element instead of 4 (10 M x 768: 2.5 ms instead of 4.6 ms
  * per query), the guard band widens to the binary16 rounding bound, the re-score is unchanged --
@@ -361,6 +363,11 @@ typedef struct rlr_profile {
     /* MMR (rlr_mmr_select*, rlr_engine_search_with_diversity*) */
     uint64_t n_mmr;            /* queries diversified */
     double mmr_ms;             /* gather + Gram + greedy kernels, HIP events on their stream, summed per call */
+    /* batches of >= 16 queries that streamed the f32 ROWS through the matrix cores because the index keeps no
+     * nomination image (rlr_index_enable_batch_image) although its shape allows one: the same results at about half
+     * the batched throughput (10 M x 768, 256 queries: 31 k instead of 59 k queries/s).  A host that sees this count
+     * grow and has dim * 2 bytes per row of HBM to spare should switch the image on. */
+    uint64_t n_batches_without_image;
 } rlr_profile;
 /* enable != 0: record HIP events around each stage on the stream it is launched on
  * (adds one event pair per stage).  Disabled by default. */

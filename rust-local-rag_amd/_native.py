@@ -62,7 +62,7 @@ class ProfileC(C.Structure):
                 ("batch_other_ms", C.c_double), ("batch_gemm_bytes", C.c_uint64), ("batch_gemm_flops", C.c_double),
                 ("n_batch_fallbacks", C.c_uint64),
                 ("batch_main_ms", C.c_double), ("batch_main_bytes", C.c_uint64), ("batch_main_flops", C.c_double),
-                ("n_mmr", C.c_uint64), ("mmr_ms", C.c_double)]
+                ("n_mmr", C.c_uint64), ("mmr_ms", C.c_double), ("n_batches_without_image", C.c_uint64)]
 
 
 class MultiStatsC(C.Structure):

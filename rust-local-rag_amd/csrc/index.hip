@@ -515,8 +515,8 @@ hipError_t rows_alloc_select(const rlr_index *ix, size_t bytes, RowBlock *b, voi
     std::vector<hipMemGenericAllocationHandle_t> rejects;
     if (!no_select && n_slabs >= 2 && slab_rows >= 4096 &&
         rlr::dev_malloc(reinterpret_cast<void **>(&d_scratch), (slab_rows + ix->q_pitch + 64) * sizeof(float)) == hipSuccess &&
-        hipMemset(d_scratch, 0, (slab_rows + ix->q_pitch + 64) * sizeof(float)) == hipSuccess && hipEventCreate(&ev0) == hipSuccess &&
-        hipEventCreate(&ev1) == hipSuccess) {
+        hipMemset(d_scratch, 0, (slab_rows + ix->q_pitch + 64) * sizeof(float)) == hipSuccess &&
+        hipStreamSynchronize(nullptr) == hipSuccess && hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess) {
         std::vector<float> ms(n_slabs, -1.0f);
         float best = -1.0f;
         bool ok = true;
@@ -1983,6 +1983,8 @@ int32_t run_batched(rlr_index *ix, Ctx *c, uint32_t q0, uint32_t nq, const Searc
         ix->prof.n_batches += 1;
         ix->prof.n_batch_queries += nq;
         ix->prof.n_batch_fallbacks += fallbacks;
+        if (!use_image && !use_multi && nq >= 16 && ix->dtype == RLR_F32 && gemm_image_usable(ix->dim))
+            ix->prof.n_batches_without_image += 1; // (an image would have halved the bytes this batch streamed)
         if (timed) {
             float prep = 0, sel = 0, g2 = 0, fin = 0;
             (void)hipEventElapsedTime(&prep, c->bev[0], c->bev[1]);

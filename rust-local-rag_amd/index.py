@@ -48,6 +48,7 @@ class Profile:
     batch_main_flops: float = 0.0
     n_mmr: int = 0
     mmr_ms: float = 0.0
+    n_batches_without_image: int = 0
 
 
 class GpuIndex:
