@@ -23,6 +23,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <time.h>
@@ -908,6 +909,8 @@ int32_t wait_polling(Complete &&complete, hipStream_t s, WaitEma *c, uint32_t ke
             if (e != hipErrorNotReady)
                 return fail(RLR_E_HIP, "stream failed while a search was in flight: %s", hipGetErrorString(e));
         }
+        if (polls > 8192 && (polls & 0xFF) == 0)
+            std::this_thread::yield(); // a long wait: more waiters than cores must not starve the threads that feed the GPU
         cpu_relax();
     }
     std::atomic_thread_fence(std::memory_order_acquire);
