@@ -107,6 +107,9 @@ struct GemmArgs {
     size_t score_stride;
     uint32_t *sync;              // gemm8, several query blocks: 256 zeroed words, one arrival counter per sibling group (or null)
     uint32_t sync_every;         // ... and the siblings meet before every sync_every-th unit
+    uint32_t a_nt_shared;        // (experiment, RLR_GEMM8_A_NT=1) row half-tiles streamed `nt` even when sibling workgroups share them:
+                                 // config 5's share fetched 1.36 x (meeting every unit) / 1.50 x (every 2nd) the image against
+                                 // 1.22 x / 1.28 x without -- the siblings are not tight enough for evict-first lines; off
 };
 
 // ---- epilogue shared by the GEMM kernels: D layout is col = lane & 15 (query), row = 4*(lane >> 4) + reg
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs a, const char
         // non-temporal only while a row tile has ONE reader (<= 256 queries).  With several query blocks the units of a tile run
         // side by side on one XCD and their 2nd..n-th read is meant to hit its L2: streamed with `nt` the lines are gone before the
         // siblings arrive -- config 5's share fetched the image 3.2 times per batch (rocprofv3 FETCH_SIZE, profiles/r03_c5_share_*)
-        if ((VAR & 4) && is_a && nqb == 1) {
+        if ((VAR & 4) && is_a && (nqb == 1 || a.a_nt_shared)) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + tid * 16),
                                              (__attribute__((address_space(3))) void *)(dst), 16, 0, 2);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + second + tid * 16),
@@ -1236,6 +1239,7 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
     a.score_stride = score_stride;
     a.sync = nullptr;
     a.sync_every = 4;
+    a.a_nt_shared = 0;
     const uint32_t n_rt = (row_end - row_begin + kBM - 1) / kBM;
     const uint32_t grid = ((n_rt + 7) / 8) * 8 * a.n_qblocks;
     const bool mat = scores != nullptr;
@@ -1269,6 +1273,8 @@ hipError_t launch_gemm_nominate(const void *rows, uint32_t pitch16, uint32_t dim
             static const uint32_t every = getenv("RLR_GEMM8_SYNC_EVERY") ? static_cast<uint32_t>(std::max(1, atoi(getenv("RLR_GEMM8_SYNC_EVERY")))) : 4u;
             a.sync_every = every;
         }
+        static const bool a_nt = getenv("RLR_GEMM8_A_NT") != nullptr;
+        a.a_nt_shared = a_nt ? 1u : 0u;
         static const int var = [] {
             const char *v = getenv("RLR_GEMM8_VARIANT");
             return v ? static_cast<int>(strtol(v, nullptr, 0)) : 6; // same-box A/B: 6 is 2-4 % faster than 0, 1 is slower

@@ -4,6 +4,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for ev in ${1:-4 2 1}; do
   export RLR_GEMM8_SYNC_EVERY=$ev
+  if [ -n "$2" ]; then export $2; fi
   echo "== RLR_GEMM8_SYNC_EVERY=$ev $2"
   timeout -k 10 200 python3 $R/scratch/time_c5_shard.py --image 2>/dev/null | tail -n 1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('  search_ms %.2f gemm_ms %.2f other_ms %.2f TFLOPs %.0f same=%s' % (d['batched_search_top308_ms'], d['gemm_ms'], d['other_ms'], d['gemm_TFLOPs'], d['batched_equals_single_path']))"
   rm -rf $O/c5ab_fetch; timeout -k 10 250 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c5ab_fetch -- python3 $R/scratch/time_c5_shard.py --image > $O/c5ab_fetch.log 2>&1 < /dev/null

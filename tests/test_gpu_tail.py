@@ -135,3 +135,39 @@ def test_tail_state_survives_interleaved_entry_points(rlr, oracle):
             assert [g.row for g in got] == list(oracle.search(rows, q, 10)[0])
     finally:
         eng.close()
+
+
+def test_synthetic_generator_flags_match_the_oracle(rlr, oracle):
+    """the two generator modes bench.py's hostile configurations use: bit 31 of n_clusters = tight clusters (twin of
+    rlr_o_synth_raw), bit 30 = the last 1 % of the rows repeat the first 1 % (a fill-level rule: two generator ranges)"""
+    n, dim = 3000, 96
+    ix = rlr.GpuIndex(dim)
+    try:
+        ix.fill_synthetic(n, seed=77, n_clusters=5 | 0x80000000)
+        want = oracle.synth_rows(n, dim, seed=77, n_clusters=5 | 0x80000000)
+        assert np.array_equal(bits(ix.fetch_rows(np.arange(n))), bits(want))
+        # near-copies inside a cluster: the best cosine to ANOTHER row is ~0.999
+        r, c = ix.search_topk(want[0], 2)
+        assert int(r[0][0]) == 0 and float(c[0][1]) > 0.99
+        ix.fill_synthetic(n, seed=78, row0=10, n_clusters=0x40000000)
+        base = oracle.synth_rows(n, dim, seed=78, row0=10)
+        want = np.concatenate([base[: n - n // 100], base[: n // 100]])
+        assert np.array_equal(bits(ix.fetch_rows(np.arange(n))), bits(want))
+    finally:
+        ix.close()
+
+
+def test_probe_bandwidth_modes(rlr):
+    """the measured-peak probes of bench.py's roofline: plausible rates, every mode, errors on bad input"""
+    ix = rlr.GpuIndex(768)
+    try:
+        ix.fill_synthetic(400_000, seed=5)                      # 1.2 GB
+        for mode in (0, 1, 2, 3):
+            gbps, ms = ix.probe_bandwidth(mode, 3)
+            assert 200.0 < gbps < 16000.0 and ms > 0, (mode, gbps, ms)
+        with pytest.raises(Exception):
+            ix.probe_bandwidth(7, 1)
+        r, c = ix.search_topk(rlr.normalize(np.ones(768, np.float32)), 10)   # the index still answers afterwards
+        assert r.shape == (1, 10)
+    finally:
+        ix.close()
