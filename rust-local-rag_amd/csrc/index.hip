@@ -141,6 +141,8 @@ struct Ctx {
     size_t h_pin_bytes = 0;
     std::vector<float> q_norm; // ||q||_2 of the staged queries (band of the 8-bit nomination scan)
     WaitEma wait_ema;          // how long the last waits for a call's completion words took (wait_flags)
+    const float *h_q_kq = nullptr; // set for the duration of a call whose scans take their query in the kernel arguments
+                                   // (ScanArgs::query_host): the staged queries in pinned host memory, q_pitch floats each
     bool hist_dirty = false; // a pipeline was enqueued and did not complete: d_hist may hold counts
     uint32_t *h_assert = nullptr; // RLR_POISON_ALLOC=1 only: pinned word the zero-histogram assertion kernel counts into
     // rlr_search_topk_device_begin / _end
@@ -993,6 +995,18 @@ __global__ __launch_bounds__(256) void stage_query_kernel(const float4 *__restri
 
 namespace {
 
+// Will this index's single-query scans take their query in the kernel arguments?  (Then nothing is uploaded in front of
+// them: workgroup 0 of the scan leaves the query in the context's device buffer for the kernels behind it.)
+bool scans_take_host_query(const rlr_index *ix, const float *h_q);
+
+// The queries of a call whose pipelines start with enqueue_query_scan: by the scans themselves where they can, else uploaded.
+hipError_t upload_queries(Ctx *c, const float *h_q, size_t q_bytes, hipStream_t s);
+hipError_t stage_queries_for_scans(const rlr_index *ix, Ctx *c, const float *h_q, size_t q_bytes, hipStream_t s)
+{
+    c->h_q_kq = scans_take_host_query(ix, h_q) ? h_q : nullptr;
+    return c->h_q_kq ? hipSuccess : upload_queries(c, h_q, q_bytes, s);
+}
+
 hipError_t upload_queries(Ctx *c, const float *h_q, size_t q_bytes, hipStream_t s)
 {
     static const bool by_copy = getenv("RLR_QUERY_MEMCPY") != nullptr; // (A/B)
@@ -1155,10 +1169,10 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
         __shared__ uint64_t s_sorted[1024];
         for (uint32_t i = threadIdx.x; i < n_pad; i += 256) {
             const uint64_t mine = s[i];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n_pad; ++j) {
-                const uint64_t o = s[j];
-                rank += (o > mine) || (o == mine && j < i);
+            uint32_t rank = lds_rank_desc(s, n_pad, mine);
+            if (mine == 0) { // the padding zeros tie among themselves: they keep their order
+                for (uint32_t j = 0; j < i; ++j)
+                    rank += s[j] == 0;
             }
             s_sorted[rank] = mine;
         }
@@ -1461,9 +1475,7 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
     if (!flood)
         for (uint32_t i = t; i < n_sel; i += 1024) {
             const uint64_t mine = s_sel[i];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n_sel; ++j) // keys are unique (the row is part of the key)
-                rank += s_sel[j] > mine;
+            const uint32_t rank = lds_rank_desc(s_sel, n_sel, mine); // keys are unique (the row is part of the key)
             if (rank < n_pool) {
                 const uint32_t slot = s_slot[i];
                 list[rank] = 0xFFFFFFFFu - static_cast<uint32_t>(mine & 0xFFFFFFFFull);
@@ -1559,6 +1571,25 @@ bool scan_over_q8(const rlr_index *ix)
     return ix->q8_enabled && ix->d_q8 && !ix->q8_has_inf;
 }
 
+bool scans_take_host_query(const rlr_index *ix, const float *h_q)
+{
+    if (scan_over_q8(ix) || scan_over_image(ix) || ix->n_rows == 0)
+        return false;
+    ScanArgs sa;
+    sa.rows = ix->d_rows;
+    sa.query = nullptr;
+    sa.scores = nullptr;
+    sa.hist = nullptr;
+    sa.n_rows = static_cast<uint32_t>(ix->n_rows);
+    sa.dim = ix->dim;
+    sa.pitch16 = ix->pitch16;
+    sa.dtype = ix->dtype;
+    sa.n_cu = ix->n_cu;
+    sa.variant = ix->scan_variant;
+    sa.query_host = h_q;
+    return launch_scan_takes_host_query(sa);
+}
+
 // band for 8-bit-nominated scores of a query of norm q_norm (Cauchy-Schwarz on the stored row error norms)
 float q8_two_eps(const rlr_index *ix, float q_norm, float guard_eps)
 {
@@ -1618,6 +1649,7 @@ hipError_t enqueue_query_scan(rlr_index *ix, Ctx *c, uint32_t qi, bool timed)
     sa.dtype = ix->dtype;
     sa.n_cu = ix->n_cu;
     sa.variant = ix->scan_variant;
+    sa.query_host = c->h_q_kq ? c->h_q_kq + static_cast<size_t>(qi) * ix->q_pitch : nullptr;
     static const bool variant_dyn = getenv("RLR_SCAN_VARIANT_DYN") != nullptr; // (experiments: the variant re-read per launch)
     if (variant_dyn)
         if (const char *v = getenv("RLR_SCAN_VARIANT"))
@@ -2051,7 +2083,12 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
     stage_query_norms(ix, c, queries, nq);
     hipStream_t s = c->stream;
     c->hist_dirty = true; // cleared when every enqueued pipeline has run to its histogram-clearing stage
-    RLR_HIP(upload_queries(c, h_q, q_bytes, s));
+    const bool batched = batch_eligible(ix, nq, p.k);
+    c->h_q_kq = nullptr;
+    if (batched) // (the matrix-core pipeline reads the queries from device memory)
+        RLR_HIP(upload_queries(c, h_q, q_bytes, s));
+    else
+        RLR_HIP(stage_queries_for_scans(ix, c, h_q, q_bytes, s));
 
     const bool timed = ix->profiling;
     double scan_ms = 0, select_ms = 0, rescore_ms = 0, total_ms = 0;
@@ -2062,7 +2099,7 @@ int32_t run_search(rlr_index *ix, Ctx *c, const float *queries, uint32_t nq, uin
         return RLR_OK;
     };
 
-    if (batch_eligible(ix, nq, p.k)) {
+    if (batched) {
         // matrix-core path in runs of <= kBatchMaxQueries; queries it hands back (overflow, or
         // fewer than k finite candidates) go through the single-query pipeline below.
         std::vector<uint32_t> redo;
@@ -2606,7 +2643,7 @@ int32_t rlr_search_topk_device_begin(rlr_index *ix, const float *queries, uint32
     if (wait_mode() != kWaitBlock)
         for (uint32_t q = 0; q < n_queries; ++q)
             h_meta[q] = kMetaPending; // (what _end polls instead of the stream's completion signal)
-    hipError_t e = upload_queries(c, h_q, q_bytes, s);
+    hipError_t e = stage_queries_for_scans(ix, c, h_q, q_bytes, s);
     uint64_t *out = static_cast<uint64_t *>(d_packed_out);
     for (uint32_t q = 0; q < n_queries && e == hipSuccess; ++q)
         e = enqueue_query(ix, c, q, p, out + static_cast<size_t>(q) * k, h_meta + q, timed);
@@ -2938,7 +2975,7 @@ int32_t rlr_search_diverse(rlr_index *ix, const float *query, uint32_t pool, uin
     stage_query_norms(ix, c, query, 1);
     c->hist_dirty = true;
     const bool timed = ix->profiling;
-    RLR_HIP(upload_queries(c, h_q, q_bytes, s));
+    RLR_HIP(stage_queries_for_scans(ix, c, h_q, q_bytes, s));
     uint64_t *d_meta = c->d_out + fetch;
     static const bool two_launches = getenv("RLR_POOL_AFTER_SORT") != nullptr; // A/B: sort_emit, then the pool from its output
     const bool from_candidates = fetch <= 512 && !two_launches;                // (the band of a larger fetch rarely fits 1024)
@@ -3104,7 +3141,7 @@ static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t nee
                 (void)hipStreamSynchronize(s);
         }
     } drain{s};
-    RLR_HIP(upload_queries(c, h_q, t->q_bytes, s));
+    RLR_HIP(stage_queries_for_scans(ix, c, h_q, t->q_bytes, s));
     uint64_t *d_meta = c->d_out + fetch;
     // the scan first; then whatever the caller runs beside it (the BM25 chain on its own stream: about as long as scan +
     // select + re-score + sort, so it must not wait for the host to have launched those -- it used to start 39 us behind the

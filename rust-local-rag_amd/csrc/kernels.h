@@ -29,8 +29,14 @@ struct ScanArgs {
     int dtype;            // RLR_F32 / RLR_F16
     int n_cu;
     int variant;          // tuning knob, 0 = default
+    // Optional: the same (zero padded) query in HOST memory.  When set and the shape allows it (f32 rows of <= 768
+    // elements on the fixed kernel), the query travels in the kernel's ARGUMENTS and workgroup 0 writes it to `query`
+    // for the kernels behind the scan: no upload in front of the scan (a 2.5 us kernel plus the ~4 us the host needs to
+    // submit the next launch, during which the device idles).  launch_scan_takes_host_query() says whether it will.
+    const float *query_host = nullptr;
 };
 hipError_t launch_scan(const ScanArgs &a, hipStream_t stream);
+bool launch_scan_takes_host_query(const ScanArgs &a);
 // one pass over the rows for 2..8 queries (a.query = n_queries x q_pitch floats, a.scores = n_queries x score_stride);
 // false when the shape is not served (then nothing was launched)
 bool launch_scan_multi(const ScanArgs &a, uint32_t q_pitch, uint32_t n_queries, size_t score_stride, hipStream_t s,

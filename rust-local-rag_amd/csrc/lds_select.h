@@ -6,6 +6,27 @@
 
 namespace rlr {
 
+// Number of keys in s[0, n) (LDS) greater than `mine`: the position of `mine` in the descending order of unique keys (the
+// rank sorts of sort_emit.h / pool_prepare.h / the merge kernel).  Eight independent 8-byte reads in flight per step: written
+// as a plain `for (j) rank += s[j] > mine` loop every iteration waited for its own LDS read (~100 cycles), and the
+// few-hundred-candidate sorts cost 5-6 us each on a workgroup whose other waves have nothing to do meanwhile.
+__device__ inline uint32_t lds_rank_desc(const uint64_t *s, uint32_t n, uint64_t mine)
+{
+    uint32_t rank = 0, j = 0;
+    for (; j + 8 <= n; j += 8) {
+        uint64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = s[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            rank += v[u] > mine;
+    }
+    for (; j < n; ++j)
+        rank += s[j] > mine;
+    return rank;
+}
+
 // The bin holding the rank-th key counted from the top of a histogram of up to 2048 bins in LDS (entries [nb, 2048) zero), by
 // all 1024 threads of the workgroup: thread t owns bins 2t and 2t + 1 (one conflict-free read), a wavefront suffix
 // scan, the 16 wave totals through LDS.  sel[0] = bin, sel[1] = rank inside the bin (1-based), sel[2] = the bin's count;

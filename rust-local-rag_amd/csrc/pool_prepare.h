@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "lds_select.h"
 #include "sort_emit.h"
 
 namespace rlr {
@@ -29,8 +30,10 @@ constexpr uint32_t kPoolLdsBytes = kPoolFetchMax * 8 + kPoolFetchMax * 4 * 2 + 1
 // one trip through memory less per search.  More than 1024 candidates (a dense band) report status 1 and the host takes
 // the two-call path, as for a guard-band overflow.  COHERENT: see sort_emit.h (candidates stored by other workgroups of
 // the same launch).  Called by all 1024 threads; `lds` = kPoolLdsBytes, 16-byte aligned.
+// `pre`: packed[threadIdx.x] already loaded by the caller (see sort_emit.h), or null.
 template <bool FROM_CANDIDATES, bool COHERENT>
-__device__ inline void pool_prepare_body(const uint64_t *packed, uint32_t n_raw, uint32_t cap, const PoolArgs &pa, char *lds)
+__device__ inline void pool_prepare_body(const uint64_t *packed, uint32_t n_raw, uint32_t cap, const PoolArgs &pa, char *lds,
+                                         const uint64_t *pre = nullptr)
 {
     uint64_t *s_key = reinterpret_cast<uint64_t *>(lds);
     float *s_c = reinterpret_cast<float *>(s_key + kPoolFetchMax);
@@ -50,15 +53,13 @@ __device__ inline void pool_prepare_body(const uint64_t *packed, uint32_t n_raw,
         overflow = n_raw > cap || n_raw > 1024;
         if (!overflow) {
             if (t < n_raw)
-                s_raw[t] = load_candidate<COHERENT>(packed + t);
+                s_raw[t] = pre ? *pre : load_candidate<COHERENT>(packed + t);
             for (uint32_t i = min(n_raw, fetch) + t; i < fetch; i += 1024)
                 s_best[i] = 0ull; // (valid entries are a prefix, zeros behind: what sort_emit writes)
             __syncthreads();
             if (t < n_raw) {
                 const uint64_t mine = s_raw[t];
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < n_raw; ++j)
-                    rank += s_raw[j] > mine;
+                const uint32_t rank = lds_rank_desc(s_raw, n_raw, mine);
                 if (rank < fetch)
                     s_best[rank] = mine;
             }
@@ -87,9 +88,7 @@ __device__ inline void pool_prepare_body(const uint64_t *packed, uint32_t n_raw,
     // rank sort: keys are unique (the row is part of the key)
     for (uint32_t i = t; i < got; i += 1024) {
         const uint64_t mine = s_key[i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < got; ++j)
-            rank += s_key[j] > mine;
+        const uint32_t rank = lds_rank_desc(s_key, got, mine);
         if (rank < need) {
             pa.list[rank] = 0xFFFFFFFFu - static_cast<uint32_t>(mine & 0xFFFFFFFFull);
             pa.comb[rank] = s_c[i];

@@ -19,6 +19,7 @@
 // The summation order differs from the reference's strict left-to-right order, so these
 // scores only NOMINATE candidates (guard band, select.hip); exact.hip re-scores them.
 #include <algorithm>
+#include <cstring>
 
 #include "common.h"
 #include "kernels.h"
@@ -79,12 +80,19 @@ __device__ inline void hist_flush(const uint32_t *s_hist, uint32_t *g_hist)
 // Fixed-shape kernel: pitch16 == CH * 64 (f32: dim = 256*CH; f16: dim = 512*CH), so a
 // row is exactly CH wave-wide 16-byte loads and the query lives in registers.
 // ---------------------------------------------------------------------------
-template <int CH, int R, bool F16, bool NT>
+// The query as a kernel ARGUMENT (f32 rows, CH <= 3: 3 KB of the 4 KB a launch may carry): see ScanArgs::query_host.
+template <int CH>
+struct QueryArg {
+    float4 v[CH * 64];
+};
+
+template <int CH, int R, bool F16, bool NT, bool KQ = false>
 __global__ __launch_bounds__(256) void scan_fixed_kernel(const float4 *__restrict__ rows,
                                                          const float *__restrict__ query,
                                                          float *__restrict__ scores,
                                                          uint32_t *__restrict__ g_hist,
-                                                         uint32_t n_rows, uint32_t group_rows)
+                                                         uint32_t n_rows, uint32_t group_rows,
+                                                         QueryArg<KQ ? CH : 0> qarg = QueryArg<KQ ? CH : 0>())
 {
     constexpr int P16 = CH * 64;                  // 16-byte units per row
     constexpr int QF4 = F16 ? 2 * P16 : P16;      // float4 units of query
@@ -94,8 +102,18 @@ __global__ __launch_bounds__(256) void scan_fixed_kernel(const float4 *__restric
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform -> scalar row addressing
-    for (int i = tid; i < QF4; i += 256)
-        s_q[i] = reinterpret_cast<const float4 *>(query)[i];
+    if constexpr (KQ) {
+        // from the argument segment; workgroup 0 also leaves it in device memory for the kernels behind the scan
+        for (int i = tid; i < QF4; i += 256) {
+            const float4 v = qarg.v[i];
+            s_q[i] = v;
+            if (blockIdx.x == 0)
+                reinterpret_cast<float4 *>(const_cast<float *>(query))[i] = v;
+        }
+    } else {
+        for (int i = tid; i < QF4; i += 256)
+            s_q[i] = reinterpret_cast<const float4 *>(query)[i];
+    }
     for (int i = tid; i < kHistBins; i += 256)
         s_hist[i] = 0;
     __syncthreads();
@@ -491,9 +509,41 @@ ScanPlan plan_scan(const ScanArgs &a)
     return p;
 }
 
+bool kq_enabled()
+{
+    static const bool on = [] {
+        const char *v = getenv("RLR_SCAN_KQ"); // the query in the kernel arguments (ScanArgs::query_host); "0" turns it off
+        return !(v && v[0] == '0');
+    }();
+    return on;
+}
+
+template <int CH>
+hipError_t launch_fixed_kq(const ScanArgs &a, const ScanPlan &p, hipStream_t s)
+{
+    const float4 *rows = static_cast<const float4 *>(a.rows);
+    QueryArg<CH> q;
+    std::memcpy(q.v, a.query_host, sizeof(q.v));
+#define RLR_SCAN_KQ_CASE(RV)                                                                                  \
+    hipLaunchKernelGGL((scan_fixed_kernel<CH, RV, false, true, true>), dim3(p.blocks), dim3(256), 0, s, rows, \
+                       a.query, a.scores, a.hist, a.n_rows, p.group_rows, q)
+    switch (p.r) {
+    case 1: RLR_SCAN_KQ_CASE(1); break;
+    case 2: RLR_SCAN_KQ_CASE(2); break;
+    case 8: RLR_SCAN_KQ_CASE(8); break;
+    default: RLR_SCAN_KQ_CASE(4); break;
+    }
+#undef RLR_SCAN_KQ_CASE
+    return hipGetLastError();
+}
+
 template <int CH, bool F16>
 hipError_t launch_fixed(const ScanArgs &a, const ScanPlan &p, hipStream_t s)
 {
+    if constexpr (!F16 && CH <= 3) {
+        if (a.query_host && p.nt && kq_enabled())
+            return launch_fixed_kq<CH>(a, p, s);
+    }
     const float4 *rows = static_cast<const float4 *>(a.rows);
 #define RLR_SCAN_CASE(RV, NTV)                                                                    \
     hipLaunchKernelGGL((scan_fixed_kernel<CH, RV, F16, NTV>), dim3(p.blocks), dim3(256), 0, s,   \
@@ -580,6 +630,14 @@ bool launch_packed(const ScanArgs &a, const ScanPlan &p, hipStream_t s, hipError
 }
 
 } // namespace
+
+bool launch_scan_takes_host_query(const ScanArgs &a)
+{
+    int ch = 0;
+    if (!a.query_host || a.n_rows == 0 || a.dtype != RLR_F32 || !fixed_shape(a, &ch) || ch > 3 || !kq_enabled())
+        return false;
+    return plan_scan(a).nt;
+}
 
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
 {

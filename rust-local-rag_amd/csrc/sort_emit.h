@@ -33,9 +33,11 @@ __host__ __device__ inline uint32_t result_chk_term(uint64_t w, uint32_t i)
 }
 
 // `s_chk`: one LDS word, zero on entry, the checksum of out[0, k) on return (valid after the caller's next barrier).
+// `pre`: packed[threadIdx.x] already loaded by the caller (issued before it knew n_raw, to overlap the two round trips), or null.
 template <bool COHERENT = false>
 __device__ inline void sort_emit_rows(const uint64_t *packed, uint32_t n_raw, uint32_t cap, uint64_t *__restrict__ out,
-                                      uint32_t k, bool unordered, uint64_t *s, uint32_t *s_hist, uint32_t *s_chk)
+                                      uint32_t k, bool unordered, uint64_t *s, uint32_t *s_hist, uint32_t *s_chk,
+                                      const uint64_t *pre = nullptr)
 {
     if (n_raw > cap || n_raw > 4096) {
         // band overflow: the host re-runs this query on the large-candidate path.  The all-ones word marks
@@ -50,13 +52,11 @@ __device__ inline void sort_emit_rows(const uint64_t *packed, uint32_t n_raw, ui
         // rank sort: keys are unique (the row number is part of the key), so the number of larger
         // keys is the output position -- one pass, two barriers, instead of a log^2 network.
         if (threadIdx.x < n_raw)
-            s[threadIdx.x] = load_candidate<COHERENT>(packed + threadIdx.x);
+            s[threadIdx.x] = pre ? *pre : load_candidate<COHERENT>(packed + threadIdx.x);
         __syncthreads();
         if (threadIdx.x < n_raw) {
             const uint64_t mine = s[threadIdx.x];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n_raw; ++j)
-                rank += s[j] > mine;
+            const uint32_t rank = lds_rank_desc(s, n_raw, mine);
             if (rank < k) {
                 out[rank] = mine;
                 atomicAdd(s_chk, result_chk_term(mine, rank));
@@ -130,13 +130,13 @@ constexpr uint64_t kMetaPending = 0xFFFFFFFFFFFFFFFEull;
 template <bool COHERENT = false>
 __device__ inline void sort_emit_body(const uint64_t *packed, uint32_t n_raw, uint32_t cap,
                                       uint64_t *__restrict__ out, uint32_t k, uint64_t *__restrict__ meta, bool unordered,
-                                      uint64_t *s, uint32_t *s_hist)
+                                      uint64_t *s, uint32_t *s_hist, const uint64_t *pre = nullptr)
 {
     __shared__ uint32_t s_chk;
     if (threadIdx.x == 0)
         s_chk = 0;
     __syncthreads();
-    sort_emit_rows<COHERENT>(packed, n_raw, cap, out, k, unordered, s, s_hist, &s_chk);
+    sort_emit_rows<COHERENT>(packed, n_raw, cap, out, k, unordered, s, s_hist, &s_chk, pre);
     if (!meta)
         return;
     __threadfence_system();

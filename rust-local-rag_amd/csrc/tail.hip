@@ -191,14 +191,20 @@ __global__ __launch_bounds__(kSelThreads) void tail_stage1_kernel(TailDev a)
 }
 
 // One workgroup, all candidates in place: publish the count, reset the tail's counters for the next query of this
-// context, order and emit.
-__device__ __forceinline__ void tail_finish(const TailDev &a, float *s_mem)
+// context, order and emit.  COHERENT: the candidates and counters were written by other workgroups of THIS launch (REFINE)
+// and are read with agent-scope loads; in DIRECT mode the previous launch wrote them and plain loads do (three dependent
+// write-through round trips less on the way to the sort: ~4 us of an 8 us stage).
+// `pre` / `pre_n` / `pre_fl` (DIRECT only): packed[threadIdx.x], n_work and flags as the caller loaded them on entry, all
+// at once with the mode word -- four dependent memory round trips in a row otherwise.
+template <bool COHERENT>
+__device__ __forceinline__ void tail_finish(const TailDev &a, float *s_mem, const uint64_t *pre = nullptr, uint32_t pre_n = 0,
+                                            uint32_t pre_fl = 0)
 {
     __shared__ uint32_t s_n;
     SelectState *st = a.st;
     if (threadIdx.x == 0) {
-        const uint32_t n = __hip_atomic_load(&st->n_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t fl = __hip_atomic_load(&st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t n = COHERENT ? __hip_atomic_load(&st->n_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pre_n;
+        const uint32_t fl = COHERENT ? __hip_atomic_load(&st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pre_fl;
         const uint32_t n_eff = (fl & 1u) ? max(n, a.cap + 1u) : n; // a local list overflowed: report a band overflow
         st->n_cand = n_eff;
         st->n_work = 0;
@@ -211,12 +217,12 @@ __device__ __forceinline__ void tail_finish(const TailDev &a, float *s_mem)
     if (a.out) {
         uint64_t *s = reinterpret_cast<uint64_t *>(s_mem);
         uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_mem) + 4096 * 2;
-        sort_emit_body<true>(a.packed, n_eff, a.cap, a.out, a.k, a.meta, a.unordered != 0, s, s_hist);
+        sort_emit_body<COHERENT>(a.packed, n_eff, a.cap, a.out, a.k, a.meta, a.unordered != 0, s, s_hist, pre);
     } else {
         if (threadIdx.x == 0 && a.meta)
             *a.meta = n_eff;
         if (a.has_pool) // a diversified search: the MMR pool straight from the candidates, in this launch (pool_prepare.h)
-            pool_prepare_body<true, true>(a.packed, n_eff, a.cap, a.pool, reinterpret_cast<char *>(s_mem));
+            pool_prepare_body<true, COHERENT>(a.packed, n_eff, a.cap, a.pool, reinterpret_cast<char *>(s_mem), pre);
     }
 }
 
@@ -229,12 +235,20 @@ __global__ __launch_bounds__(1024) void tail_stage2_kernel(TailDev a)
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * 1024 + tid;
     SelectState *st = a.st;
+    // workgroup 0 loads everything the DIRECT finish needs in one go (the candidate buffer always holds >= 1024 entries)
+    uint64_t pre = 0;
+    uint32_t pre_n = 0, pre_fl = 0;
+    if (blockIdx.x == 0) {
+        pre = a.packed[tid];
+        pre_n = st->n_work;
+        pre_fl = st->flags;
+    }
     const uint32_t mode = st->mode;
     if (gid < kHistBins)
         a.hist[gid] = 0; // digit 1: stage 1 was its last reader
     if (mode == 1u) {
         if (blockIdx.x == 0)
-            tail_finish(a, s_mem);
+            tail_finish<false>(a, s_mem, &pre, pre_n, pre_fl);
         return;
     }
     if (mode != 2u)
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(1024) void tail_stage2_kernel(TailDev a)
         st->bin2 = bin2;
         st->key_lo = key_lo;
     }
-    tail_finish(a, s_mem);
+    tail_finish<true>(a, s_mem);
 }
 
 bool tail_shape(uint32_t pitch16, uint32_t dim, int dtype, uint32_t *cpb_out, size_t *staging_out)
@@ -350,8 +364,12 @@ hipError_t launch_tail_stage2(const TailArgs &a, hipStream_t s)
     // 1024-thread workgroup per CU is what is resident at this kernel's register count: a second round of workgroups would
     // only start when the first has finished its bin search, pass and re-score.
     // (and, as in stage 1, at least one workgroup per 64 score units: the candidates of a small corpus spread out)
+    // -- when REFINE is certain (more results wanted than DIRECT ever takes); a launch that will most likely find DIRECT
+    // mode, where only workgroup 0 works, stays small: 230 idle 1024-thread workgroups cost ~2 us to dispatch and retire.
     const uint32_t n4 = a.n / 4 + 1;
-    uint32_t blocks = std::max((n4 + 1023) / 1024, (n4 + 63) / 64);
+    uint32_t blocks = (n4 + 1023) / 1024;
+    if (a.k > a.direct_max)
+        blocks = std::max(blocks, (n4 + 63) / 64);
     blocks = std::max<uint32_t>(2, std::min<uint32_t>(blocks, static_cast<uint32_t>(a.n_cu)));
     if (a.dtype == RLR_F16)
         hipLaunchKernelGGL(tail_stage2_kernel<true>, dim3(blocks), dim3(1024), lds, s, d);
