@@ -1125,7 +1125,7 @@ struct MergeBases {
 };
 
 
-__global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restrict__ gathered, uint32_t world,
+__global__ __launch_bounds__(1024) void merge_topk_kernel(const uint64_t *__restrict__ gathered, uint32_t world,
                                                          uint32_t n_queries, uint32_t k, MergeBases bases,
                                                          uint64_t *__restrict__ rows_out, float *__restrict__ cos_out,
                                                          uint32_t *__restrict__ n_out, uint64_t *__restrict__ flag_out)
@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
     }
     __syncthreads();
     uint32_t valid = 0;
-    for (uint32_t i = threadIdx.x; i < n_pad; i += 256) {
+    for (uint32_t i = threadIdx.x; i < n_pad; i += 1024) {
         uint64_t v = 0;
         if (i < n) {
             const uint32_t r = i / k, j = i - r * k;
@@ -1164,26 +1164,68 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
     }
     atomicAdd(&s_valid, valid);
     __syncthreads();
-    if (n_pad <= 1024) {
-        // rank sort: the keys are unique (global row in the low word); padding zeros keep their place
-        __shared__ uint64_t s_sorted[1024];
-        for (uint32_t i = threadIdx.x; i < n_pad; i += 256) {
+    // Every partial list arrives sorted (score desc, row asc; zeros behind) -- that is how sort_emit leaves it -- so an entry's
+    // place in the merged order is its index in its own list plus, for every other list, the number of entries there that
+    // are greater: world - 1 binary searches of log2(k) steps instead of a sort (a rank sort of the 800 keys of a world-8
+    // merge walked ~45 us, a bitonic network of 1024 took ~25 us; this takes ~2).  Keys are unique (the global row is in
+    // the low word).  Lists that are NOT sorted (a caller's own data) take the network below.
+    __shared__ uint32_t s_unsorted;
+    if (threadIdx.x == 0)
+        s_unsorted = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i + 1 < n; i += 1024)
+        if ((i + 1) % k != 0 && s[i] < s[i + 1])
+            s_unsorted = 1u;
+    __syncthreads();
+    if (!s_unsorted) {
+        const uint32_t m_out = min(s_valid, k);
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
             const uint64_t mine = s[i];
-            uint32_t rank = lds_rank_desc(s, n_pad, mine);
-            if (mine == 0) { // the padding zeros tie among themselves: they keep their order
-                for (uint32_t j = 0; j < i; ++j)
-                    rank += s[j] == 0;
+            if (mine == 0)
+                continue;
+            const uint32_t r = i / k;
+            uint32_t rank = i - r * k;
+            for (uint32_t o = 0; o < world && rank < k; ++o) {
+                if (o == r)
+                    continue;
+                const uint64_t *lst = s + o * k;
+                uint32_t lo = 0, hi = k; // first position whose entry is not greater than `mine`
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (lst[mid] > mine)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                rank += lo;
             }
-            s_sorted[rank] = mine;
+            if (rank < m_out) {
+                const uint64_t row = 0xFFFFFFFFull - (mine & 0xFFFFFFFFull);
+                const float cs = key_score(static_cast<uint32_t>(mine >> 32));
+                rows_out[static_cast<size_t>(q) * k + rank] = row;
+                cos_out[static_cast<size_t>(q) * k + rank] = cs;
+                atomicAdd(&s_chk, result_chk_term(row, rank) + result_chk_term(__builtin_bit_cast(uint32_t, cs), rank + k));
+            }
         }
+        for (uint32_t i = m_out + threadIdx.x; i < k; i += 1024) { // (the padding behind fewer than k results)
+            const float cs = key_score(0u);
+            rows_out[static_cast<size_t>(q) * k + i] = ~0ull;
+            cos_out[static_cast<size_t>(q) * k + i] = cs;
+            atomicAdd(&s_chk, result_chk_term(~0ull, i) + result_chk_term(__builtin_bit_cast(uint32_t, cs), i + k));
+        }
+        __threadfence_system();
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n_pad; i += 256)
-            s[i] = s_sorted[i];
-        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t cnt = s_valid_overflow ? 0xFFFFFFFFu : m_out;
+            n_out[q] = cnt;
+            if (flag_out)
+                flag_out[q] = (static_cast<uint64_t>(s_chk) << 32) | cnt;
+        }
+        return;
     } else
     for (uint32_t kk = 2; kk <= n_pad; kk <<= 1) {
         for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < n_pad; i += 256) {
+            for (uint32_t i = threadIdx.x; i < n_pad; i += 1024) {
                 const uint32_t ixj = i ^ j;
                 if (ixj > i) {
                     const uint64_t a = s[i], b = s[ixj];
@@ -1198,7 +1240,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t *__restr
         }
     }
     const uint32_t m = min(s_valid, k);
-    for (uint32_t i = threadIdx.x; i < k; i += 256) {
+    for (uint32_t i = threadIdx.x; i < k; i += 1024) {
         const uint64_t v = i < m ? s[i] : 0ull;
         const uint64_t row = i < m ? 0xFFFFFFFFull - (v & 0xFFFFFFFFull) : ~0ull;
         const float cs = key_score(static_cast<uint32_t>(v >> 32));
@@ -2751,7 +2793,7 @@ int32_t rlr_merge_topk(int32_t device_id, const void *d_gathered, uint32_t world
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (uint32_t q = 0; q < n_queries; ++q)
         h_flag[q] = kMetaPending;
-    hipLaunchKernelGGL(rlr::merge_topk_kernel, dim3(n_queries), dim3(256), 0, s, static_cast<const uint64_t *>(d_gathered),
+    hipLaunchKernelGGL(rlr::merge_topk_kernel, dim3(n_queries), dim3(1024), 0, s, static_cast<const uint64_t *>(d_gathered),
                        world, n_queries, k, mb, h_rows, h_cos, h_n, h_flag);
     RLR_HIP(hipGetLastError());
     // (this wait usually spans the scans queued in front of the merge on the same stream)
