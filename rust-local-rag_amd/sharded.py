@@ -142,17 +142,19 @@ class ShardedIndex:
             self._rows_h = np.zeros((nq, k), dtype=np.uint64)
             self._cos_h = np.zeros((nq, k), dtype=np.float32)
             self._n_h = np.zeros(nq, dtype=np.uint32)
+            self._local_ptr = self._local.data_ptr()   # (torch's accessors cost ~1 us a call: looked up once per buffer)
+            self._gath_ptr = self._gath.data_ptr()
         # torch's current stream carries the collective; without one (world 1) the library's calls only need A stream
         if self.world > 1 or self.dist is not None or self._stream0 is None:
             stream = self._stream0 = torch.cuda.current_stream(self.dev).cuda_stream
         else:
             stream = self._stream0
         if _redo:
-            self.index.search_topk_device(q, k, self._local.data_ptr(), stream)   # synchronous, handles overflow
+            self.index.search_topk_device(q, k, self._local_ptr, stream)   # synchronous, handles overflow
             ticket = None
         else:
             # the collective and the merge are queued behind the scan: no host round trip in between
-            ticket = self.index.search_topk_device_begin(q, k, self._local.data_ptr(), stream)
+            ticket = self.index.search_topk_device_begin(q, k, self._local_ptr, stream)
         rows_h, cos_h, n_h = self._rows_h, self._cos_h, self._n_h
         try:
             if self._time_exchange:
@@ -160,15 +162,15 @@ class ShardedIndex:
             if self.world > 1 or (self.dist is not None and os.environ.get("RLR_BENCH_FORCE_DIST") == "1"):
                 # the exchange step: world x k x 8 B per query over xGMI (RCCL all-gather)
                 self.dist.all_gather_into_tensor(self._gath.view(self.world * nq, k), self._local, group=self.group)
-                gathered = self._gath
+                gathered_ptr = self._gath_ptr
             else:
-                gathered = self._local
+                gathered_ptr = self._local_ptr
             # merge on the GPU in one launch (rlr_merge_topk), results land in pinned host memory
             ma = self._merge_args
             if ma is None or ma[0] is not rows_h:   # (ctypes views of the persistent buffers: ~1 us each to build)
                 ma = self._merge_args = (rows_h, self._bases_h.ctypes.data_as(N.u64p), rows_h.ctypes.data_as(N.u64p),
                                          cos_h.ctypes.data_as(N.f32p), n_h.ctypes.data_as(N.u32p), N.lib().rlr_merge_topk)
-            N.check(ma[5](self.dev.index, C.c_void_p(gathered.data_ptr()), self.world, nq, k, ma[1], ma[2], ma[3], ma[4],
+            N.check(ma[5](self.dev.index, C.c_void_p(gathered_ptr), self.world, nq, k, ma[1], ma[2], ma[3], ma[4],
                           C.c_void_p(stream)))
             if self._time_exchange:
                 self._ev[1].record()
@@ -184,7 +186,7 @@ class ShardedIndex:
         # A shard whose guard band overflowed (massive exact ties) marks its slot; the marker travels through the
         # all-gather, so every rank sees it in the merged counts and takes the same branch: redo the step on
         # the synchronous path, which handles the overflow.
-        if not _redo and nq and (n_h[:nq] == 0xFFFFFFFF).any():
+        if not _redo and nq and (int(n_h[0]) == 0xFFFFFFFF if nq == 1 else bool((n_h[:nq] == 0xFFFFFFFF).any())):
             return self.search_topk(queries, k, _redo=True)
         n_valid = int(n_h[0]) if nq else 0
         return rows_h[:, :n_valid].astype(np.int64), cos_h[:, :n_valid].copy()
