@@ -168,7 +168,10 @@ struct rlr_index {
     int scan_variant = 0;
     int fused_tail = -1;         // select -> re-score -> sort behind the scan in two launches (tail.hip): RLR_TAIL=1 always, 0 never
                                  // (the five-launch form), unset: while the corpus is small enough for the one-pass mode to be the rule
-    uint32_t tail_direct_max = 1024; // RLR_TAIL_DIRECT_MAX: most scores in/above the k-th score's digit-1 bin for the one-pass mode (0: always refine)
+    uint32_t tail_direct_max = 3584; // RLR_TAIL_DIRECT_MAX: most scores in/above the k-th score's digit-1 bin for the one-pass mode (0: always
+                                     // refine).  Re-scoring a few thousand candidates costs less than the two extra passes of the refine
+                                     // mode (they spread over the workgroups that found them); 512 slots of the 4096 stay for the guard band.
+                                     // A call that builds an MMR pool from the candidates caps it at 1024 (what the pool kernel takes).
     uint32_t batch_min = 0;   // smallest batch that takes the matrix-core path; 0 = decide by the cost model,
                               // RLR_BATCH_MIN=n forces a threshold (a huge n disables the path)
     float max_row_sumsq = 1.0f; // largest sum of squares of a row stored with normalize_on_device = 0 (>= 1): the guard
@@ -1750,9 +1753,9 @@ hipError_t enqueue_query_rest(rlr_index *ix, Ctx *c, uint32_t qi, const SearchPl
         ta.out = emit ? d_out_q : nullptr;
         ta.meta = d_meta_q;
         ta.unordered = p.unordered;
-        ta.direct_max = ix->tail_direct_max;
-        ta.n_cu = ix->n_cu;
         ta.pool = emit ? nullptr : pool;
+        ta.direct_max = ta.pool ? std::min<uint32_t>(ix->tail_direct_max, 1024u) : ix->tail_direct_max;
+        ta.n_cu = ix->n_cu;
         if (pool_done)
             *pool_done = ta.pool != nullptr;
         if ((e = launch_tail_stage1(ta, s)) != hipSuccess) return e;

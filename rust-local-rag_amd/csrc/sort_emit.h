@@ -89,6 +89,34 @@ __device__ inline void sort_emit_rows(const uint64_t *packed, uint32_t n_raw, ui
             out[i] = 0ull;
         return;
     }
+    if (k <= 1024) {
+        // more than 1024 candidates, at most 1024 wanted, in order: select the k-th key by radix passes over LDS, move the k
+        // winners (keys are unique: exactly k of them are >= it) into the histogram's space and rank-sort those -- instead
+        // of a bitonic network over all of them (4096 entries: 78 barrier-separated stages)
+        __shared__ uint32_t s_pick2[3];
+        __shared__ uint32_t s_n2;
+        for (uint32_t i = threadIdx.x; i < n_raw; i += 1024)
+            s[i] = load_candidate<COHERENT>(packed + i);
+        if (threadIdx.x == 0)
+            s_n2 = 0;
+        __syncthreads();
+        const uint64_t kth = lds_kth_key64(s, n_raw, k, s_hist, s_pick2, 1024);
+        uint64_t *win = reinterpret_cast<uint64_t *>(s_hist); // 2048 u32 = 1024 u64; the select is done with it
+        for (uint32_t i = threadIdx.x; i < n_raw; i += 1024) {
+            const uint64_t v = s[i];
+            if (v >= kth)
+                win[atomicAdd(&s_n2, 1u)] = v;
+        }
+        __syncthreads();
+        const uint32_t m = s_n2; // == k
+        if (threadIdx.x < m) {
+            const uint64_t mine = win[threadIdx.x];
+            const uint32_t rank = lds_rank_desc(win, m, mine);
+            out[rank] = mine;
+            atomicAdd(s_chk, result_chk_term(mine, rank));
+        }
+        return;
+    }
     uint32_t n_pad = 1;
     while (n_pad < n_raw)
         n_pad <<= 1;

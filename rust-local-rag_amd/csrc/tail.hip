@@ -364,11 +364,13 @@ hipError_t launch_tail_stage2(const TailArgs &a, hipStream_t s)
     // 1024-thread workgroup per CU is what is resident at this kernel's register count: a second round of workgroups would
     // only start when the first has finished its bin search, pass and re-score.
     // (and, as in stage 1, at least one workgroup per 64 score units: the candidates of a small corpus spread out)
-    // -- when REFINE is certain (more results wanted than DIRECT ever takes); a launch that will most likely find DIRECT
-    // mode, where only workgroup 0 works, stays small: 230 idle 1024-thread workgroups cost ~2 us to dispatch and retire.
+    // -- when many results are wanted: REFINE mode leaves at least k candidates to re-score, eight at a time per workgroup,
+    // so a small grid is only safe for a small k (25 workgroups x 80 candidates each: 82 us at k = 1808).  A launch for a
+    // few hundred results most likely finds DIRECT mode, where only workgroup 0 works, and stays small: 230 idle
+    // 1024-thread workgroups cost ~2 us to dispatch and retire.
     const uint32_t n4 = a.n / 4 + 1;
     uint32_t blocks = (n4 + 1023) / 1024;
-    if (a.k > a.direct_max)
+    if (a.k > 256 || a.k > a.direct_max)
         blocks = std::max(blocks, (n4 + 63) / 64);
     blocks = std::max<uint32_t>(2, std::min<uint32_t>(blocks, static_cast<uint32_t>(a.n_cu)));
     if (a.dtype == RLR_F16)
