@@ -23,6 +23,11 @@
  *     delete, fill, reserve, enable_batch_image, destroy) need external exclusion.
  *   - there is NO CPU fallback inside the library: with no usable GPU every
  *     compute entry point returns RLR_E_NO_DEVICE.
+ *   - every entry point returns when its results are in the caller's buffers.
+ *     How it waits for the device is the library's business (RLR_WAIT, see
+ *     INTEGRATION.md section 6): by default it polls a completion word the last
+ *     kernel stores behind its results in pinned host memory, and verifies a
+ *     checksum over them, instead of waiting for the stream's completion signal.
  */
 #ifndef RLR_GPU_H
 #define RLR_GPU_H
@@ -34,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RLR_VERSION 120 /* 0.1.20: + lexical, sharded begin/end + MMR exchange, nomination copies, shared small-batch scan */
+#define RLR_VERSION 121 /* 0.1.21: + bandwidth probe, n_batches_without_image, n_mmr_host_bounces (both structs grew at the end) */
 
 typedef struct rlr_index rlr_index;
 
@@ -340,8 +345,10 @@ typedef struct rlr_profile {
     uint64_t n_searches;   /* rlr_search_topk* calls (queries, not batches) since reset */
     uint64_t n_scan_launches;
     double scan_ms;        /* sum of HIP-event durations of the scan kernel, on its stream */
-    double select_ms;      /* histogram / threshold / collect kernels */
-    double rescore_ms;     /* reference-order re-score + final sort */
+    double select_ms;      /* tail stage 1: bin search + collect + reference-order re-score of what it finds (or the
+                            * digit-2 histogram of a crowded bin); in the split form: histogram / threshold / collect */
+    double rescore_ms;     /* tail stage 2: final sort + emit (after a digit-2 histogram: collect + re-score + sort); in
+                            * the split form: reference-order re-score + final sort */
     double total_ms;       /* first launch -> results ready, per call, summed */
     uint64_t scan_bytes;   /* algorithmic bytes the scan launches covered (rows*dim*elem) */
     uint64_t n_candidates; /* rows nominated by the guard band, summed */

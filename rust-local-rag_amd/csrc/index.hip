@@ -1,6 +1,8 @@
 // index.hip -- the C ABI of include/rlr_gpu.h: device-resident chunk-embedding matrix,
-// per-call search contexts (stream + workspace), and the kernel pipeline
-//   scan (+hist1) -> find1 -> hist2 -> find2 -> collect -> rescore -> sort -> D2H
+// per-call search contexts (stream + workspace), and the kernel pipeline of a single query
+//   scan (+digit-1 histogram) -> tail stage 1 -> tail stage 2 (tail.hip: select, reference-order re-score, sort, results
+//   and a completion word straight into pinned host memory), or above 4 M rows the four specialised launches
+//   hist2_find1 -> collect_find2 -> rescore_staged -> sort_emit; batches of queries go through the matrix cores (gemm.hip).
 // There is no CPU compute path in this file: without a HIP device every compute entry
 // point fails with RLR_E_NO_DEVICE.
 #include "../../include/rlr_gpu.h"
@@ -1664,12 +1666,12 @@ int32_t check_hist_assert(Ctx *c)
 }
 
 // Enqueue the whole pipeline for query `qi` on the context's stream:
-//   scan (+digit-1 histogram) -> digit-2 histogram (bin search folded in) -> collect (bin search
-//   folded in) -> LDS-staged reference-order re-score (clears the histograms for the next query)
-//   -> sort + emit (+ candidate count into *d_meta_q).
-// The context's histograms are zero on entry (cleared at creation and by every re-score).
+//   scan (+digit-1 histogram) -> the tail in two launches (tail.hip), or in its split form: digit-2 histogram (bin search
+//   folded in) -> collect (bin search folded in) -> LDS-staged reference-order re-score -> sort + emit; either way the
+//   candidate count (| checksum) goes into *d_meta_q last.
+// The context's histograms are zero on entry: cleared at creation and by every pipeline (tail stage 2 / the re-score kernel).
 // (in two halves, so that a caller with work for ANOTHER stream -- the BM25 kernels of a text search -- can launch it right
-// behind the scan instead of behind all five launches: enqueue_query_scan, then enqueue_query_rest)
+// behind the scan instead of behind every launch of the pipeline: enqueue_query_scan, then enqueue_query_rest)
 hipError_t enqueue_query_scan(rlr_index *ix, Ctx *c, uint32_t qi, bool timed)
 {
     hipStream_t s = c->stream;

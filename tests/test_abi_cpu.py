@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(rlr):
 
 
 def test_version_and_guard_eps(rlr):
-    assert rlr.lib().rlr_version() == 120
+    assert rlr.lib().rlr_version() == 121
     e768, e1024 = rlr.default_guard_eps(768), rlr.default_guard_eps(1024)
     # rigorous bound: (dim + depth) * 2^-24, i.e. ~5e-5 at 768-d (hard part 1)
     assert 768 * 2.0 ** -24 < e768 < 6e-5 and e768 < e1024 < 8e-5
