@@ -349,10 +349,10 @@ int32_t rlr_engine_search_text(rlr_index *idx, rlr_lexical *lex, const float *qu
         st = rlr::search_hybrid_begin(
             idx, q.data(), nd, top_k, diversity_factor, diversify ? 1 : 0, w.embedding, w.lexical,
             std::min<uint32_t>(limit, RLR_LEXICAL_MAX_LIMIT), -1.0f, &ticket, &fb,
-            [](void *a) -> int32_t {
+            [](void *a, const rlr::LexSink *sink) -> int32_t {
                 BesideScan *b = static_cast<BesideScan *>(a);
                 const int32_t e = rlr::lexical_enqueue(b->lex, b->tokens, b->len, b->limit, &b->lp, /*need_sorted=*/false,
-                                                       /*exact_passes=*/false);
+                                                       /*exact_passes=*/false, sink);
                 b->queued = e == RLR_OK;
                 return e;
             },

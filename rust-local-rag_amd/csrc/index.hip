@@ -174,6 +174,14 @@ struct rlr_index {
                                      // refine).  Re-scoring a few thousand candidates costs less than the two extra passes of the refine
                                      // mode (they spread over the workgroups that found them); 512 slots of the 4096 stay for the guard band.
                                      // A call that builds an MMR pool from the candidates caps it at 1024 (what the pool kernel takes).
+    // Hybrid (text) searches: how many rows by cosine the blend asks the tail for beyond the `need` it keeps.  A lexical term
+    // only ever ADDS to a row's blended score (weights and BM25 scores are non-negative as a rule), so the need + 8 best
+    // cosines already hold every non-lexical row that can reach the pool, whatever the lexical rows among them do; the
+    // blend kernel checks that on what it got -- its need-th blended score must beat anything an unfetched row can reach,
+    // status 2 and the host's widening path else (a negative lexical weight, a tie across the boundary).  Rounds 2-3
+    // fetched need + n_lexical + 8 (every lexical row counted as if it displaced one): 1808 rows instead of 332 for a
+    // top-100 text search, a crowded digit-1 bin and ~25 us more tail.  RLR_HYBRID_FETCH=full at creation restores that.
+    bool hybrid_fetch_full = false;
     uint32_t batch_min = 0;   // smallest batch that takes the matrix-core path; 0 = decide by the cost model,
                               // RLR_BATCH_MIN=n forces a threshold (a huge n disables the path)
     float max_row_sumsq = 1.0f; // largest sum of squares of a row stored with normalize_on_device = 0 (>= 1): the guard
@@ -1344,6 +1352,7 @@ __global__ __launch_bounds__(1024) void pool_prepare_kernel(const uint64_t *__re
 // every unfetched row is non-lexical and scores at most combine(cos of the last fetched row, 0); if the need-th
 // candidate does not beat that, info[1] = 2 and the host takes the widening path.
 constexpr uint32_t kHybridSlots = 4096, kHybridLexMax = 2048, kHybridSelMax = 2048, kHybridHash = 4096;
+constexpr uint32_t kHybridFetchMargin = 32; // rows by cosine fetched beyond `need` (rlr_index::hybrid_fetch_full): room for ties
 
 // What the blend needs to know about the lexical pairs, in device memory: written by the host copy (pairs handed in by
 // the caller) or by lex_unpack_kernel (pairs left on the device by a BM25 scoring call).
@@ -1502,13 +1511,16 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
     }
     __syncthreads();
     const uint32_t got = s_got, n_cand = got + s_cand, n_pool = min(n_cand, need);
-    // the need-th largest 32-bit score, then everything at or above it (ties included) is ranked by the full key
-    uint32_t key_lo = 0;
+    // a lower edge that between need and need + 32 of the full keys reach (the passes of the radix select stop as soon as a
+    // bin decides that much), then those are ranked.  [It was the need-th largest 32-bit SCORE in three fixed passes and
+    // everything at or above it: a score shared by thousands of candidates flooded the rank sort and sent the query to the
+    // host path -- the row half of the key splits such a class here.]
+    uint64_t key_lo = 0;
     if (n_cand > need)
-        key_lo = lds_kth_key(s_key, total, need, s_hist, s_pick, 1024);
+        key_lo = lds_kth_key64(s_key, total, need, s_hist, s_pick, 1024, /*slack=*/32);
     for (uint32_t i = t; i < total; i += 1024) {
         const uint64_t v = s_key[i];
-        if (v != 0 && static_cast<uint32_t>(v >> 32) >= key_lo) {
+        if (v != 0 && v >= key_lo) {
             const uint32_t at = atomicAdd(&s_nsel, 1u);
             if (at < kHybridSelMax) {
                 s_sel[at] = v;
@@ -1518,7 +1530,7 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
     }
     __syncthreads();
     const uint32_t n_sel = s_nsel;
-    const bool flood = n_sel > kHybridSelMax; // thousands of candidates share the need-th score: the host path sorts them
+    const bool flood = n_sel > kHybridSelMax; // (cannot happen with the select above; kept as the guard of s_sel's capacity)
     if (!flood)
         for (uint32_t i = t; i < n_sel; i += 1024) {
             const uint64_t mine = s_sel[i];
@@ -2354,6 +2366,8 @@ int32_t rlr_index_create(uint32_t dim, int32_t dtype, int32_t device_id, rlr_ind
         ix->fused_tail = v[0] != '0' ? 1 : 0;
     if (const char *v = getenv("RLR_TAIL_DIRECT_MAX"))
         ix->tail_direct_max = static_cast<uint32_t>(std::min<unsigned long>(strtoul(v, nullptr, 0), 4096));
+    if (const char *v = getenv("RLR_HYBRID_FETCH"))
+        ix->hybrid_fetch_full = !strcmp(v, "full");
     if (const char *v = getenv("RLR_BATCH_MIN"))
         ix->batch_min = static_cast<uint32_t>(strtoul(v, nullptr, 0));
     if (const char *v = getenv("RLR_MAX_CONTEXTS"))
@@ -3117,7 +3131,8 @@ struct HybridTicket {
 
 static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t need_in, uint32_t k, float lambda, int32_t diversify,
                                  float w_embedding, float w_lexical, uint32_t n_lex_bound, float guard_eps, HybridTicket **out,
-                                 int32_t *fallback, int32_t (*behind_scan)(void *) = nullptr, void *behind_scan_arg = nullptr)
+                                 int32_t *fallback, int32_t (*behind_scan)(void *, const LexSink *) = nullptr,
+                                 void *behind_scan_arg = nullptr)
 {
     *out = nullptr;
     *fallback = 0;
@@ -3126,8 +3141,9 @@ static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t nee
         return fail(RLR_E_INVALID, "null argument");
     const uint32_t n = static_cast<uint32_t>(ix->n_rows);
     const uint32_t need = std::min<uint32_t>(n, need_in);
-    const uint64_t fetch64 = std::min<uint64_t>(n, static_cast<uint64_t>(need) + n_lex_bound + 8);
-    if (n == 0 || need == 0 || need > kPoolMax || n_lex_bound > kHybridLexMax || fetch64 + n_lex_bound > kHybridSlots ||
+    const uint64_t fetch_full = std::min<uint64_t>(n, static_cast<uint64_t>(need) + n_lex_bound + 8);
+    const uint64_t fetch64 = ix->hybrid_fetch_full ? fetch_full : std::min<uint64_t>(fetch_full, static_cast<uint64_t>(need) + kHybridFetchMargin);
+    if (n == 0 || need == 0 || need > kPoolMax || n_lex_bound > kHybridLexMax || fetch_full + n_lex_bound > kHybridSlots ||
         !(w_embedding > 0.0f) || !std::isfinite(w_embedding) || !std::isfinite(w_lexical)) {
         *fallback = 1; // outside what the fused kernels cover: the caller's host path handles it
         return RLR_OK;
@@ -3194,8 +3210,17 @@ static int32_t hybrid_begin_impl(rlr_index *ix, const float *query, uint32_t nee
     // select + re-score + sort, so it must not wait for the host to have launched those -- it used to start 39 us behind the
     // scan and was the critical path by as much); then the four launches that wait for the scan anyway
     RLR_HIP(enqueue_query_scan(ix, c, 0, t->timed));
-    if (behind_scan)
-        RLR_TRY(behind_scan(behind_scan_arg));
+    if (behind_scan) {
+        // (the lexical side of the workspace as hybrid_finish_impl lays it out for pairs that stay on the device)
+        uint32_t *d_nsel = reinterpret_cast<uint32_t *>(c->d_pool + static_cast<uint64_t>(P) * P + 5ull * P);
+        LexSink sink;
+        sink.d_header = d_nsel + 8;
+        sink.d_rows = d_nsel + 10;
+        sink.d_scores = reinterpret_cast<float *>(sink.d_rows + n_lex_bound);
+        sink.n_bound = n_lex_bound;
+        sink.n_index_rows = n;
+        RLR_TRY(behind_scan(behind_scan_arg, &sink));
+    }
     RLR_HIP(enqueue_query_rest(ix, c, 0, p, c->d_out, d_meta, t->timed));
     if (t->timed) RLR_HIP(hipEventRecord(c->bev[0], s));
     drain.armed = false;
@@ -3245,9 +3270,11 @@ static int32_t hybrid_finish_impl(HybridTicket *ticket, const HybridLexSrc &src,
     h_out[4 * k_cap + 3] = kBlockPending; // (the last kernel's last store replaces it: what the wait below polls)
     if (src.dev) { // the BM25 kernels ran beside the scan on their own stream: join, then unpack their result
         RLR_HIP(hipStreamWaitEvent(s, static_cast<hipEvent_t>(src.dev->ready), 0));
-        hipLaunchKernelGGL(lex_unpack_kernel, dim3(1), dim3(1024), 0, s, src.dev->d_packed, src.dev->d_count,
-                           std::min(n_lex, src.dev->limit), n, d_lrow, d_lscore, d_hdr);
-        RLR_HIP(hipGetLastError());
+        if (!src.dev->unpacked) { // (begin's LexSink: the scoring stream has done it in front of `ready`)
+            hipLaunchKernelGGL(lex_unpack_kernel, dim3(1), dim3(1024), 0, s, src.dev->d_packed, src.dev->d_count,
+                               std::min(n_lex, src.dev->limit), n, d_lrow, d_lscore, d_hdr);
+            RLR_HIP(hipGetLastError());
+        }
     } else {
         for (uint32_t i = 0; i < n_lex; ++i)
             if (src.h_rows[i] >= n || (i && src.h_rows[i] <= src.h_rows[i - 1]))
@@ -3325,9 +3352,15 @@ static int32_t hybrid_finish_impl(HybridTicket *ticket, const HybridLexSrc &src,
     return RLR_OK;
 }
 
+void launch_lex_unpack(const uint64_t *d_packed, const uint32_t *d_count, uint32_t limit, const LexSink &sink, void *stream)
+{
+    hipLaunchKernelGGL(lex_unpack_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), d_packed, d_count, limit,
+                       sink.n_index_rows, sink.d_rows, sink.d_scores, static_cast<HybridLexHeader *>(sink.d_header));
+}
+
 int32_t search_hybrid_begin(rlr_index *ix, const float *query, uint32_t need, uint32_t k, float lambda, int32_t diversify,
                             float w_embedding, float w_lexical, uint32_t n_lex_bound, float guard_eps, HybridTicket **ticket,
-                            int32_t *fallback, int32_t (*behind_scan)(void *), void *behind_scan_arg)
+                            int32_t *fallback, int32_t (*behind_scan)(void *, const LexSink *), void *behind_scan_arg)
 {
     return hybrid_begin_impl(ix, query, need, k, lambda, diversify, w_embedding, w_lexical, n_lex_bound, guard_eps, ticket,
                              fallback, behind_scan, behind_scan_arg);

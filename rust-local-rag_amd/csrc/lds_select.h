@@ -122,37 +122,59 @@ __device__ inline uint32_t lds_kth_key(const uint64_t *s_c, uint32_t n, uint32_t
     return prefix;
 }
 
-// k-th largest full 64-bit key of s_c[0, n) (keys are unique where the caller needs exactly k winners): six radix
-// passes over LDS (11-bit digits, laid out as described inside), same structure as lds_kth_key.  All threads must call it.
+// k-th largest full 64-bit key of s_c[0, n) (keys are unique where the caller needs exactly k winners): radix passes over
+// LDS with 11-bit digits, same structure as lds_kth_key.  All threads must call it (n >= 1).
 //
 // `slack`: the passes stop as soon as the bin holding the k-th key has at most `slack` keys ranked BELOW it (bin
 // population - rank inside the bin <= slack); the bin's lower edge is returned then, so between k and k + slack keys are
 // >= the result.  slack = 0 still yields exactly k keys (it stops when the whole bin belongs to the top k -- with unique
-// keys usually after three of the six passes); a threshold that may admit a few more uses a larger slack.
+// keys usually after two or three passes); a threshold that may admit a few more uses a larger slack.
+//
+// Only bits that DIFFER between keys get a pass: one AND / OR reduction over the keys in front of the first pass finds the
+// bits every key shares (the sign and most of the exponent of scores from a narrow range; the ones above the highest row
+// number in the inverted row word), and every digit starts at the highest varying bit that is still undecided.  With the
+// digits on a fixed grid from bit 63 the first pass of a BM25 selection put 8192 keys into a dozen bins -- thousands of
+// LDS atomics on one address, and a pass that decided almost nothing.  (`row_bits` told the fixed grid where the row
+// word's constant ones end; the reduction finds that by itself and the argument is ignored.)
 __device__ inline uint64_t lds_kth_key64(const uint64_t *s_c, uint32_t n, uint32_t k, uint32_t *s_hist, uint32_t *s_sel,
                                          uint32_t nthreads, uint32_t slack = 0, uint32_t row_bits = 32)
 {
-    // `row_bits`: the low word is 0xFFFFFFFF - row with row < 2^row_bits, so its bits [31, row_bits) are ones in EVERY key: they
-    // belong to the result but need no pass.  The digits are laid out over the 32 score bits (11 + 11 + 10) and then over
-    // the row_bits significant row bits from the top (11 at a time) -- with BM25's massive score ties the select runs deep
-    // into the row bits, and at 100 k rows the fixed 11-bit grid spent a whole pass on constant bits.
-    const uint64_t const_ones = row_bits >= 32 ? 0ull : ((0xFFFFFFFFull >> row_bits) << row_bits);
-    uint64_t prefix = const_ones, mask = const_ones;
+    (void)row_bits;
+    uint64_t all_and = ~0ull, all_or = 0ull;
+    for (uint32_t i = threadIdx.x; i < n; i += nthreads) {
+        const uint64_t key = s_c[i];
+        all_and &= key;
+        all_or |= key;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        all_and &= __shfl_xor(all_and, off);
+        all_or |= __shfl_xor(all_or, off);
+    }
+    uint64_t *s_red = reinterpret_cast<uint64_t *>(s_hist); // (the histogram is cleared in front of every pass)
+    const uint32_t n_waves = nthreads / 64, wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_red[2 * wave] = all_and;
+        s_red[2 * wave + 1] = all_or;
+    }
+    __syncthreads();
+    for (uint32_t w = 0; w < n_waves; ++w) {
+        all_and &= s_red[2 * w];
+        all_or |= s_red[2 * w + 1];
+    }
+    __syncthreads();
+    const uint64_t diff = all_and ^ all_or; // the bits that are not the same in every key
+    uint64_t prefix = all_and & ~diff, mask = ~diff;
     uint32_t rank = k;
-    uint32_t next_hi = 64; // the digit of this pass covers bits [next_hi - bits, next_hi)
+    uint32_t next_hi = 64; // bits [next_hi, 64) are decided
 #pragma unroll 1
-    for (int pass = 0; pass < 7; ++pass) {
-        uint32_t bits;
-        if (next_hi > 32) {
-            bits = next_hi == 42 ? 10u : 11u; // 64..53, 53..42, 42..32
-        } else {
-            if (next_hi == 32)
-                next_hi = row_bits < 32 ? row_bits : 32;
-            if (next_hi == 0)
-                break;
-            bits = next_hi < 11 ? next_hi : 11u;
-        }
-        const uint32_t shift = next_hi - bits, nb = 1u << bits;
+    for (int pass = 0; pass < 8; ++pass) {
+        const uint64_t open = next_hi >= 64 ? diff : diff & ((1ull << next_hi) - 1ull);
+        if (open == 0)
+            break; // the keys still in the race agree in every remaining bit
+        const uint32_t top = 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(open))); // one past the highest open bit
+        const uint32_t bits = top < 11u ? top : 11u;
+        const uint32_t shift = top - bits, nb = 1u << bits;
         for (uint32_t i = threadIdx.x; i < (nthreads == 1024 ? 2048u : nb); i += nthreads)
             s_hist[i] = 0;
         __syncthreads();

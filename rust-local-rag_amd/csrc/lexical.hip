@@ -6,11 +6,12 @@
 // and uploaded lazily by the first score call after a mutation.
 // Device side, per query (the call's own workspace and stream out of a small pool, so calls on different host threads
 // overlap; no host round trip until the results are read):
-//   bm25_term_kernel   one launch per unique query term, in query order: every posting adds its
-//                      BM25 contribution to a dense per-row accumulator (one writer per row per
-//                      launch, so the f32 sum order is the term order -- deterministic); rows
-//                      whose sum becomes positive are appended to a compact "touched" list
-//                      (wave-aggregated atomics);
+//   bm25_terms_lds_kernel  all unique query terms in one launch, the ROWS partitioned over the workgroups: every
+//                      posting adds its BM25 contribution to its row's accumulator in query-term order (the f32 sum
+//                      order of the reference -- deterministic), the accumulators of a workgroup's rows in LDS; rows
+//                      whose sum becomes positive are appended to a compact "touched" list.  (bm25_terms_kernel: the
+//                      same with the accumulators in device memory, for indexes beyond a few million rows;
+//                      bm25_term_kernel: one launch per term, an A/B switch);
 //   <= 8192 postings   lex_sort_kernel: packed (score, row) keys sorted in LDS;
 //   more, limit <= 4096  sampled selection, 3 launches: lex_sample_kernel (threshold key from a strided sample),
 //                      lex_filter_kernel (one pass, ~1.5 limit candidates), lex_final_kernel (exact limit-th key
@@ -227,6 +228,199 @@ __global__ __launch_bounds__(256) void bm25_terms_kernel(TermBatch tb, const uin
     }
 }
 
+// The same launch with the accumulators of the workgroup's rows in LDS (<= kLdsRows of them: indexes up to a few million
+// rows).  The global form above walks a chain of dependent memory round trips per term -- posting -> document length ->
+// accumulator -> first-touch slot (an atomic on one counter per wave) -> store -- behind seventeen more for the range
+// searches: ~40 us for six terms over 100 k rows, the longest kernel beside the scan of a text search.  Here the document
+// lengths and accumulators of the rows are loaded once (coalesced, in flight during the searches), the searches take one
+// round as a rule, a term's postings are on their way while the previous term is added, the sums stay in LDS between terms, and the
+// touched rows are appended with one reservation per workgroup.  The f32 sum order per row is the term order, as before.
+constexpr uint32_t kLdsRows = 2048;
+constexpr int kSearchPerWave = 4;        // range searches a wave runs at a time
+constexpr uint32_t kSearchWin = 512;     // entries of the window around a search's estimated place
+
+// First index with rows[i] >= key, by one wavefront: 64 probes per round (the last entry of each 64th of the range), three
+// dependent loads for a 100 k-entry list.  Uniform result.
+__device__ inline uint32_t wave_lower_bound_rows(const uint32_t *__restrict__ rows, uint32_t cnt, uint32_t key, uint32_t lane)
+{
+    uint32_t lo = 0, hi = cnt;
+    while (hi - lo > 64) {
+        const uint32_t step = (hi - lo + 63) / 64;
+        const uint32_t begin = min(lo + lane * step, hi), end = min(lo + (lane + 1) * step, hi);
+        const bool below = begin < end && rows[end - 1] < key; // this lane's whole block lies below the key
+        const uint32_t c = static_cast<uint32_t>(__popcll(__ballot(below)));
+        const uint32_t nlo = min(lo + c * step, hi);
+        hi = min(lo + (c + 1) * step, hi);
+        lo = nlo;
+    }
+    const uint32_t i = lo + lane;
+    const bool below = i < hi && rows[i] < key;
+    return lo + static_cast<uint32_t>(__popcll(__ballot(below)));
+}
+__global__ __launch_bounds__(256) void bm25_terms_lds_kernel(TermBatch tb, const uint32_t *__restrict__ post_row,
+                                                             const uint32_t *__restrict__ post_tf, const uint32_t *__restrict__ dpost_row,
+                                                             const uint32_t *__restrict__ dpost_tf, const uint32_t *__restrict__ doc_len,
+                                                             uint32_t n_rows, float avg, float *__restrict__ scores,
+                                                             uint32_t *__restrict__ touched, LexControl *__restrict__ ctl)
+{
+    __shared__ uint32_t s_range[kTermsPerLaunch][4]; // [term][main lo, main hi, appended lo, appended hi]
+    __shared__ float s_sc[kLdsRows], s_dl[kLdsRows], s_nk[kLdsRows];
+    __shared__ uint8_t s_fl[kLdsRows]; // bit 0: the sum became positive (first touch), bit 1: the sum was written
+    __shared__ uint32_t s_cnt, s_base;
+    __shared__ uint32_t s_id[kTermsPerLaunch * 4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r0 = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * n_rows / gridDim.x);
+    const uint32_t r1 = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * n_rows / gridDim.x);
+    const uint32_t nr = r1 - r0; // <= kLdsRows (the launch sees to it)
+    for (uint32_t r = tid; r < nr; r += 256) {
+        s_sc[r] = scores[r0 + r]; // zero unless an earlier launch of this query (more than 16 terms) was here
+        const float dl = static_cast<float>(doc_len[r0 + r]);
+        s_dl[r] = dl;
+        s_nk[r] = kK1 * ((1.0f - kB) + kB * (dl / avg)); // the row's share of every posting's denominator (same operations, once)
+        s_fl[r] = 0;
+    }
+    if (tid == 0)
+        s_cnt = 0;
+    // This workgroup's share of every posting list (sorted by row): first index >= r0 and first index >= r1.  A lane's binary
+    // search took seventeen dependent loads per list, each of them microseconds while the scan kernel next door saturates
+    // the memory system; probing 64 or 512 places per round took few rounds but so many cache lines (a line per probe,
+    // ~400 workgroups x 12 searches) that the traffic itself became the cost.  So: the place is ESTIMATED from the key
+    // (postings spread evenly over the rows land within a few hundred entries of cnt * key / n_rows), one coalesced window of
+    // 512 entries around the estimate is read, and the window decides if the key falls inside it; else the 64-ary search
+    // below takes the side it points to.  A wave runs four searches at a time, their windows in flight together.
+    uint32_t nz = 0;
+    for (uint32_t id = 0; id < tb.n_terms * 4; ++id) {
+        const uint32_t cnt = (id & 2) ? tb.cnt_d[id >> 2] : tb.cnt_m[id >> 2];
+        if (cnt == 0) {
+            if (tid == 0)
+                s_range[id >> 2][id & 3] = 0;
+            continue;
+        }
+        if (tid == 0)
+            s_id[nz] = id;
+        ++nz;
+    }
+    __syncthreads();
+    for (uint32_t b0 = wave * kSearchPerWave; b0 < nz; b0 += 4 * kSearchPerWave) {
+        uint32_t wlo[kSearchPerWave], whi[kSearchPerWave], key[kSearchPerWave], v[kSearchPerWave][kSearchWin / 64];
+#pragma unroll
+        for (int j = 0; j < kSearchPerWave; ++j) {
+            wlo[j] = whi[j] = key[j] = 0;
+            if (b0 + j >= nz)
+                continue;
+            const uint32_t id = s_id[b0 + j], t = id >> 2;
+            const uint32_t *rows = (id & 2) ? dpost_row + tb.off_d[t] : post_row + tb.off_m[t];
+            const uint32_t cnt = (id & 2) ? tb.cnt_d[t] : tb.cnt_m[t];
+            key[j] = (id & 1) ? r1 : r0;
+            // (an estimate: f32 is exact enough, and a 64-bit integer division is ~200 instructions, four times per wave)
+            const uint32_t est = min(cnt, static_cast<uint32_t>(static_cast<float>(cnt) * (static_cast<float>(key[j]) / static_cast<float>(n_rows))));
+            whi[j] = min(max(est, kSearchWin / 2) + kSearchWin / 2, cnt);
+            wlo[j] = whi[j] > kSearchWin ? whi[j] - kSearchWin : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < kSearchWin / 64; ++u) {
+                const uint32_t i = wlo[j] + lane + 64 * u;
+                v[j][u] = i < whi[j] ? rows[i] : 0xFFFFFFFFu;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kSearchPerWave; ++j) {
+            if (b0 + j >= nz)
+                continue;
+            const uint32_t id = s_id[b0 + j], t = id >> 2;
+            const uint32_t *rows = (id & 2) ? dpost_row + tb.off_d[t] : post_row + tb.off_m[t];
+            const uint32_t cnt = (id & 2) ? tb.cnt_d[t] : tb.cnt_m[t];
+            uint32_t c = 0; // entries of the window below the key (a prefix of it: the list is sorted)
+#pragma unroll
+            for (uint32_t u = 0; u < kSearchWin / 64; ++u)
+                c += static_cast<uint32_t>(__popcll(__ballot(v[j][u] < key[j])));
+            uint32_t res;
+            if ((wlo[j] == 0 || c > 0) && (whi[j] == cnt || c < whi[j] - wlo[j]))
+                res = wlo[j] + c; // the boundary lies inside the window
+            else if (c == 0)
+                res = wave_lower_bound_rows(rows, wlo[j], key[j], lane); // the whole window is at or above the key
+            else
+                res = whi[j] + wave_lower_bound_rows(rows + whi[j], cnt - whi[j], key[j], lane);
+            if (lane == 0)
+                s_range[t][id & 3] = res;
+        }
+    }
+    __syncthreads();
+    // chunks of <= 256 postings in (term, segment) order; a row lives in exactly one segment and once in a list, so only a
+    // change of TERM needs a barrier (the next term adds to sums other threads wrote)
+    auto seek = [&](uint32_t &t, uint32_t &seg, uint32_t &i0) { // the first chunk at or behind (t, seg, i0) that holds postings
+        while (t < tb.n_terms && i0 >= s_range[t][2 * seg + 1]) {
+            if (seg == 0) {
+                seg = 1;
+            } else {
+                seg = 0;
+                ++t;
+            }
+            if (t < tb.n_terms)
+                i0 = s_range[t][2 * seg];
+        }
+    };
+    auto fetch = [&](uint32_t t, uint32_t seg, uint32_t i0, uint32_t *row, uint32_t *tf) -> bool {
+        if (t >= tb.n_terms)
+            return false;
+        const uint32_t i = i0 + tid;
+        if (i >= s_range[t][2 * seg + 1])
+            return false;
+        *row = (seg ? dpost_row + tb.off_d[t] : post_row + tb.off_m[t])[i];
+        *tf = (seg ? dpost_tf + tb.off_d[t] : post_tf + tb.off_m[t])[i];
+        return true;
+    };
+    uint32_t t = 0, seg = 0, i0 = s_range[0][0];
+    seek(t, seg, i0);
+    uint32_t row = 0, tfw = 0;
+    bool ok = fetch(t, seg, i0, &row, &tfw);
+    while (t < tb.n_terms) {
+        uint32_t t2 = t, seg2 = seg, j0 = i0 + 256;
+        seek(t2, seg2, j0);
+        uint32_t row2 = 0, tfw2 = 0;
+        const bool ok2 = fetch(t2, seg2, j0, &row2, &tfw2); // on its way while this chunk is added
+        if (ok) {
+            const uint32_t r = row - r0;
+            const float dl = s_dl[r];
+            const float tf = static_cast<float>(tfw);
+            const float denom = tf + s_nk[r];
+            if (dl != 0.0f && denom != 0.0f) {
+                const float sc = tb.idf[t] * (tf * (kK1 + 1.0f)) / denom;
+                const float old = s_sc[r];
+                const float now = old + sc; // `*scores.entry(doc).or_insert(0.0) += score`
+                s_sc[r] = now;
+                s_fl[r] = static_cast<uint8_t>(s_fl[r] | 2u | ((old == 0.0f && now > 0.0f) ? 1u : 0u));
+            }
+        }
+        if (t2 != t)
+            __syncthreads();
+        t = t2;
+        seg = seg2;
+        i0 = j0;
+        row = row2;
+        tfw = tfw2;
+        ok = ok2;
+    }
+    __syncthreads();
+    // the sums back to the dense array; the rows that became positive into the touched list, one reservation per workgroup
+    uint32_t mine = 0;
+    for (uint32_t r = tid; r < nr; r += 256) {
+        const uint32_t fl = s_fl[r];
+        if (fl & 2u)
+            scores[r0 + r] = s_sc[r];
+        mine += fl & 1u;
+    }
+    uint32_t at = mine ? atomicAdd(&s_cnt, mine) : 0u;
+    __syncthreads();
+    if (tid == 0)
+        s_base = s_cnt ? atomicAdd(&ctl->n_touched, s_cnt) : 0u;
+    __syncthreads();
+    at += s_base;
+    if (mine)
+        for (uint32_t r = tid; r < nr; r += 256)
+            if (s_fl[r] & 1u)
+                touched[at++] = r0 + r;
+}
+
 // `results.sort_by(score desc)` + `truncate(limit)` (:2218-2222) when everything fits one workgroup
 template <bool FROM_TOUCHED>
 __global__ __launch_bounds__(1024) void lex_sort_kernel(const float *__restrict__ scores,
@@ -383,12 +577,14 @@ __global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restric
     // two dependent gathers per sample (list entry -> its score): all eight list loads of a thread first, then all
     // eight score loads, instead of eight serial round trips
     constexpr int kPer = kSampleMax / 1024;
+    static_assert(kSampleMax == 1u << 13, "the sample stride below shifts by 13");
     uint32_t rows_[kPer];
     float sc_[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
         const uint32_t i = threadIdx.x + 1024 * u;
-        const uint32_t at = i < s ? static_cast<uint32_t>(static_cast<uint64_t>(i) * n / s) : 0u; // strided: every part of the list
+        // strided: every part of the list (s is kSampleMax = 2^13 whenever it is not n itself: a shift, not a 64-bit division)
+        const uint32_t at = i >= s ? 0u : s == n ? i : static_cast<uint32_t>((static_cast<uint64_t>(i) * n) >> 13);
         rows_[u] = touched[at];
     }
 #pragma unroll
@@ -650,6 +846,7 @@ constexpr int kMaxWorkspaces = 8; // callers beyond this wait for a free one
 struct rlr_lexical {
     int32_t device = 0;
     int n_cu = 256;
+    bool terms_global = false; // RLR_LEX_TERMS=global at creation: the BM25 sums always in device memory (bm25_terms_kernel)
     std::shared_mutex mu; // mutators and commit exclusive, scoring calls shared
     // ---- host state (LexicalIndex fields, rag_engine.rs:2084-2090, keyed by row instead of chunk id)
     std::unordered_map<std::string, uint32_t> term_id;
@@ -958,6 +1155,8 @@ int32_t rlr_lexical_create(int32_t device_id, rlr_lexical **out)
         e = hipGetDeviceProperties(&prop, device_id);
     if (e == hipSuccess) {
         lx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (const char *v = getenv("RLR_LEX_TERMS"))
+            lx->terms_global = !strcmp(v, "global");
     }
     if (e != hipSuccess) {
         rlr_lexical_destroy(lx);
@@ -1258,7 +1457,7 @@ struct PendingGuard { // releases whatever lexical_enqueue had taken when it fai
 } // namespace
 
 int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, LexPending *out,
-                        bool need_sorted, bool exact_passes)
+                        bool need_sorted, bool exact_passes, const LexSink *sink)
 {
     *out = LexPending{};
     out->lx = lx;
@@ -1341,8 +1540,16 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     // workgroups of the row-partitioned kernel: one per CU while each still owns a few hundred rows
     const uint32_t row_wgs = std::max<uint32_t>(1u, std::min<uint32_t>(static_cast<uint32_t>(lx->n_cu), static_cast<uint32_t>(n_rows / 256)));
     TermBatch tb{};
+    // ... with the accumulators in LDS while a workgroup's rows fit there: one workgroup per 256 rows, up to 8 per CU
+    // (RLR_LEX_TERMS=global when the index is created: the form that adds in device memory, also the one for larger indexes)
+    const uint32_t lds_wgs = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(max_blocks, (n_rows + 255) / 256)));
+    const bool terms_lds = !lx->terms_global && (n_rows + lds_wgs - 1) / lds_wgs + 1 <= kLdsRows;
     auto flush_terms = [&]() {
-        if (tb.n_terms)
+        if (tb.n_terms && terms_lds)
+            hipLaunchKernelGGL(bm25_terms_lds_kernel, dim3(lds_wgs), dim3(256), 0, s, tb, lx->d_post_row, lx->d_post_tf,
+                               lx->d_dpost_row, lx->d_dpost_tf, lx->d_doc_len, static_cast<uint32_t>(n_rows), avg, ws->d_scores,
+                               ws->d_touched, ws->d_ctl);
+        else if (tb.n_terms)
             hipLaunchKernelGGL(bm25_terms_kernel, dim3(row_wgs), dim3(256), 0, s, tb, lx->d_post_row, lx->d_post_tf, lx->d_dpost_row,
                                lx->d_dpost_tf, lx->d_doc_len, static_cast<uint32_t>(n_rows), avg, ws->d_scores, ws->d_touched,
                                ws->d_ctl);
@@ -1423,6 +1630,10 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
             d_result = ws->d_sel;
             d_result_n = &ws->d_ctl->n_sel;
         }
+    }
+    if (sink && sink->d_rows) { // a hybrid search takes the result apart on its own stream otherwise: one launch behind its join
+        launch_lex_unpack(d_result, d_result_n, std::min(lim, sink->n_bound), *sink, s);
+        out->unpacked = true;
     }
     LEX_HIP(hipGetLastError());
     LEX_HIP(hipEventRecord(ws->ready, s)); // the result list is complete here; the clean-up below runs behind it

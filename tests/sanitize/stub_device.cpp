@@ -167,7 +167,7 @@ extern "C" int32_t rlr_lexical_score(rlr_lexical *, const char *, size_t, uint32
 
 #include "../../rust-local-rag_amd/csrc/lexical_internal.h"
 namespace rlr {
-int32_t lexical_enqueue(rlr_lexical *, const char *, size_t, uint32_t, LexPending *out, bool, bool)
+int32_t lexical_enqueue(rlr_lexical *, const char *, size_t, uint32_t, LexPending *out, bool, bool, const LexSink *)
 {
     *out = LexPending{};
     return RLR_OK; // limit == 0: "no lexical candidate"
@@ -183,7 +183,7 @@ int32_t lexical_score_exact(rlr_lexical *lx, const char *t, size_t len, uint32_t
     return rlr_lexical_score(lx, t, len, limit, rows, scores, n_out);
 }
 int32_t search_hybrid_begin(rlr_index *, const float *, uint32_t, uint32_t, float, int32_t, float, float, uint32_t, float,
-                            HybridTicket **ticket, int32_t *fallback, int32_t (*)(void *), void *)
+                            HybridTicket **ticket, int32_t *fallback, int32_t (*)(void *, const LexSink *), void *)
 {
     *ticket = nullptr;
     *fallback = 1;

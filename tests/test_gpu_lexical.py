@@ -455,3 +455,94 @@ def test_hybrid_entry_points_reject_bad_arguments_and_stay_usable(rlr, oracle):
     wr, wc, _, _ = oracle.search_with_diversity(eng.index.fetch_rows(np.arange(n)), q, 5, 0.3, lex=pairs)
     assert [g_.row for g_ in got] == list(wr) and np.array_equal(bits([g_.score for g_ in got]), bits(wc))
     eng.close()
+
+
+def clustered_texts(n, seed):
+    """terms that live in row BANDS (a document ingested chunk after chunk keeps its vocabulary together): the place of a row
+    in such a posting list is nowhere near cnt * row / n_rows, so the range search's estimate misses and its fallback runs"""
+    rng = np.random.default_rng(seed)
+    texts = []
+    for r in range(n):
+        words = [f"band{r * 16 // n:02d}"] * int(rng.integers(1, 4))          # 16 bands of n / 16 rows
+        if r < n // 8:
+            words.append("early")
+        if r >= n - n // 5:
+            words += ["late", "late"]
+        if r % 7 == 0:
+            words.append("spread")
+        words += list(rng.choice(VOCAB[:60], size=int(rng.integers(2, 9))))
+        texts.append(" ".join(words))
+    return texts
+
+
+@pytest.mark.parametrize("form", ["lds", "global"])
+def test_bm25_clustered_postings_both_accumulator_forms(rlr, monkeypatch, form):
+    """bm25_terms_lds_kernel (sums in LDS, estimated range search with its fallback) and bm25_terms_kernel (sums in device
+    memory, RLR_LEX_TERMS=global at creation) against the oracle, on posting lists clustered by row; 17 terms take two
+    launches (the second continues from the first one's sums)"""
+    if form == "global":
+        monkeypatch.setenv("RLR_LEX_TERMS", "global")
+    n = 30000
+    texts = clustered_texts(n, seed=41)
+    g, o = build_pair(rlr, texts)
+    many = " ".join(VOCAB[:15]) + " early late"
+    for q, lim in [("early", 100), ("late spread", 1500), ("band00 band15 early late", 700), ("band07", 0),
+                   ("spread w000x band03 late", 2000), (many, 1200), ("band08 band09 w001x", 5000)]:
+        assert check(g, o, q, lim) > 0
+    # appended rows (the second posting segment) and a removed band
+    extra = clustered_texts(2000, seed=42)
+    for i, t in enumerate(extra):
+        g.add_chunk(n + i, t)
+        o.add_chunk(n + i, t, rank=n + i)
+    for q, lim in [("early late", 900), ("band15 spread", 1500)]:
+        assert check(g, o, q, lim) > 0
+    g.close()
+
+
+@pytest.mark.parametrize("fetch", ["tight", "full"])
+def test_engine_search_text_cosine_fetch_of_need_plus_a_margin_is_exact(rlr, oracle, monkeypatch, fetch):
+    """The blend of a text search asks for the need + 32 best rows by cosine (rlr_index::hybrid_fetch_full; rounds 2-3:
+    need + n_lexical + 8, RLR_HYBRID_FETCH=full): a lexical term only adds to a blended score, so those rows hold every
+    non-lexical row that can reach the pool.  Against the oracle where the lexical term decides the pool, where the cosine
+    alone does (many lexical rows among the best cosines), and with duplicated rows tying across the fetch boundary
+    (status 2: the host's widening path answers)."""
+    if fetch == "full":
+        monkeypatch.setenv("RLR_HYBRID_FETCH", "full")
+    n, dim = 20000, 64
+    texts = make_texts(n, seed=51, lo=4, hi=25)
+    rows = oracle.synth_rows(n, dim, seed=52)
+    q_dup = oracle.synth_query(dim, seed=599)
+    rows[300:420] = q_dup                      # 120 identical rows: the best cosines of q_dup tie far across need + 32
+    eng = rlr.RagEngine(dim)
+    eng.add_document("d", texts, rows)
+    stored = eng.index.fetch_rows(np.arange(n))
+    o = OL.LexicalIndex()
+    for r, t in enumerate(texts):
+        o.add_chunk(r, t, rank=r)
+    text, k, div = "w000x w001x common the w017x", 20, 0.4
+    k_eff = max(3 * k, k + 10)
+    pairs = [(c, float(s)) for c, s in o.score(text, 5 * k_eff, keep_zero=False)]
+    assert len(pairs) > 100
+
+    def run(q, wts, diverse=True):
+        w = rlr.QueryWeights(**wts) if wts else None
+        w_e, w_l = (wts["embedding"], wts["lexical"]) if wts else (0.7, 0.3)
+        if diverse:
+            got = eng.search_with_diversity(q, k, div, weights=w, query_text=text)
+            wr, wc, we, wl = oracle.search_with_diversity(stored, q, k, div, w_e, w_l, lex=pairs)
+        else:
+            got = eng.search(q, k, weights=w, query_text=text)
+            wr, wc, we, wl = oracle.search(stored, q, k, w_e, w_l, lex=[(c, s) for c, s in o.score(text, 5 * k, keep_zero=False)])
+        assert [g_.row for g_ in got] == list(wr), wts
+        assert np.array_equal(bits([g_.score for g_ in got]), bits(wc)), wts
+        assert np.array_equal(bits([g_.lexical_score for g_ in got]), bits(wl)), wts
+
+    for i in range(6):
+        q = oracle.synth_query(dim, seed=600 + i)
+        run(q, None)                                            # the lexical term decides the pool
+        run(q, dict(embedding=1.0, lexical=1e-6))               # the cosine decides it
+        run(q, dict(embedding=0.5, lexical=0.05), diverse=False)
+    # the query whose 120 best rows are identical: the need-th blended score does not beat the last fetched cosine
+    run(q_dup, dict(embedding=1.0, lexical=1e-6))
+    run(q_dup, None)
+    eng.close()
