@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void lex_collect_kernel(const uint64_t *__rest
 
 // ---- sampled selection: 3 launches instead of 8 radix passes + collect ------------------------------------------
 // The `limit` best of n_touched documents by (score desc, row asc), for limit << n_touched:
-//   lex_sample_kernel   one workgroup reads a strided sample of <= 8192 (score, row) keys and takes, by an LDS radix
+//   lex_sample_kernel   one workgroup reads a strided sample of 4096 or 8192 (score, row) keys and takes, by an LDS radix
 //                       select, the sample's r-th largest key as threshold, r = mu + 4.5 sqrt(mu) + 8 with mu =
 //                       limit * s / n the expected number of sample members among the true top `limit`: the threshold
 //                       lies at or below the true limit-th key unless the sample holds > r of them (< 1e-5).  Full
@@ -558,17 +558,17 @@ __global__ __launch_bounds__(256) void lex_collect_kernel(const uint64_t *__rest
 // When the list overflowed or came out short (the unlucky sample), the count
 // word is set to kLexRetry and the caller repeats the query on the exact eight-pass path.
 constexpr uint32_t kLexRetry = 0xFFFFFFFFu;
-constexpr uint32_t kSampleMax = 8192, kFastLimitMax = 4096;
+constexpr uint32_t kSampleMax = 8192, kFastLimitMax = 4096; // (the launch picks 4096 or 8192 sample keys: sample_log2)
 
 __global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restrict__ scores, const uint32_t *__restrict__ touched,
                                                           LexControl *__restrict__ ctl, uint32_t limit, uint32_t r_forced,
-                                                          uint32_t row_bits)
+                                                          uint32_t row_bits, uint32_t sample_log2)
 {
     __shared__ uint64_t s_k[kSampleMax];
     __shared__ uint32_t s_hist[2048];
     __shared__ uint32_t s_pick[3];
     const uint32_t n = ctl->n_touched;
-    const uint32_t s = min(n, kSampleMax);
+    const uint32_t s = min(n, 1u << sample_log2); // 4096 or 8192
     if (limit >= n || s == 0) { // everything is wanted
         if (threadIdx.x == 0)
             ctl->thr = 0;
@@ -577,19 +577,23 @@ __global__ __launch_bounds__(1024) void lex_sample_kernel(const float *__restric
     // two dependent gathers per sample (list entry -> its score): all eight list loads of a thread first, then all
     // eight score loads, instead of eight serial round trips
     constexpr int kPer = kSampleMax / 1024;
-    static_assert(kSampleMax == 1u << 13, "the sample stride below shifts by 13");
     uint32_t rows_[kPer];
     float sc_[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
         const uint32_t i = threadIdx.x + 1024 * u;
-        // strided: every part of the list (s is kSampleMax = 2^13 whenever it is not n itself: a shift, not a 64-bit division)
-        const uint32_t at = i >= s ? 0u : s == n ? i : static_cast<uint32_t>((static_cast<uint64_t>(i) * n) >> 13);
-        rows_[u] = touched[at];
+        // strided: every part of the list (s is a power of two whenever it is not n itself: a shift, not a 64-bit division)
+        const uint32_t at = i >= s ? 0u : s == n ? i : static_cast<uint32_t>((static_cast<uint64_t>(i) * n) >> sample_log2);
+        rows_[u] = 0;
+        if (1024u * u < s) // (uniform: the upper half of the slots is idle with the smaller sample)
+            rows_[u] = touched[at];
     }
 #pragma unroll
-    for (int u = 0; u < kPer; ++u)
-        sc_[u] = scores[rows_[u]];
+    for (int u = 0; u < kPer; ++u) {
+        sc_[u] = 0.0f;
+        if (1024u * u < s)
+            sc_[u] = scores[rows_[u]];
+    }
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
         const uint32_t i = threadIdx.x + 1024 * u;
@@ -674,18 +678,17 @@ __global__ __launch_bounds__(1024) void lex_final_kernel(const uint64_t *__restr
         *out_n = want;
 }
 
-__global__ __launch_bounds__(1024) void lex_zero_words_kernel(uint32_t *__restrict__ p, uint32_t n)
-{
-    for (uint32_t i = threadIdx.x; i < n; i += 1024)
-        p[i] = 0u;
-}
-
+// ... and zeroes the control block the NEXT call of this workspace will use (`next`: not the one this call worked in)
 __global__ __launch_bounds__(256) void lex_clear_kernel(float *__restrict__ scores, const uint32_t *__restrict__ touched,
-                                                        const LexControl *__restrict__ ctl)
+                                                        const LexControl *__restrict__ ctl, uint32_t *__restrict__ next,
+                                                        uint32_t next_words)
 {
     const uint32_t n = ctl->n_touched;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
         scores[touched[i]] = 0.0f;
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < next_words; i += 256)
+            next[i] = 0u;
 }
 
 // ---- removal of rows without rebuilding the postings on the host ---------------------------------------------
@@ -835,7 +838,9 @@ struct LexWorkspace {
     uint64_t *d_keys = nullptr;
     uint64_t keys_cap = 0;
     uint64_t *d_sel = nullptr;
-    LexControl *d_ctl = nullptr;
+    LexControl *d_ctl = nullptr; // TWO control blocks: a call works in d_ctl[ctl_cur] and its clean-up launch (behind `ready`, off
+                                 // the critical path) zeroes the other one for the next call -- it was a launch in front of every call
+    uint32_t ctl_cur = 0;
     uint64_t *d_out = nullptr; // kMaxLimit keys + count
     uint64_t *h_out = nullptr; // pinned mirror
     bool dirty = false;        // a call failed after enqueuing work: accumulators / control may be non-zero
@@ -932,9 +937,9 @@ int32_t workspace_create(LexWorkspace **out)
     if (e == hipSuccess)
         e = hipEventCreateWithFlags(&ws->ready, hipEventDisableTiming);
     if (e == hipSuccess)
-        e = rlr::dev_malloc(reinterpret_cast<void **>(&ws->d_ctl), sizeof(LexControl));
+        e = rlr::dev_malloc(reinterpret_cast<void **>(&ws->d_ctl), 2 * sizeof(LexControl));
     if (e == hipSuccess)
-        e = hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), ws->stream); // ordered before every call on this stream
+        e = hipMemsetAsync(ws->d_ctl, 0, 2 * sizeof(LexControl), ws->stream); // ordered before every call on this stream
     if (e == hipSuccess)
         e = rlr::dev_malloc(reinterpret_cast<void **>(&ws->d_sel), kMaxLimit * sizeof(uint64_t));
     if (e == hipSuccess)
@@ -1456,6 +1461,13 @@ struct PendingGuard { // releases whatever lexical_enqueue had taken when it fai
 };
 } // namespace
 
+// expected candidates of the sampled selection: (mu + 4.5 sqrt(mu) + 8) n / s with mu = limit s / n the expected number of
+// sample members among the true top `limit`
+static double sampled_candidates(uint32_t limit, uint64_t n, uint32_t s)
+{
+    return static_cast<double>(limit) + 4.5 * std::sqrt(static_cast<double>(limit) * n / s) + 8.0 * static_cast<double>(n) / s;
+}
+
 int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, uint32_t limit, LexPending *out,
                         bool need_sorted, bool exact_passes, const LexSink *sink)
 {
@@ -1513,12 +1525,12 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
         LEX_HIP(hipStreamSynchronize(ws->stream));
         LEX_TRY(dev_grow(&ws->d_scores, &ws->scores_cap, n_rows + n_rows / 4, /*zero=*/true));
         ws->dirty = false;
-        LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), ws->stream));
+        LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, 2 * sizeof(LexControl), ws->stream));
     }
     if (ws->dirty) { // restore the all-zero invariant a failed call may have broken
         LEX_HIP(hipStreamSynchronize(ws->stream));
         LEX_HIP(hipMemsetAsync(ws->d_scores, 0, ws->scores_cap * sizeof(float), ws->stream));
-        LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, sizeof(LexControl), ws->stream));
+        LEX_HIP(hipMemsetAsync(ws->d_ctl, 0, 2 * sizeof(LexControl), ws->stream));
         ws->dirty = false;
     }
     LEX_TRY(dev_grow(&ws->d_touched, &ws->touched_cap, upper));
@@ -1527,14 +1539,13 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     const float avg = static_cast<float>(lx->total_length) / n_docs; // :2184-2188
     hipStream_t s = ws->stream;
     ws->dirty = true; // cleared by lexical_finish(ok) once the whole pipeline has run
-    // the control block (counters, histograms) is zeroed in front of a call, not behind it: its counts stay readable
-    // for a consumer on another stream until the workspace is handed back
-    // (one small kernel: hipMemsetAsync turns the 8328-byte block into two fill kernels of ~5 us each, at the head of a chain
-    // that is as long as the scan .. sort chain it runs beside)
+    // The control block (counters, histograms) of THIS call: all zero on entry -- the previous call's clean-up launch (or the
+    // memsets above) saw to that -- and readable for a consumer on another stream until the workspace is handed back: the
+    // next call works in the other block and zeroes this one only behind its own `ready`.
     static_assert(sizeof(LexControl) % 4 == 0, "cleared as 32-bit words");
-    hipLaunchKernelGGL(lex_zero_words_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<uint32_t *>(ws->d_ctl),
-                       static_cast<uint32_t>(sizeof(LexControl) / 4));
-    LEX_HIP(hipGetLastError());
+    LexControl *ctl = ws->d_ctl + ws->ctl_cur;
+    LexControl *ctl_next = ws->d_ctl + (ws->ctl_cur ^ 1u);
+    ws->ctl_cur ^= 1u;
     const uint32_t max_blocks = static_cast<uint32_t>(lx->n_cu) * 8;
     static const bool per_term = getenv("RLR_LEX_PER_TERM") != nullptr; // (A/B switch: one launch per term and segment)
     // workgroups of the row-partitioned kernel: one per CU while each still owns a few hundred rows
@@ -1548,11 +1559,11 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
         if (tb.n_terms && terms_lds)
             hipLaunchKernelGGL(bm25_terms_lds_kernel, dim3(lds_wgs), dim3(256), 0, s, tb, lx->d_post_row, lx->d_post_tf,
                                lx->d_dpost_row, lx->d_dpost_tf, lx->d_doc_len, static_cast<uint32_t>(n_rows), avg, ws->d_scores,
-                               ws->d_touched, ws->d_ctl);
+                               ws->d_touched, ctl);
         else if (tb.n_terms)
             hipLaunchKernelGGL(bm25_terms_kernel, dim3(row_wgs), dim3(256), 0, s, tb, lx->d_post_row, lx->d_post_tf, lx->d_dpost_row,
                                lx->d_dpost_tf, lx->d_doc_len, static_cast<uint32_t>(n_rows), avg, ws->d_scores, ws->d_touched,
-                               ws->d_ctl);
+                               ctl);
         tb.n_terms = 0;
     };
     for (uint32_t t : terms) {
@@ -1577,13 +1588,13 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
             const uint64_t off = lx->term_off[t];
             const uint32_t blocks = std::min<uint32_t>((cnt_m + 255) / 256, max_blocks);
             hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_post_row + off, lx->d_post_tf + off, cnt_m,
-                               lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
+                               lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ctl);
         }
         if (cnt_d) {
             const uint64_t off = lx->dterm_off[t];
             const uint32_t blocks = std::min<uint32_t>((cnt_d + 255) / 256, max_blocks);
             hipLaunchKernelGGL(bm25_term_kernel, dim3(blocks), dim3(256), 0, s, lx->d_dpost_row + off, lx->d_dpost_tf + off,
-                               cnt_d, lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ws->d_ctl);
+                               cnt_d, lx->d_doc_len, avg, idf, ws->d_scores, ws->d_touched, ctl);
         }
     }
     flush_terms();
@@ -1593,13 +1604,13 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     const uint64_t *d_result = ws->d_out;
     const uint32_t *d_result_n = d_out_n;
     if (upper <= kMaxLimit) {
-        hipLaunchKernelGGL(lex_sort_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, nullptr, ws->d_ctl,
+        hipLaunchKernelGGL(lex_sort_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, nullptr, ctl,
                            lim, ws->d_out, d_out_n);
-    } else if (!exact_passes && lim <= kFastLimitMax &&
-               // expected candidates of the sampled selection: (mu + 4.5 sqrt(mu) + 8) n / s with mu = lim s / n, s = 8192;
-               // beyond ~3 M touched documents the 8192-entry sample is too coarse for the 8192-entry candidate list
-               static_cast<double>(lim) + 4.5 * std::sqrt(static_cast<double>(lim) * upper / kSampleMax) +
-                       8.0 * static_cast<double>(upper) / kSampleMax <= 6000.0) {
+    } else if (!exact_passes && lim <= kFastLimitMax && sampled_candidates(lim, upper, kSampleMax) <= 6000.0) {
+        // (beyond ~3 M touched documents even the 8192-entry sample is too coarse for the 8192-entry candidate list)
+        // 4096 sample keys while that keeps the list short: half the gathers and LDS work of the sample launch for ~15 % more
+        // candidates at 100 k touched documents
+        const uint32_t sample_log2 = sampled_candidates(lim, upper, 4096) <= 4000.0 ? 12u : 13u;
         // sampled threshold -> one filter pass -> exact finish among the ~1.5 lim candidates (3 launches); the count word
         // says kLexRetry when that list overflowed or came out short
         // RLR_LEX_SAMPLE_RANK (a test switch): the sample rank to use instead of mu + 4.5 sqrt(mu) + 8 -- 1 makes the
@@ -1608,36 +1619,42 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
         while (row_bits < 32 && (n_rows - 1) >> row_bits)
             ++row_bits;
         static const uint32_t r_forced = getenv("RLR_LEX_SAMPLE_RANK") ? static_cast<uint32_t>(atoi(getenv("RLR_LEX_SAMPLE_RANK"))) : 0u;
-        hipLaunchKernelGGL(lex_sample_kernel, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl, lim, r_forced, row_bits);
-        hipLaunchKernelGGL(lex_filter_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl, ws->d_sel);
+        hipLaunchKernelGGL(lex_sample_kernel, dim3(1), dim3(1024), 0, s, ws->d_scores, ws->d_touched, ctl, lim, r_forced, row_bits,
+                           sample_log2);
+        hipLaunchKernelGGL(lex_filter_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ctl, ws->d_sel);
         if (need_sorted)
-            hipLaunchKernelGGL(lex_final_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_sel, ws->d_ctl, lim, ws->d_out, d_out_n, row_bits);
+            hipLaunchKernelGGL(lex_final_kernel<true>, dim3(1), dim3(1024), 0, s, ws->d_sel, ctl, lim, ws->d_out, d_out_n, row_bits);
         else
-            hipLaunchKernelGGL(lex_final_kernel<false>, dim3(1), dim3(1024), 0, s, ws->d_sel, ws->d_ctl, lim, ws->d_out, d_out_n, row_bits);
+            hipLaunchKernelGGL(lex_final_kernel<false>, dim3(1), dim3(1024), 0, s, ws->d_sel, ctl, lim, ws->d_out, d_out_n, row_bits);
         out->may_retry = true;
     } else {
         LEX_TRY(dev_grow(&ws->d_keys, &ws->keys_cap, upper));
-        hipLaunchKernelGGL(lex_select_pass_kernel<true>, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, 0,
+        hipLaunchKernelGGL(lex_select_pass_kernel<true>, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ctl, lim, 0,
                            ws->d_scores, ws->d_touched);
         for (int p = 1; p < kPasses; ++p)
-            hipLaunchKernelGGL(lex_select_pass_kernel<false>, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, p,
+            hipLaunchKernelGGL(lex_select_pass_kernel<false>, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ctl, lim, p,
                                nullptr, nullptr);
-        hipLaunchKernelGGL(lex_collect_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ws->d_ctl, lim, ws->d_sel);
+        hipLaunchKernelGGL(lex_collect_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_keys, ctl, lim, ws->d_sel);
         if (need_sorted) {
-            hipLaunchKernelGGL(lex_sort_kernel<false>, dim3(1), dim3(1024), 0, s, nullptr, nullptr, ws->d_sel, ws->d_ctl, lim,
+            hipLaunchKernelGGL(lex_sort_kernel<false>, dim3(1), dim3(1024), 0, s, nullptr, nullptr, ws->d_sel, ctl, lim,
                                ws->d_out, d_out_n);
         } else { // the consumer (the hybrid blend) wants the set, not its order: one LDS sort less on the critical path
             d_result = ws->d_sel;
-            d_result_n = &ws->d_ctl->n_sel;
+            d_result_n = &ctl->n_sel;
         }
     }
+    static const bool ready_by_launch = getenv("RLR_LEX_READY_BY_LAUNCH") != nullptr; // (experiment)
+    bool recorded = false;
     if (sink && sink->d_rows) { // a hybrid search takes the result apart on its own stream otherwise: one launch behind its join
-        launch_lex_unpack(d_result, d_result_n, std::min(lim, sink->n_bound), *sink, s);
+        launch_lex_unpack(d_result, d_result_n, std::min(lim, sink->n_bound), *sink, s, ready_by_launch ? ws->ready : nullptr);
         out->unpacked = true;
+        recorded = ready_by_launch;
     }
     LEX_HIP(hipGetLastError());
-    LEX_HIP(hipEventRecord(ws->ready, s)); // the result list is complete here; the clean-up below runs behind it
-    hipLaunchKernelGGL(lex_clear_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ws->d_ctl);
+    if (!recorded)
+        LEX_HIP(hipEventRecord(ws->ready, s)); // the result list is complete here; the clean-up below runs behind it
+    hipLaunchKernelGGL(lex_clear_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ctl,
+                       reinterpret_cast<uint32_t *>(ctl_next), static_cast<uint32_t>(sizeof(LexControl) / 4));
     LEX_HIP(hipGetLastError());
     out->stream = s;
     out->ready = ws->ready;
