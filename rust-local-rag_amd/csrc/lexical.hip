@@ -20,7 +20,8 @@
 //   otherwise / retry  8 x lex_select_pass_kernel (MSD radix select, 8-bit digits over the unique 64-bit keys --
 //                      exact under massive score ties, which BM25 produces whenever tf and document length
 //                      repeat; the first pass packs the keys) + lex_collect_kernel + lex_sort_kernel;
-//   lex_clear_kernel   restores the all-zero accumulator by visiting only the touched rows.
+//   lex_clear_kernel   restores the all-zero accumulator by visiting only the touched rows, and zeroes the control block
+//                      (counters, histograms) the workspace's NEXT call works in -- there are two, used in turn.
 // All of it is integer/f32 work bounded by HBM latency, not bandwidth: a query touches
 // sum(df) postings x 8 B.
 #include "../../include/rlr_lexical.h"
@@ -1643,16 +1644,12 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
             d_result_n = &ctl->n_sel;
         }
     }
-    static const bool ready_by_launch = getenv("RLR_LEX_READY_BY_LAUNCH") != nullptr; // (experiment)
-    bool recorded = false;
     if (sink && sink->d_rows) { // a hybrid search takes the result apart on its own stream otherwise: one launch behind its join
-        launch_lex_unpack(d_result, d_result_n, std::min(lim, sink->n_bound), *sink, s, ready_by_launch ? ws->ready : nullptr);
+        launch_lex_unpack(d_result, d_result_n, std::min(lim, sink->n_bound), *sink, s);
         out->unpacked = true;
-        recorded = ready_by_launch;
     }
     LEX_HIP(hipGetLastError());
-    if (!recorded)
-        LEX_HIP(hipEventRecord(ws->ready, s)); // the result list is complete here; the clean-up below runs behind it
+    LEX_HIP(hipEventRecord(ws->ready, s)); // the result list is complete here; the clean-up below runs behind it
     hipLaunchKernelGGL(lex_clear_kernel, dim3(blocks_u), dim3(256), 0, s, ws->d_scores, ws->d_touched, ctl,
                        reinterpret_cast<uint32_t *>(ctl_next), static_cast<uint32_t>(sizeof(LexControl) / 4));
     LEX_HIP(hipGetLastError());

@@ -35,10 +35,8 @@ struct LexSink {
     uint32_t n_bound = 0;       // most pairs the search takes
     uint32_t n_index_rows = 0;  // rows of the embedding index (pairs beyond it are marked, see lex_unpack_kernel)
 };
-// (index.hip) no error check inside: the caller's hipGetLastError sees it.  stop_event (hipEvent_t, may be null): recorded by
-// the launch itself -- the kernel's own completion signal, no marker packet behind it.
-void launch_lex_unpack(const uint64_t *d_packed, const uint32_t *d_count, uint32_t limit, const LexSink &sink, void *stream,
-                       void *stop_event);
+// (index.hip) no error check inside: the caller's hipGetLastError sees it
+void launch_lex_unpack(const uint64_t *d_packed, const uint32_t *d_count, uint32_t limit, const LexSink &sink, void *stream);
 
 // LexicalIndex::score (rag_engine.rs:2169-2225) up to the ordered result list in device memory.  No synchronisation.
 // need_sorted = false: d_packed holds the same set in no particular order (saves the final LDS sort; lexical_fetch
