@@ -853,6 +853,8 @@ struct rlr_lexical {
     int32_t device = 0;
     int n_cu = 256;
     bool terms_global = false; // RLR_LEX_TERMS=global at creation: the BM25 sums always in device memory (bm25_terms_kernel)
+    uint32_t lds_wgs_forced = 0; // RLR_LEX_LDS_WGS=n at creation (a test switch): workgroups of bm25_terms_lds_kernel -- few of
+                                 // them give each one more rows than a small test corpus would (several chunks per term)
     std::shared_mutex mu; // mutators and commit exclusive, scoring calls shared
     // ---- host state (LexicalIndex fields, rag_engine.rs:2084-2090, keyed by row instead of chunk id)
     std::unordered_map<std::string, uint32_t> term_id;
@@ -1163,6 +1165,8 @@ int32_t rlr_lexical_create(int32_t device_id, rlr_lexical **out)
         lx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char *v = getenv("RLR_LEX_TERMS"))
             lx->terms_global = !strcmp(v, "global");
+        if (const char *v = getenv("RLR_LEX_LDS_WGS"))
+            lx->lds_wgs_forced = static_cast<uint32_t>(strtoul(v, nullptr, 0));
     }
     if (e != hipSuccess) {
         rlr_lexical_destroy(lx);
@@ -1554,7 +1558,9 @@ int32_t lexical_enqueue(rlr_lexical *lx, const char *query_tokens, size_t len, u
     TermBatch tb{};
     // ... with the accumulators in LDS while a workgroup's rows fit there: one workgroup per 256 rows, up to 8 per CU
     // (RLR_LEX_TERMS=global when the index is created: the form that adds in device memory, also the one for larger indexes)
-    const uint32_t lds_wgs = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(max_blocks, (n_rows + 255) / 256)));
+    const uint32_t lds_wgs = lx->lds_wgs_forced
+                                 ? lx->lds_wgs_forced
+                                 : static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(max_blocks, (n_rows + 255) / 256)));
     const bool terms_lds = !lx->terms_global && (n_rows + lds_wgs - 1) / lds_wgs + 1 <= kLdsRows;
     auto flush_terms = [&]() {
         if (tb.n_terms && terms_lds)

@@ -475,13 +475,16 @@ def clustered_texts(n, seed):
     return texts
 
 
-@pytest.mark.parametrize("form", ["lds", "global"])
+@pytest.mark.parametrize("form", ["lds", "lds-wide", "global"])
 def test_bm25_clustered_postings_both_accumulator_forms(rlr, monkeypatch, form):
     """bm25_terms_lds_kernel (sums in LDS, estimated range search with its fallback) and bm25_terms_kernel (sums in device
     memory, RLR_LEX_TERMS=global at creation) against the oracle, on posting lists clustered by row; 17 terms take two
-    launches (the second continues from the first one's sums)"""
+    launches (the second continues from the first one's sums).  lds-wide: 17 workgroups of ~1900 rows each, as on an index
+    of millions of rows -- a term's share of a workgroup comes in several chunks of 256 postings"""
     if form == "global":
         monkeypatch.setenv("RLR_LEX_TERMS", "global")
+    if form == "lds-wide":
+        monkeypatch.setenv("RLR_LEX_LDS_WGS", "17")
     n = 30000
     texts = clustered_texts(n, seed=41)
     g, o = build_pair(rlr, texts)
