@@ -1398,6 +1398,39 @@ __global__ __launch_bounds__(1024) void lex_unpack_kernel(const uint64_t *__rest
     }
 }
 
+// [row u32 | cos f32 | combined f32 | lexical f32] x k_cap, then n, status, checksum, done (the layout the greedy kernel's
+// emit tail writes) into pinned host memory, by all threads of one workgroup
+__device__ inline void hybrid_emit_body(const uint32_t *list, const float *comb, const float *cosv, const float *lexv, uint32_t n,
+                                        uint32_t status, uint32_t k_cap, uint32_t *__restrict__ h_out)
+{
+    __shared__ uint32_t s_chk;
+    if (threadIdx.x == 0)
+        s_chk = 0;
+    __syncthreads();
+    uint32_t chk = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t w0 = list[i], w1 = __builtin_bit_cast(uint32_t, cosv[i]), w2 = __builtin_bit_cast(uint32_t, comb[i]);
+        const uint32_t w3 = __builtin_bit_cast(uint32_t, lexv[i]);
+        h_out[i] = w0;
+        h_out[k_cap + i] = w1;
+        h_out[2 * k_cap + i] = w2;
+        h_out[3 * k_cap + i] = w3;
+        chk += result_chk_term(w0, i) + result_chk_term(w1, k_cap + i) + result_chk_term(w2, 2 * k_cap + i) +
+               result_chk_term(w3, 3 * k_cap + i);
+    }
+    if (chk)
+        atomicAdd(&s_chk, chk);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { // (the greedy kernel's emit tail writes the same four words)
+        h_out[4 * k_cap] = n;
+        h_out[4 * k_cap + 1] = status;
+        h_out[4 * k_cap + 2] = block_chk_tail(s_chk, n, status, k_cap);
+        __threadfence_system();
+        h_out[4 * k_cap + 3] = kBlockDone;
+    }
+}
+
 __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__restrict__ packed, uint32_t fetch, uint32_t need,
                                                            uint32_t n_rows, float w_e, float w_l,
                                                            const uint32_t *__restrict__ lrow, const float *__restrict__ lscore,
@@ -1406,7 +1439,9 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
                                                            float *__restrict__ cand, // 3 x kHybridSlots: combined | cos | lex
                                                            uint32_t *__restrict__ list, float *__restrict__ comb,
                                                            float *__restrict__ cosv, float *__restrict__ lexv,
-                                                           uint32_t *__restrict__ info)
+                                                           uint32_t *__restrict__ info,
+                                                           uint32_t k_cap, uint32_t *__restrict__ h_out) // h_out != null: a search
+                                                           // without diversification -- the pool IS the result, emitted here
 {
     __shared__ uint64_t s_key[kHybridSlots];   // slot -> (ordered combined score, ~row); 0 = empty
     __shared__ uint64_t s_sel[kHybridSelMax];  // the keys that can be among the first `need`
@@ -1425,6 +1460,8 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
             info[0] = 0;
             info[1] = 3;
         }
+        if (h_out)
+            hybrid_emit_body(list, comb, cosv, lexv, 0u, 3u, k_cap, h_out);
         return;
     }
     const uint32_t n_lex = min(hdr->n_lex, kHybridLexMax);
@@ -1564,43 +1601,23 @@ __global__ __launch_bounds__(1024) void hybrid_pool_kernel(const uint64_t *__res
         }
         info[0] = status ? 0u : n_pool;
         info[1] = status;
+        s_pick[0] = status;
+    }
+    if (h_out) { // (list .. lexv were stored by this workgroup's own threads in front of the barrier above)
+        __syncthreads();
+        const uint32_t status = s_pick[0];
+        hybrid_emit_body(list, comb, cosv, lexv, status ? 0u : min(n_pool, k_cap), status, k_cap, h_out);
     }
 }
 
-// the first info[0] candidates in their sorted order (no diversification) -> pinned host memory:
-// [row u32 | cos f32 | combined f32 | lexical f32] x k_cap, then n, status (the layout the greedy kernel's emit tail writes)
+// the first info[0] candidates in their sorted order (no diversification) -> pinned host memory: hybrid_emit_body, below
+// hybrid_pool_kernel's helpers; this launch only exists for RLR_HYBRID_EMIT=split (the blend kernel emits by itself)
 __global__ __launch_bounds__(256) void hybrid_emit_kernel(const uint32_t *__restrict__ list, const float *__restrict__ comb,
                                                           const float *__restrict__ cosv, const float *__restrict__ lexv,
                                                           const uint32_t *__restrict__ info, uint32_t k_cap,
                                                           uint32_t *__restrict__ h_out)
 {
-    __shared__ uint32_t s_chk;
-    if (threadIdx.x == 0)
-        s_chk = 0;
-    __syncthreads();
-    const uint32_t n = info[1] ? 0u : min(info[0], k_cap);
-    uint32_t chk = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint32_t w0 = list[i], w1 = __builtin_bit_cast(uint32_t, cosv[i]), w2 = __builtin_bit_cast(uint32_t, comb[i]);
-        const uint32_t w3 = __builtin_bit_cast(uint32_t, lexv[i]);
-        h_out[i] = w0;
-        h_out[k_cap + i] = w1;
-        h_out[2 * k_cap + i] = w2;
-        h_out[3 * k_cap + i] = w3;
-        chk += result_chk_term(w0, i) + result_chk_term(w1, k_cap + i) + result_chk_term(w2, 2 * k_cap + i) +
-               result_chk_term(w3, 3 * k_cap + i);
-    }
-    if (chk)
-        atomicAdd(&s_chk, chk);
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) { // (the greedy kernel's emit tail writes the same four words)
-        h_out[4 * k_cap] = n;
-        h_out[4 * k_cap + 1] = info[1];
-        h_out[4 * k_cap + 2] = block_chk_tail(s_chk, n, info[1], k_cap);
-        __threadfence_system();
-        h_out[4 * k_cap + 3] = kBlockDone;
-    }
+    hybrid_emit_body(list, comb, cosv, lexv, info[1] ? 0u : min(info[0], k_cap), info[1], k_cap, h_out);
 }
 } // namespace rlr
 
@@ -3290,8 +3307,11 @@ static int32_t hybrid_finish_impl(HybridTicket *ticket, const HybridLexSrc &src,
     }
     RLR_HIP(launch_score_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_query, d_lrow, n_lex, d_lcos, s,
                               src.dev ? &d_hdr->n_lex : nullptr, n));
+    static const bool emit_split = getenv("RLR_HYBRID_EMIT") && !strcmp(getenv("RLR_HYBRID_EMIT"), "split"); // (A/B: its own launch)
+    const bool pool_emits = !t->diversify && !emit_split;
     hipLaunchKernelGGL(hybrid_pool_kernel, dim3(1), dim3(1024), 0, s, c->d_out, t->fetch, t->need, n, t->w_e, t->w_l, d_lrow,
-                       d_lscore, d_lcos, d_hdr, d_cand, c->d_list, d_comb, d_cos, d_lexv, d_info);
+                       d_lscore, d_lcos, d_hdr, d_cand, c->d_list, d_comb, d_cos, d_lexv, d_info, k_cap,
+                       pool_emits ? h_out : static_cast<uint32_t *>(nullptr));
     RLR_HIP(hipGetLastError());
     if (t->diversify) {
         RLR_HIP(launch_gram_rows(ix->d_rows, ix->pitch16, ix->dim, ix->dtype, c->d_list, P, d_gram, 1, s));
@@ -3304,7 +3324,7 @@ static int32_t hybrid_finish_impl(HybridTicket *ticket, const HybridLexSrc &src,
         emit.k_cap = k_cap;
         emit.h_out = h_out;
         RLR_HIP(launch_mmr_greedy(d_gram, d_comb, P, t->k, t->lambda, d_order, d_mmr, d_nsel, d_info, 1, s, &emit));
-    } else {
+    } else if (!pool_emits) {
         hipLaunchKernelGGL(hybrid_emit_kernel, dim3(1), dim3(256), 0, s, c->d_list, d_comb, d_cos, d_lexv, d_info, k_cap, h_out);
         RLR_HIP(hipGetLastError());
     }
