@@ -519,8 +519,17 @@ def config_shard_1of8(rlr, torch, sharded, args, headline_ms):
             "implied_speedup_8": headline_ms / (el * 1e3),
             "implied_note": "headline ms_per_step / this; an 8-rank all-gather of 6.4 KB is not in it",
             "candidates_per_query": p.n_candidates / max(p.n_searches, 1), "band_retries": p.n_retries,
-            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "scan_fixed_kernel", "kernel_ms": scan_ms, "bytes_per_launch": b}}
+            "roofline": scan_roofline(gbps, scan_ms, b)}
+
+
+def scan_roofline(gbps, scan_ms, b):
+    """roofline object of a single-query configuration: the scan kernel against the HBM peak; `traffic` from the committed
+    counter passes of this kernel at this shape (profiles/r*_pmc.json), under quote_traffic's same-build rule"""
+    roof = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+            "traffic": None, "kernel": "scan_fixed_kernel", "kernel_ms": scan_ms, "bytes_per_launch": b}
+    quote_traffic(roof, pmc_traffic(b, "scan_fixed_kernel"),
+                  "rocprofv3 --pmc passes of this kernel over an index of this shape, FETCH_SIZE x2 + WRITE_SIZE")
+    return roof
 
 
 def config_single(rlr, torch, args, n, seed, n_clusters, what, steps=30):
@@ -553,8 +562,7 @@ def config_single(rlr, torch, args, n, seed, n_clusters, what, steps=30):
     return {"workload": what, "value": 1.0 / el, "unit": "queries/s", "ms_per_step": el * 1e3,
             "stages_ms": {"scan": scan_ms, "select": p.select_ms / ns, "rescore_sort": p.rescore_ms / ns},
             "candidates_per_query": p.n_candidates / max(p.n_searches, 1), "band_retries": p.n_retries,
-            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "scan_fixed_kernel", "kernel_ms": scan_ms, "bytes_per_launch": b}}
+            "roofline": scan_roofline(gbps, scan_ms, b)}
 
 
 def in_process(args):

@@ -11,3 +11,8 @@ python3 profiles/summarize.py kernels r04_c2_text $G/r04_hyb_kt "python3 scratch
 python3 profiles/summarize.py kernels r04_c5_share $G/r04_c5_kt "python3 scratch/time_c5_shard.py --image  (6.25 M x 1024 binary16, 1024 queries, pool 308, MMR 0.7; steady state: second full-size pass)" "gemm8_kernel,gram_mfma_f32,batch_rescore,mmr_greedy,batch_band,batch_emit,batch_select" --pmc $G/r04_c5_fetch $G/r04_c5_write $G/r04_c5_sq $G/r04_c5_sq2 $G/r04_c5_sq3 > /dev/null
 for f in bench_under_rocprof bench_batch256_image_under_rocprof bench_batch256_under_rocprof bench_n1 bench_inprocess_n1; do cp $G/r04_$f.json profiles/r04_$f.json; done
 ls -la profiles/r04_*
+# (scratch/collect_r04_traffic.sh: the scan's counter traffic at the two per-GPU share shapes)
+if [ -d $G/r04_shard_fetch ] && [ -d $G/r04_c4_fetch ]; then
+python3 profiles/summarize.py r04_shard1of8 $G/r04_shard_kt $G/r04_shard_fetch $G/r04_shard_write "python3 scratch/time_shard_step.py  (1.25 M x 768 f32: one GPU's share of the headline at 8 GPUs)" > /dev/null
+python3 profiles/summarize.py r04_c4share $G/r04_c4_kt $G/r04_c4_fetch $G/r04_c4_write "python3 bench.py --rows 12500000 --steps 20 --warmup 3 --no-cpu --no-extras --settle-ms 500  (12.5 M x 768 f32: one GPU's share of config 4)" > /dev/null
+fi
