@@ -6,5 +6,4 @@ timeout -k 10 200 python3 $R/scratch/time_c2_hybrid.py hybrid-only > $O/${TAG}_t
 timeout -k 10 250 rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_kt -- python3 $R/scratch/time_c2_hybrid.py hybrid-only > $O/${TAG}_kt.log 2>&1 < /dev/null || { echo "profiled run failed"; exit 1; }
 f=$(ls $O/${TAG}_kt/*/*kernel_trace.csv | tail -n 1)
 python3 $R/scratch/text_timeline.py $f mmr_greedy > $O/${TAG}_timeline.txt; cat $O/${TAG}_timeline.txt
-python3 $R/scratch/text_timeline.py $f hybrid_emit > $O/${TAG}_timeline_nodiv.txt
 rm -rf $O/${TAG}_kt
